@@ -1,0 +1,165 @@
+"""Pin the CPU oracle (oracle/vocoder_oracle.py) against outputs of the reference itself.
+
+The fixtures under tests/golden/ were produced by tests/golden/make_golden.py,
+which imports the reference in the build container.  The reference holds no
+tests of its own for this path, so these are the pins.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from cases import sw
+from oracle import vocoder_oracle as O
+
+TOL = 2e-6  # abs; oracle and reference run the same ATen fp32 kernels in a different call structure
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def sdT(d):
+    return {k: T(v) for k, v in d.items()}
+
+
+def close(a, ref, tol=TOL):
+    a = a.numpy() if isinstance(a, torch.Tensor) else a
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    err = float(np.abs(a - ref).max())
+    assert err <= tol, err
+
+
+def test_weight_checksums():
+    import json, os
+    want = json.load(open(os.path.join(cases.GOLDEN_DIR, "weights_checksums.json")))
+    sd = cases.full_model_weights(skip_enc_q=False)
+    assert len(sd) == 659 and set(sd) == set(want)
+    bad = [k for k, v in sd.items() if sw.checksum(v) != want[k]]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("name", list(cases.INFER_CASES))
+def test_infer(name):
+    c = cases.INFER_CASES[name]
+    mel, ln, eps = cases.infer_inputs(name)
+    sd = sdT(cases.full_model_weights())
+    with torch.no_grad():
+        o, mask, (z, z_p, m_p, logs_p) = O.infer(sd, T(mel), T(ln), T(eps), c["noise_scale"], c["max_len"])
+    g = cases.golden("infer_" + name)
+    close(mask, g["mask"], 0)
+    close(m_p, g["m_p"]); close(logs_p, g["logs_p"]); close(z_p, g["z_p"], 4e-6); close(z, g["z"], 4e-6)
+    close(o, g["o"], 1e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.RESBLOCK1_CASES))
+def test_resblock1(name):
+    c = cases.RESBLOCK1_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.resblock1_shapes(c["C"], c["k"]), c["seed"], 1.0))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["C"], c["L"]), 0.5))
+    mask = T(cases.lengths_mask(c["mask_lengths"], c["L"])) if "mask_lengths" in c else None
+    close(O.resblock1(sd, "", x, c["k"], c["d"], mask), cases.golden(name)["y"], 4e-6)
+
+
+@pytest.mark.parametrize("name", list(cases.RESBLOCK2_CASES))
+def test_resblock2(name):
+    c = cases.RESBLOCK2_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.resblock2_shapes(c["C"], c["k"]), c["seed"], 1.0))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["C"], c["L"]), 0.5))
+    close(O.resblock2(sd, "", x, c["k"], c["d"]), cases.golden(name)["y"], 4e-6)
+
+
+@pytest.mark.parametrize("name", list(cases.UPS_CASES))
+def test_ups(name):
+    c = cases.UPS_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.ups_shapes(c["Ci"], c["Co"], c["k"]), c["seed"], 1.0))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["Ci"], c["L"]), 0.5))
+    w = O.fold_weight_norm(sd["weight_v"], sd["weight_g"])
+    y = torch.nn.functional.conv_transpose1d(torch.nn.functional.leaky_relu(x, 0.1), w, sd["bias"], stride=c["s"],
+                                             padding=(c["k"] - c["s"]) // 2)
+    close(y, cases.golden(name)["y"], 4e-6)
+
+
+@pytest.mark.parametrize("name", list(cases.WN_CASES))
+def test_wn(name):
+    c = cases.WN_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.wn_shapes(c["H"], c["k"], c["n"], c["gin"]), c["seed"]))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["H"], c["T"]), 1.0))
+    mask = T(cases.lengths_mask(c["lengths"], c["T"]))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["gin"], 1), 1.0)) if c["gin"] else None
+    y = O.wn(sd, "", x * mask, mask, g, hidden=c["H"], kernel_size=c["k"], dilation_rate=c["dr"], n_layers=c["n"])
+    close(y, cases.golden(name)["y"], 4e-6)
+
+
+@pytest.mark.parametrize("name", list(cases.COUPLING_CASES))
+def test_coupling(name):
+    c = cases.COUPLING_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.coupling_shapes(c["C"], c["H"], c["k"], c["n"], c["gin"], c["mean_only"]), c["seed"]))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["C"], c["T"]), 1.0))
+    mask = T(cases.lengths_mask(c["lengths"], c["T"]))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["gin"], 1), 1.0)) if c["gin"] else None
+    r = O.coupling(sd, "", x, mask, g, reverse=c["reverse"], hidden=c["H"], kernel_size=c["k"], dilation_rate=c["dr"],
+                   n_layers=c["n"], mean_only=c["mean_only"])
+    gold = cases.golden(name)
+    if c["reverse"]:
+        close(r, gold["y"], 4e-6)
+    else:
+        close(r[0], gold["y"], 4e-6)
+        close(r[1], gold["logdet"], 1e-4)
+
+
+@pytest.mark.parametrize("name", list(cases.FLOWBLOCK_CASES))
+def test_flowblock(name):
+    c = cases.FLOWBLOCK_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.flowblock_shapes(c["n"]), c["seed"]))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], 192, c["T"]), 1.0))
+    mask = T(cases.lengths_mask(c["lengths"], c["T"]))
+    y = O.flow(sd, x, mask, None, reverse=c["reverse"], prefix="", n_layers=c["n"])
+    close(y, cases.golden(name)["y"], 4e-6)
+
+
+@pytest.mark.parametrize("name", list(cases.GENERATOR_CASES))
+def test_generator(name):
+    c = cases.GENERATOR_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.generator_shapes(c), c["seed"], 1.0))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["initial_channel"], c["T"]), 1.0))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["gin"], 1), 1.0)) if c["gin"] else None
+    y = O.generator(sd, x, g, prefix="", resblock=c["resblock"], resblock_kernel_sizes=c["rks"],
+                    resblock_dilation_sizes=c["rds"], upsample_rates=c["ur"], upsample_kernel_sizes=c["uks"])
+    close(y, cases.golden(name)["y"], 1e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.DDS_CASES))
+def test_dds(name):
+    c = cases.DDS_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.dds_shapes(c["C"], c["k"], c["n"]), c["seed"], 1.0))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["C"], c["T"]), 1.0))
+    mask = T(cases.lengths_mask(c["lengths"], c["T"]))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["C"], c["T"]), 0.5)) if c["with_g"] else None
+    close(O.dds_conv(sd, "", x, mask, g, kernel_size=c["k"], n_layers=c["n"]), cases.golden(name)["y"], 1e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.CONVFLOW_CASES))
+def test_convflow(name):
+    c = cases.CONVFLOW_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.convflow_shapes(c["Cin"], c["F"], c["k"], c["n"]), c["seed"], 2.0))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["Cin"], c["T"]), 2.5))
+    mask = T(cases.lengths_mask(c["lengths"], c["T"]))
+    r = O.conv_flow(sd, "", x, mask, None, reverse=c["reverse"], filter_channels=c["F"], kernel_size=c["k"],
+                    n_layers=c["n"])
+    gold = cases.golden(name)
+    if c["reverse"]:
+        close(r, gold["y"], 2e-5)
+    else:
+        close(r[0], gold["y"], 2e-5)
+        close(r[1], gold["logdet"], 1e-3)
+
+
+@pytest.mark.parametrize("name", list(cases.SPLINE_CASES))
+def test_spline(name):
+    c = cases.SPLINE_CASES[name]
+    x, uw, uh, ud = cases.spline_inputs(name)
+    y, lad = O.rq_spline_linear_tails(T(x), T(uw), T(uh), T(ud), inverse=c["inverse"], tail_bound=5.0)
+    gold = cases.golden(name)
+    close(y, gold["y"], 2e-6)
+    close(lad, gold["logabsdet"], 2e-5)
