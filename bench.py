@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the SMART-Vocoder inference path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--frames 512]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = SynthesizerTrn.infer over one batch of synthetic mels (BASELINE.json configs[1]:
+iitp_base, batch 16 x 512 frames per GPU, 22.05 kHz), inputs resident in HBM.  Metric: audio samples/s
+(whole job).  Weak scaling: every rank runs its own 16x512 shard; rank 0 owns the job's batch
+(scattered over RCCL before the timed region) and receives all waveforms (gather inside the timed region).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_SAMPLE = 2568280.0          # 2*MAC of the 184 convolutions per output sample
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+SAMPLE_RATE = 22050
+
+
+def cpu_baseline(sd_np, B, T, seed):
+    """The CPU oracle (oracle/vocoder_oracle.py, a port of the reference forward) timed on the host cores on a
+    bounded sample of the same workload: B utterances of T frames."""
+    from oracle import vocoder_oracle as O
+    from cases import sw
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    with torch.no_grad():
+        mel = torch.from_numpy(sw.synthetic_mel(seed, 1, 32)); eps = torch.from_numpy(sw.synthetic_eps(seed, 1, 32))
+        O.infer(sd, mel, torch.tensor([32]), eps, 0.667)          # thread-pool / allocator warm-up
+        mel = torch.from_numpy(sw.synthetic_mel(seed, B, T)); eps = torch.from_numpy(sw.synthetic_eps(seed, B, T))
+        ln = torch.full((B,), T, dtype=torch.int64)
+        t0 = time.perf_counter()
+        o, *_ = O.infer(sd, mel, ln, eps, 0.667)
+        dt = time.perf_counter() - t0
+    return dict(value=o.numel() / dt, unit="samples/s", cores=cores, kind="port",
+                sample=f"{B}x{T} frames of the same synthetic workload, one pass, {dt:.2f} s, torch {torch.__version__} fp32 oneDNN")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=512, help="mel frames per utterance")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    args = ap.parse_args()
+
+    import cases
+    from cases import sw
+    from smart_vocoder_amd import models, parallel, _native
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, T = args.batch, args.frames
+    sd_np = cases.full_model_weights(skip_enc_q=True)
+    net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    net = net.to(dev).eval()
+
+    # the job's batch lives on rank 0 and is scattered once (RCCL over xGMI); shards stay resident in HBM
+    Bj = B * world
+    if world > 1:
+        if rank == 0:
+            mel_j = torch.from_numpy(sw.synthetic_mel(1001, Bj, T)).to(dev)
+            eps_j = torch.from_numpy(sw.synthetic_eps(1001, Bj, T)).to(dev)
+            ln_j = torch.full((Bj,), T, dtype=torch.int64, device=dev)
+            full = [mel_j, ln_j, eps_j]
+        else:
+            full = None
+        mel, ln, eps = parallel.scatter_batch(full, [(80, T), (), (192, T)], [torch.float32, torch.int64, torch.float32],
+                                              Bj, src=0, device=dev)
+    else:
+        mel = torch.from_numpy(sw.synthetic_mel(1001, B, T)).to(dev)
+        eps = torch.from_numpy(sw.synthetic_eps(1001, B, T)).to(dev)
+        ln = torch.full((B,), T, dtype=torch.int64, device=dev)
+
+    def step():
+        o = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+        if world > 1:
+            return parallel.gather_waveforms(o, Bj, dst=0)
+        return o
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        _native.stats_reset()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                     # the HIP kernels are enqueued on torch's current stream
+        for _ in range(args.steps):
+            out = step()
+        ev1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    stats = _native.stats_get()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        samples_per_step = Bj * T * net.dec.hop
+        value = samples_per_step * args.steps / dt
+        # dominant kernel family: conv_mfma_kernel<...> (every convolution of the path).  Algorithmic FLOPs of the
+        # launches in the timed region (counted by the library, 2*MAC) over the device time of the region measured
+        # with HIP events on the launch stream (includes the few % spent in the small non-GEMM kernels).
+        conv_tflops = stats["conv_flops"] / (gpu_ms * 1e-3) / 1e12
+        res = {
+            "metric": "audio samples/sec (22.05 kHz), iitp_base batch 16 per GPU",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs/iitp_base.json SynthesizerTrn.infer, {B}x{T}-frame synthetic mels per GPU "
+                                   f"(BASELINE.json configs[1]), noise_scale 0.667, random-init trained-like weights",
+                       "global_batch": Bj, "frames": T, "samples_per_step": samples_per_step, "parallelism": f"dp{world}"},
+            "real_time_factor": value / SAMPLE_RATE / world,
+            "samples_per_s_per_gpu": value / world,
+            "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv, all instantiations)",
+                         "launches_per_step": stats["conv_launches"] / args.steps,
+                         "flop_per_step": stats["conv_flops"] / args.steps,
+                         "gpu_ms_per_step_rank0": gpu_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_sample_batch, T, 1001)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

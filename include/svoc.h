@@ -1,0 +1,212 @@
+/*
+ * svoc.h — C ABI of libsvoc_hip.so: the MI355X (gfx950) implementation of the
+ * SMART-Vocoder inference path.
+ *
+ * The reference (SMART-TTS/SMART-Vocoder) is pure Python/PyTorch and has no
+ * FFI of its own; the drop-in boundary is its Python surface (models.py /
+ * modules.py / transforms.py).  Each entry point below is what a ctypes
+ * binding of one reference class or function would call; the reference
+ * interface it replaces is cited as file:line (relative to the reference repo).
+ * `smart-vocoder_amd/_native.py` is that binding; INTEGRATION.md shows the stub
+ * a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every tensor is fp32, device memory, contiguous NCW unless a stride is
+ *     given; lengths are int64 device memory;
+ *   - every function returns 0 on success or a negative svoc_status and never
+ *     throws, exits or synchronises the device (create/destroy functions may
+ *     block while they upload and repack weights);
+ *   - work is enqueued on the caller's hipStream_t (passed as void*); handles
+ *     are per-device and not thread-safe; the caller selects the device
+ *     (hipSetDevice) before create;
+ *   - the library owns packed weights and its activation workspace (grow-only
+ *     hipMalloc), the caller owns all inputs and outputs;
+ *   - state-dict tables: weights are handed over as an array of svoc_tensor
+ *     named exactly like the reference's state_dict keys below a prefix
+ *     (e.g. "in_layers.0.weight_v"); weight-norm pairs (weight_g, weight_v) are
+ *     folded on the device at create time (reference: torch weight_norm at
+ *     modules.py:128,135,145,191-206, models.py:125; removal models.py:162-167).
+ */
+#ifndef SVOC_H
+#define SVOC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum svoc_status {
+  SVOC_OK = 0,
+  SVOC_ERR_INVALID_ARG = -1,
+  SVOC_ERR_MISSING_TENSOR = -2,
+  SVOC_ERR_SHAPE = -3,
+  SVOC_ERR_HIP = -4,
+  SVOC_ERR_UNSUPPORTED = -5,
+  SVOC_ERR_NOMEM = -6
+} svoc_status;
+
+typedef struct svoc_tensor {
+  const char* name;    /* state_dict key below the module prefix */
+  const float* data;   /* device pointer, fp32, contiguous */
+  int32_t ndim;
+  int64_t shape[4];
+} svoc_tensor;
+
+/* Library / error reporting ------------------------------------------------ */
+int svoc_abi_version(void);
+const char* svoc_last_error(void);       /* thread-local message of the last failure */
+const char* svoc_build_arch(void);       /* "gfx950" */
+/* Launch statistics of the implicit-GEMM convolution kernel since the last
+ * reset: number of launches and algorithmic FLOPs (2*MAC) — used by bench.py's
+ * roofline block. */
+int svoc_stats_reset(void);
+int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches);
+
+/* ---- modules.WN (modules.py:111-185) ------------------------------------- */
+typedef struct svoc_wn svoc_wn;
+/* tensors: in_layers.{i}.{bias,weight_g,weight_v}, res_skip_layers.{i}.*, cond_layer.* if gin_channels>0 */
+int svoc_wn_create(svoc_wn** out, int hidden_channels, int kernel_size, int dilation_rate, int n_layers,
+                   int gin_channels, const svoc_tensor* tensors, int n_tensors, const char* prefix);
+/* WN.forward(x, x_mask, g) (modules.py:148-176): x [B,H,T], x_mask [B,1,T], g NULL or [B,gin,Tg] (Tg==1 or T),
+ * out [B,H,T]. */
+int svoc_wn_forward(svoc_wn* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T,
+                    float* out, int B, int T);
+void svoc_wn_destroy(svoc_wn* h);
+
+/* ---- modules.ResBlock1 / ResBlock2 (modules.py:187-256) ------------------- */
+typedef struct svoc_resblock svoc_resblock;
+/* kind 1: convs1.{0..n-1}.*, convs2.{0..n-1}.* ; kind 2: convs.{0..n-1}.* ; n = n_dilations */
+int svoc_resblock_create(svoc_resblock** out, int kind, int channels, int kernel_size, const int* dilations,
+                         int n_dilations, const svoc_tensor* tensors, int n_tensors, const char* prefix);
+/* forward(x, x_mask=None): x,y [B,C,L]; x_mask NULL or [B,1,L] */
+int svoc_resblock_forward(svoc_resblock* h, void* stream, const float* x, const float* x_mask, float* y, int B, int L);
+void svoc_resblock_destroy(svoc_resblock* h);
+
+/* ---- modules.ResidualCouplingLayer (modules.py:298-343) ------------------- */
+typedef struct svoc_coupling svoc_coupling;
+/* tensors: pre.{weight,bias}, enc.<WN tensors>, post.{weight,bias} */
+int svoc_coupling_create(svoc_coupling** out, int channels, int hidden_channels, int kernel_size, int dilation_rate,
+                         int n_layers, int gin_channels, int mean_only, const svoc_tensor* tensors, int n_tensors,
+                         const char* prefix);
+/* forward(x, x_mask, g, reverse): x,y [B,C,T]; logdet [B] written when reverse==0 (may be NULL) */
+int svoc_coupling_forward(svoc_coupling* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T,
+                          int reverse, float* y, float* logdet, int B, int T);
+void svoc_coupling_destroy(svoc_coupling* h);
+
+/* ---- models.ResidualCouplingBlock (models.py:50-80) incl. modules.Flip (modules.py:270-277) */
+typedef struct svoc_flow svoc_flow;
+/* tensors: flows.{0,2,4,..}.<coupling tensors>; Flips are folded into channel-permuted weights */
+int svoc_flow_create(svoc_flow** out, int channels, int hidden_channels, int kernel_size, int dilation_rate,
+                     int n_layers, int n_flows, int gin_channels, const svoc_tensor* tensors, int n_tensors,
+                     const char* prefix);
+int svoc_flow_forward(svoc_flow* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T,
+                      int reverse, float* y, int B, int T);
+void svoc_flow_destroy(svoc_flow* h);
+
+/* ---- models.Generator (models.py:115-167) --------------------------------- */
+typedef struct svoc_generator svoc_generator;
+typedef struct svoc_generator_config {
+  int32_t initial_channel;
+  int32_t resblock_kind;                 /* 1 or 2 ("resblock": "1"|"2") */
+  int32_t n_kernels;                     /* len(resblock_kernel_sizes) <= 8 */
+  int32_t resblock_kernel_sizes[8];
+  int32_t n_dilations[8];
+  int32_t resblock_dilation_sizes[8][8];
+  int32_t n_upsamples;                   /* <= 8 */
+  int32_t upsample_rates[8];
+  int32_t upsample_kernel_sizes[8];
+  int32_t upsample_initial_channel;
+  int32_t gin_channels;
+} svoc_generator_config;
+/* tensors: conv_pre.*, ups.{i}.*, resblocks.{j}.*, conv_post.weight, cond.* if gin_channels>0 */
+int svoc_generator_create(svoc_generator** out, const svoc_generator_config* cfg, const svoc_tensor* tensors,
+                          int n_tensors, const char* prefix);
+/* Generator.forward(x, g): x [B,initial_channel,T] with row stride x_ld (>=T), optional input mask [B,1,*]
+ * (infer passes z*x_mask, models.py:338), g NULL or [B,gin,1]; out [B,1,T*prod(upsample_rates)]. */
+int svoc_generator_forward(svoc_generator* h, void* stream, const float* x, int x_ld, int64_t x_bs,
+                           const float* in_mask, int64_t in_mask_bs, const float* g, float* out, int B, int T);
+void svoc_generator_destroy(svoc_generator* h);
+
+/* ---- models.SynthesizerTrn.infer (models.py:266-339) ---------------------- */
+typedef struct svoc_synth svoc_synth;
+typedef struct svoc_synth_config {
+  int32_t n_mel;                 /* 80: MelEncoder.pre_enc in-channels (models.py:32) */
+  int32_t inter_channels;        /* 192 */
+  int32_t hidden_channels;       /* 192 */
+  int32_t enc_n_layers;          /* 16  (models.py:308) */
+  int32_t enc_kernel_size;       /* 5 */
+  int32_t enc_dilation_rate;     /* 1 */
+  int32_t flow_n_layers;         /* 8   (models.py:314) */
+  int32_t flow_kernel_size;      /* 5 */
+  int32_t flow_dilation_rate;    /* 1 */
+  int32_t flow_n_flows;          /* 4 */
+  int32_t gin_channels;          /* 256 (conditioning weights exist but infer passes g=None, models.py:332) */
+  svoc_generator_config dec;
+} svoc_synth_config;
+/* tensors: the reference state_dict (enc_p.*, flow.*, dec.*; enc_q.* ignored) */
+int svoc_synth_create(svoc_synth** out, const svoc_synth_config* cfg, const svoc_tensor* tensors, int n_tensors);
+/* infer(x, x_lengths, noise_scale, max_len) with the randn_like draw (models.py:336) supplied by the caller:
+ *   mel [B,n_mel,T]; lengths int64 [B]; eps [B,inter,T] or NULL (then noise_scale must be 0);
+ *   max_len <= 0 means None; outputs (any may be NULL except o):
+ *   o [B,1,min(T,max_len)*hop], x_mask [B,1,T], z,z_p,m_p,logs_p [B,inter,T]. */
+int svoc_synth_infer(svoc_synth* h, void* stream, const float* mel, const int64_t* lengths, const float* eps,
+                     float noise_scale, int max_len, float* o, float* x_mask, float* z, float* z_p, float* m_p,
+                     float* logs_p, int B, int T);
+int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T);
+int svoc_synth_hop(svoc_synth* h);         /* prod(upsample_rates) */
+void svoc_synth_destroy(svoc_synth* h);
+
+/* ---- modules.DDSConv (modules.py:70-108) ---------------------------------- */
+typedef struct svoc_dds svoc_dds;
+/* tensors: convs_sep.{i}.{weight,bias}, convs_1x1.{i}.{weight,bias}, norms_1.{i}.{gamma,beta}, norms_2.{i}.* */
+int svoc_dds_create(svoc_dds** out, int channels, int kernel_size, int n_layers, const svoc_tensor* tensors,
+                    int n_tensors, const char* prefix);
+/* forward(x, x_mask, g): x,y [B,C,T]; g NULL or [B,C,T] */
+int svoc_dds_forward(svoc_dds* h, void* stream, const float* x, const float* x_mask, const float* g, float* y, int B,
+                     int T);
+void svoc_dds_destroy(svoc_dds* h);
+
+/* ---- modules.ConvFlow (modules.py:346-390) -------------------------------- */
+typedef struct svoc_convflow svoc_convflow;
+/* tensors: pre.*, convs.<DDSConv tensors>, proj.* */
+int svoc_convflow_create(svoc_convflow** out, int in_channels, int filter_channels, int kernel_size, int n_layers,
+                         int num_bins, float tail_bound, const svoc_tensor* tensors, int n_tensors, const char* prefix);
+int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const float* x_mask, const float* g,
+                          int reverse, float* y, float* logdet, int B, int T);
+void svoc_convflow_destroy(svoc_convflow* h);
+
+/* ---- transforms.piecewise_rational_quadratic_transform (transforms.py:12-193), tails='linear' or none */
+/* inputs [n]; unnormalized widths/heights [n,num_bins]; derivatives [n,num_bins-1] (linear tails) or
+ * [n,num_bins+1] (tails==0, domain [0,1]); outputs, logabsdet [n]. */
+int svoc_rq_spline(void* stream, const float* inputs, const float* unnorm_widths, const float* unnorm_heights,
+                   const float* unnorm_derivs, int64_t n, int num_bins, int inverse, int linear_tails,
+                   float tail_bound, float* outputs, float* logabsdet);
+
+/* ---- single ops (unit-testable pieces of the path) ------------------------- */
+/* commons.sequence_mask (commons.py:121-125) as float [B,1,T] */
+int svoc_sequence_mask(void* stream, const int64_t* lengths, float* mask, int B, int T);
+/* commons.fused_add_tanh_sigmoid_multiply (commons.py:100-107): a,b [B,2H,T] -> acts [B,H,T] */
+int svoc_fused_add_tanh_sigmoid_multiply(void* stream, const float* a, const float* b, float* acts, int B, int H, int T);
+/* modules.Flip (modules.py:270-277): y[b][c] = x[b][C-1-c]; x,y [B,C,T] */
+int svoc_flip_channels(void* stream, const float* x, float* y, int B, int C, int T);
+/* torch.nn.utils.remove_weight_norm (models.py:162-167, modules.py:178-184): w = g * v / ||v||, norm over all
+ * dims but 0; v,w [d0, inner], g [d0] */
+int svoc_fold_weight_norm(void* stream, const float* weight_v, const float* weight_g, float* weight, int64_t d0,
+                          int64_t inner);
+/* F.leaky_relu -> (weight-normed) Conv1d with "same" zero padding (commons.get_padding, commons.py:14-15)
+ * [-> + residual]: the decoder's unit of work (modules.py:212-218).  weight_g may be NULL (plain conv).
+ * x [B,Cin,L], y [B,Cout,L], residual NULL or [B,Cout,L]; pre_slope 1.0 = no activation. */
+int svoc_conv1d(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias,
+                const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation,
+                float pre_slope);
+/* F.leaky_relu -> weight-normed ConvTranspose1d(k, stride, padding=(k-stride)//2) (models.py:125-127, 147-148):
+ * x [B,Cin,L], weight_v [Cin,Cout,k], weight_g [Cin,1,1] or NULL, y [B,Cout,L*stride] */
+int svoc_conv_transpose1d(void* stream, const float* x, const float* weight_v, const float* weight_g,
+                          const float* bias, float* y, int B, int Cin, int Cout, int L, int kernel_size, int stride,
+                          float pre_slope);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVOC_H */

@@ -1,0 +1,398 @@
+// Implicit-GEMM 1-D convolution on the gfx950 FP32 matrix cores.
+//
+// One kernel family covers every convolution of the SMART-Vocoder inference
+// path (reference models.py:32-33,120-135; modules.py:127-146,190-207,318-320):
+//   D[M = out-channel rows][N = time] = sum_{tap j, in-channel c} W[row][c][j] * act(x[c][n + j*dil - pad])
+// computed with v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//
+// Mapping to the hardware
+//   * M = output channels, N = time: the MFMA C/D layout puts 32 consecutive
+//     time steps of one channel in the 32 lanes of a half-wave, so every
+//     accumulator register stores as 128-byte contiguous NCW segments.
+//   * B operand (activations): a [KC=32 channels][BN + dilation halo] tile is
+//     staged ONCE per input-channel chunk into LDS with 16-byte coalesced
+//     loads; the leaky-relu that precedes the conv in the reference
+//     (modules.py:212,216; models.py:147) and the optional x*x_mask are applied
+//     while staging, and out-of-range positions are written as zeros (the
+//     conv's own zero padding, commons.py:14-15).  All k taps re-read the same
+//     tile at shifted columns (ds_read_b32, 32 consecutive lanes = 32
+//     consecutive banks, conflict-free).
+//   * A operand (weights): repacked at load time into MFMA fragment order
+//     (pack.hip) so one global_load_dwordx4 per lane feeds four k-steps; the
+//     stream is shared by every time tile of every utterance, stays L2
+//     resident, and is prefetched one group ahead in registers.
+//   * Each wave owns MR x NR 32x32 accumulator tiles; fused epilogues (bias,
+//     residual, MRF accumulate, masks, WN gate, reparameterisation, coupling,
+//     polyphase ConvTranspose scatter) run from the accumulators.
+#include "svoc_internal.h"
+
+#include <algorithm>
+
+namespace svoc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr unsigned F_VECST = 1u << 16;   // internal: float4 stores legal for EPI_UPS
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float pick4(const float4& v, int s) {
+  return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
+}
+
+template <int WM, int WN, int MR, int NR>
+__global__ void __launch_bounds__(WM* WN * 64) conv_mfma_kernel(const ConvArgs p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BN = WN * NR * 32;
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * BN;
+  const int mt0 = (blockIdx.y * WM + wm) * MR;
+  const int ncol0 = n0 + wn * NR * 32;
+  const bool wave_active = (mt0 < p.mtiles) && (ncol0 < p.Ncols);
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mr][nr][i] = 0.0f;
+
+  // ---- weight fragment stream (prefetched one group of 4 k-steps ahead)
+  const float4* wp4 = reinterpret_cast<const float4*>(p.wp);
+  long long abase[MR];
+  float4 a_cur[MR], a_nxt[MR];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    const int mt = min(mt0 + mr, p.mtiles - 1);
+    abase[mr] = (long long)mt * p.ksg_total * 64 + lane;
+    a_cur[mr] = wp4[abase[mr]];
+  }
+  int ksg = 0;
+  const int ksg_last = p.ksg_total - 1;
+
+  const int R4 = p.row_len >> 2;
+  const int xs_start = n0 + p.xoff0;
+  const float* xb = p.x + (long long)b * p.x_bs;
+  const float* mb = p.in_mask ? p.in_mask + (long long)b * p.in_mask_bs : nullptr;
+  const float slope = p.pre_slope;
+  const bool act = slope != 1.0f;
+  const float* bp0 = xs + hi * p.row_len + (wn * NR * 32 + l31 - p.pad - p.xoff0);
+
+  for (int ch = 0; ch < p.nchunks; ++ch) {
+    __syncthreads();
+    // ---- stage [KC][row_len] activations, zero-filled outside [0,Lin) and beyond Cin
+    const int c0 = ch * KC;
+    for (int idx = tid; idx < KC * R4; idx += NT) {
+      const int c = idx / R4;
+      const int g4 = idx - c * R4;
+      const int gc = c0 + c;
+      const int t = xs_start + 4 * g4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
+        const float* row = xb + (long long)gc * p.x_ld;
+        if (p.vec4 && t >= 0 && t + 3 < p.Lin) {
+          v = *reinterpret_cast<const float4*>(row + t);
+        } else {
+          if (t >= 0 && t < p.Lin) v.x = row[t];
+          if (t + 1 >= 0 && t + 1 < p.Lin) v.y = row[t + 1];
+          if (t + 2 >= 0 && t + 2 < p.Lin) v.z = row[t + 2];
+          if (t + 3 >= 0 && t + 3 < p.Lin) v.w = row[t + 3];
+        }
+        if (act) {
+          v.x = v.x > 0.f ? v.x : v.x * slope;
+          v.y = v.y > 0.f ? v.y : v.y * slope;
+          v.z = v.z > 0.f ? v.z : v.z * slope;
+          v.w = v.w > 0.f ? v.w : v.w * slope;
+        }
+        if (mb) {
+          if (t >= 0 && t < p.Lin) v.x *= mb[t];
+          if (t + 1 >= 0 && t + 1 < p.Lin) v.y *= mb[t + 1];
+          if (t + 2 >= 0 && t + 2 < p.Lin) v.z *= mb[t + 2];
+          if (t + 3 >= 0 && t + 3 < p.Lin) v.w *= mb[t + 3];
+        }
+      }
+      *reinterpret_cast<float4*>(xs + c * p.row_len + 4 * g4) = v;
+    }
+    __syncthreads();
+
+    if (wave_active) {
+      for (int j = 0; j < p.ktaps; ++j) {
+        const float* bp = bp0 + j * p.dil;
+#pragma unroll
+        for (int g = 0; g < KC / 8; ++g) {
+          ++ksg;
+          const int kn = ksg < ksg_last ? ksg : ksg_last;
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) a_nxt[mr] = wp4[abase[mr] + (long long)kn * 64];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float* br = bp + (g * 8 + 2 * s) * p.row_len;
+            float bf[NR];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) bf[nr] = br[nr * 32];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+              const float av = pick4(a_cur[mr], s);
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[nr], acc[mr][nr], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) a_cur[mr] = a_nxt[mr];
+        }
+      }
+    }
+  }
+
+  if (!wave_active) return;
+
+  // ------------------------------------------------------------------ epilogues
+  const float* maskb = p.mask ? p.mask + (long long)b * p.mask_bs : nullptr;
+  const float* gaddb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
+
+  if (p.mode == EPI_PLAIN) {
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      if (mt0 + mr >= p.mtiles) break;
+      // split_row is a multiple of 32, so the output set is uniform per accumulator tile
+      const int trow0 = (mt0 + mr) * 32;
+      const bool sel = trow0 >= p.split_row;
+      float* const oy = sel ? p.out[1].y : p.out[0].y;
+      if (oy == nullptr) continue;
+      const long long oy_bs = sel ? p.out[1].y_bs : p.out[0].y_bs;
+      const int oy_ld = sel ? p.out[1].y_ld : p.out[0].y_ld;
+      const float* const ores = sel ? p.out[1].res : p.out[0].res;
+      const long long ores_bs = sel ? p.out[1].res_bs : p.out[0].res_bs;
+      const int ores_ld = sel ? p.out[1].res_ld : p.out[0].res_ld;
+      const unsigned fl = sel ? p.out[1].flags : p.out[0].flags;
+      const float odiv = sel ? p.out[1].div : p.out[0].div;
+      const int onrows = sel ? p.out[1].nrows : p.out[0].nrows;
+      const int rbase = sel ? trow0 - p.split_row : trow0;
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) {
+        const int col = ncol0 + nr * 32 + l31;
+        if (col >= p.Ncols) continue;
+        const float mk = maskb ? maskb[col] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int rr = rbase + lr;
+          if (rr >= onrows) continue;
+          float v = acc[mr][nr][r] + p.bias[trow0 + lr];
+          if (gaddb) v += gaddb[(long long)rr * p.gadd_ld + (long long)col * p.gadd_ts];
+          float* yp = oy + (long long)b * oy_bs + (long long)rr * oy_ld + col;
+          if (fl & (F_RES | F_CPL_REV | F_CPL_FWD)) {
+            const float rv = ores[(long long)b * ores_bs + (long long)rr * ores_ld + col];
+            if (fl & F_RES) v = v + rv;
+            else if (fl & F_CPL_REV) v = (rv - v * mk) * mk;
+            else v = v * mk + rv * mk;
+          }
+          if (fl & F_ACC) v = *yp + v;
+          if (fl & F_DIV) v = v / odiv;
+          if (fl & F_OUTMASK) v *= mk;
+          *yp = v;
+        }
+      }
+    }
+    return;
+  }
+
+  if (p.mode == EPI_UPS) {
+    const EpiOut& o = p.out[0];
+    const int s = p.ups_s;
+    float* yb = o.y + (long long)b * o.y_bs;
+    const bool vec = (o.flags & F_VECST) != 0;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      if (mt0 + mr >= p.mtiles) break;
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) {
+        const int col = ncol0 + nr * 32 + l31;
+        if (col >= p.Ncols) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row0 = (mt0 + mr) * 32 + 8 * q + 4 * hi;   // rows row0..row0+3 are accumulator regs 4q..4q+3
+          if (vec && row0 + 3 < o.nrows) {   // s == 8: the four rows are four consecutive output samples of one channel
+            const int oc = row0 >> 3;
+            const int n = col * 8 + (row0 & 7) - p.ups_pad;
+            float4 v;
+            v.x = acc[mr][nr][4 * q + 0] + p.bias[row0 + 0];
+            v.y = acc[mr][nr][4 * q + 1] + p.bias[row0 + 1];
+            v.z = acc[mr][nr][4 * q + 2] + p.bias[row0 + 2];
+            v.w = acc[mr][nr][4 * q + 3] + p.bias[row0 + 3];
+            float* yp = yb + (long long)oc * o.y_ld + n;
+            if (n >= 0 && n + 3 < p.Lout) {
+              *reinterpret_cast<float4*>(yp) = v;
+            } else {
+              if (n >= 0 && n < p.Lout) yp[0] = v.x;
+              if (n + 1 >= 0 && n + 1 < p.Lout) yp[1] = v.y;
+              if (n + 2 >= 0 && n + 2 < p.Lout) yp[2] = v.z;
+              if (n + 3 >= 0 && n + 3 < p.Lout) yp[3] = v.w;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = row0 + i;
+              const int oc = row / s;
+              const int n = col * s + (row - oc * s) - p.ups_pad;
+              if (row < o.nrows && n >= 0 && n < p.Lout) yb[(long long)oc * o.y_ld + n] = acc[mr][nr][4 * q + i] + p.bias[row];
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- paired-tile modes: accumulator tiles (mr, mr+1) hold the two halves of the same channels
+  if constexpr (MR % 2 == 0) {
+    const int H = p.half_rows;
+    const EpiOut& o = p.out[0];
+    float lsum = 0.0f;
+#pragma unroll
+    for (int mr = 0; mr < MR; mr += 2) {
+      if (mt0 + mr >= p.mtiles) break;
+      const int pi = (mt0 + mr) >> 1;
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) {
+        const int col = ncol0 + nr * 32 + l31;
+        if (col >= p.Ncols) continue;
+        const float mk = maskb ? maskb[col] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int chn = pi * 32 + rr;
+          if (chn >= H) continue;
+          const int rowA = (mt0 + mr) * 32 + rr;
+          float vA = acc[mr][nr][r] + p.bias[rowA];
+          float vB = acc[mr + 1][nr][r] + p.bias[rowA + 32];
+          const long long yo = (long long)b * o.y_bs + (long long)chn * o.y_ld + col;
+          if (p.mode == EPI_GATE) {
+            if (gaddb) {
+              vA += gaddb[(long long)chn * p.gadd_ld + (long long)col * p.gadd_ts];
+              vB += gaddb[(long long)(H + chn) * p.gadd_ld + (long long)col * p.gadd_ts];
+            }
+            o.y[yo] = tanhf(vA) * sigmoidf_(vB);
+          } else if (p.mode == EPI_PROJ) {
+            const float m = vA * mk, lg = vB * mk;
+            const float e = p.eps ? p.eps[(long long)b * p.eps_bs + (long long)chn * p.eps_ld + col] : 0.0f;
+            if (o.y) o.y[yo] = m;
+            if (p.y2) p.y2[yo] = lg;
+            if (p.y3) p.y3[yo] = m + e * expf(lg) * p.noise_scale;
+          } else {
+            const float m = vA * mk, lg = vB * mk;
+            const float x1 = o.res[(long long)b * o.res_bs + (long long)chn * o.res_ld + col];
+            if (p.mode == EPI_CPL_FULL_REV) {
+              o.y[yo] = (x1 - m) * expf(-lg) * mk;
+            } else {
+              o.y[yo] = m + x1 * expf(lg) * mk;
+              lsum += lg;
+            }
+          }
+        }
+      }
+    }
+    if (p.mode == EPI_CPL_FULL_FWD && p.logdet) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+      if (lane == 0) atomicAdd(p.logdet + b, lsum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+namespace {
+
+struct TileCfg { int WM, WN, MR, NR; };
+constexpr TileCfg CFG_A{4, 1, 2, 4};   // 256 rows x 128 cols
+constexpr TileCfg CFG_B{2, 2, 2, 2};   // 128 x 128
+constexpr TileCfg CFG_C{2, 2, 1, 4};   //  64 x 256
+constexpr TileCfg CFG_D{1, 4, 1, 4};   //  32 x 512
+constexpr TileCfg CFG_E{2, 2, 2, 1};   // 128 x  64  (short sequences, paired)
+constexpr TileCfg CFG_F{2, 2, 1, 1};   //  64 x  64  (short sequences)
+constexpr TileCfg CFG_G{1, 4, 1, 1};   //  32 x 128  (short sequences, odd tile counts)
+
+template <int WM, int WN, int MR, int NR>
+int launch_cfg(const ConvArgs& a, int B, hipStream_t st) {
+  constexpr int BN = WN * NR * 32;
+  auto kern = conv_mfma_kernel<WM, WN, MR, NR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  const size_t lds = (size_t)KC * a.row_len * sizeof(float);
+  if (lds > 96 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "conv LDS tile of %zu bytes exceeds 96 KiB (kernel %d taps, dilation %d)", lds, a.ktaps, a.dil);
+  dim3 grid((a.Ncols + BN - 1) / BN, (a.mtiles + WM * MR - 1) / (WM * MR), B);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, a);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+
+}  // namespace
+
+int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
+  if (B <= 0 || a.Ncols <= 0) return SVOC_OK;
+  a.wp = pc.wp.f();
+  a.bias = pc.bias.f();
+  a.Cin = pc.Cin;
+  a.nchunks = pc.CinP / KC;
+  a.ktaps = pc.ktaps;
+  a.dil = pc.dil;
+  a.pad = pc.pad;
+  a.mtiles = pc.mtiles;
+  a.ksg_total = pc.ksg_total;
+  a.half_rows = pc.half_rows;
+  a.ups_s = pc.ups_s;
+  a.ups_pad = pc.ups_pad;
+  a.vec4 = ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_ld & 3) == 0 && (a.x_bs & 3) == 0) ? 1 : 0;
+  if (a.mode == EPI_UPS) {
+    const EpiOut& o = a.out[0];
+    if (pc.ups_s == 8 && (pc.ups_pad & 3) == 0 && (reinterpret_cast<uintptr_t>(o.y) & 15) == 0 && (o.y_ld & 3) == 0 &&
+        (o.y_bs & 3) == 0)
+      a.out[0].flags |= F_VECST;
+  }
+  const bool needs_pair = a.mode >= EPI_GATE;
+  if (needs_pair && !pc.paired) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "paired epilogue on an unpaired convolution");
+
+  // tile configuration: rows per block must not leave whole waves idle; short sequences get narrow tiles
+  const int mt = pc.mtiles;
+  const bool shortN = a.Ncols <= 1024;
+  TileCfg c;
+  if (needs_pair) c = shortN ? CFG_E : CFG_B;
+  else if (shortN) c = (mt % 2 == 0) ? CFG_F : CFG_G;
+  else if (mt % 8 == 0) c = CFG_A;
+  else if (mt % 4 == 0) c = CFG_B;
+  else if (mt % 2 == 0) c = CFG_C;
+  else c = CFG_D;
+
+  const int BN = c.WN * c.NR * 32;
+  const int off_first = -pc.pad, off_last = (pc.ktaps - 1) * pc.dil - pc.pad;
+  const int minoff = std::min(off_first, off_last), maxoff = std::max(off_first, off_last);
+  a.xoff0 = minoff & ~3;                                  // floor to a multiple of 4 (two's complement)
+  a.row_len = round_up(BN + maxoff - a.xoff0, 4);
+
+  stats_add_conv(pc.flops_per_col * (double)B * (double)(pc.transposed ? a.Lin : a.Ncols));
+
+#define SVOC_LAUNCH(C) if (c.WM == C.WM && c.WN == C.WN && c.MR == C.MR && c.NR == C.NR) return launch_cfg<C.WM, C.WN, C.MR, C.NR>(a, B, st)
+  SVOC_LAUNCH(CFG_A);
+  SVOC_LAUNCH(CFG_B);
+  SVOC_LAUNCH(CFG_C);
+  SVOC_LAUNCH(CFG_D);
+  SVOC_LAUNCH(CFG_E);
+  SVOC_LAUNCH(CFG_F);
+  SVOC_LAUNCH(CFG_G);
+#undef SVOC_LAUNCH
+  SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "no tile configuration");
+}
+
+}  // namespace svoc

@@ -1,0 +1,685 @@
+// Module graph of the SMART-Vocoder inference path, expressed as launch plans over
+// the MFMA convolution kernel (conv_mfma.hip) and the small kernels (misc_kernels.hip).
+// Every object mirrors one reference class (file:line in include/svoc.h); the host
+// code here only sequences launches on the caller's stream.
+#include "svoc_internal.h"
+
+#include <cstring>
+#include <new>
+
+namespace svoc {
+
+static ConvArgs mk_args() {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pre_slope = 1.0f;
+  a.split_row = 1 << 30;
+  a.mode = EPI_PLAIN;
+  a.out[0].nrows = 1 << 30;
+  a.out[1].nrows = 1 << 30;
+  return a;
+}
+static void set_in(ConvArgs& a, const float* x, long long bs, int ld, int Lin) { a.x = x; a.x_bs = bs; a.x_ld = ld; a.Lin = Lin; }
+static void set_out(EpiOut& o, float* y, long long bs, int ld, int nrows, unsigned flags = 0) {
+  o.y = y; o.y_bs = bs; o.y_ld = ld; o.nrows = nrows; o.flags = flags; o.div = 1.0f;
+}
+static void set_res(EpiOut& o, const float* r, long long bs, int ld) { o.res = r; o.res_bs = bs; o.res_ld = ld; }
+static inline int pad4(int n) { return round_up(n, 4); }
+
+// =================================================================== WN (modules.py:111-185)
+struct WNStack {
+  int H = 0, K = 0, DR = 1, NL = 0, gin = 0;
+  std::vector<std::unique_ptr<PackedConv>> in_l, rs_l;
+  std::unique_ptr<PackedConv> cond;
+  DevBuf ws;
+
+  int create(int hidden, int k, int dr, int nl, int gin_, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
+    if (hidden <= 0 || k <= 0 || (k % 2) == 0 || nl <= 0 || dr <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "WN: bad hyper-parameters");
+    H = hidden; K = k; DR = dr; NL = nl; gin = gin_;
+    int d = 1;
+    for (int i = 0; i < NL; ++i) {
+      PackSpec sp{}; sp.Cin = H; sp.Cout = 2 * H; sp.K = K; sp.dil = d; sp.paired = true;
+      in_l.emplace_back(new PackedConv());
+      SVOC_TRY(pack_conv_named(*in_l.back(), sp, tab, prefix + "in_layers." + std::to_string(i), st));
+      PackSpec rp{}; rp.Cin = H; rp.K = 1;
+      if (i < NL - 1) { rp.Cout = 2 * H; rp.split_at = H; } else { rp.Cout = H; }
+      rs_l.emplace_back(new PackedConv());
+      SVOC_TRY(pack_conv_named(*rs_l.back(), rp, tab, prefix + "res_skip_layers." + std::to_string(i), st));
+      d *= DR;
+    }
+    if (gin > 0) {
+      PackSpec cp{}; cp.Cin = gin; cp.Cout = 2 * H * NL; cp.K = 1;
+      cond.reset(new PackedConv());
+      SVOC_TRY(pack_conv_named(*cond, cp, tab, prefix + "cond_layer", st));
+    }
+    return SVOC_OK;
+  }
+
+  // x (already masked by the caller, as the reference's callers do) -> out; both [B][H][ld]
+  int forward(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs,
+              const float* g, int g_T, float* out, long long out_bs, int out_ld, int B, int T) {
+    const int Tp = pad4(T);
+    const long long per = (long long)H * Tp;
+    const int gTp = g ? pad4(g_T) : 0;
+    const long long gper = (long long)2 * H * NL * gTp;
+    SVOC_TRY(ws.ensure((size_t)(2 * per * B + gper * B) * sizeof(float)));
+    float* xw = ws.f();
+    float* acts = xw + per * B;
+    float* gc = acts + per * B;
+    if (g) {
+      if (!cond) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "WN: g given but the module has gin_channels == 0");
+      if (g_T != 1 && g_T != T) SVOC_FAIL(SVOC_ERR_SHAPE, "WN: g must have 1 or T=%d frames, got %d", T, g_T);
+      ConvArgs a = mk_args();
+      set_in(a, g, (long long)gin * g_T, g_T, g_T);
+      a.Ncols = g_T;
+      set_out(a.out[0], gc, gper, gTp, 2 * H * NL);
+      SVOC_TRY(launch_conv(*cond, a, B, st));
+    }
+    for (int i = 0; i < NL; ++i) {
+      const bool last = i == NL - 1;
+      const float* xin = i == 0 ? x : xw;
+      const long long xin_bs = i == 0 ? x_bs : per;
+      const int xin_ld = i == 0 ? x_ld : Tp;
+      {   // in_layer + fused_add_tanh_sigmoid_multiply (commons.py:100-107)
+        ConvArgs a = mk_args();
+        set_in(a, xin, xin_bs, xin_ld, T);
+        a.Ncols = T;
+        a.mode = EPI_GATE;
+        set_out(a.out[0], acts, per, Tp, H);
+        if (g) { a.gadd = gc + (long long)i * 2 * H * gTp; a.gadd_bs = gper; a.gadd_ld = gTp; a.gadd_ts = g_T == 1 ? 0 : 1; }
+        SVOC_TRY(launch_conv(*in_l[i], a, B, st));
+      }
+      {   // res_skip 1x1 + residual/skip bookkeeping (modules.py:168-175)
+        ConvArgs a = mk_args();
+        set_in(a, acts, per, Tp, T);
+        a.Ncols = T;
+        a.mask = mask; a.mask_bs = mask_bs;
+        if (!last) {
+          a.split_row = rs_l[i]->split_row;
+          set_out(a.out[0], xw, per, Tp, H, F_RES | F_OUTMASK);
+          set_res(a.out[0], xin, xin_bs, xin_ld);
+          set_out(a.out[1], out, out_bs, out_ld, H, i == 0 ? 0u : (unsigned)F_ACC);
+        } else {
+          set_out(a.out[0], out, out_bs, out_ld, H, (i == 0 ? 0u : (unsigned)F_ACC) | F_OUTMASK);
+        }
+        SVOC_TRY(launch_conv(*rs_l[i], a, B, st));
+      }
+    }
+    return SVOC_OK;
+  }
+};
+
+// =================================================================== ResBlock1 / ResBlock2 (modules.py:187-256)
+struct ResSink { float* y; long long bs; int ld; unsigned flags; float div; };
+
+struct ResBlock {
+  int kind = 1, C = 0, K = 0, ND = 0;
+  std::vector<std::unique_ptr<PackedConv>> c1, c2;
+  DevBuf ws;
+
+  int create(int kind_, int channels, int k, const int* dil, int nd, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
+    if ((kind_ != 1 && kind_ != 2) || channels <= 0 || k <= 0 || (k % 2) == 0 || nd <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "ResBlock: bad hyper-parameters");
+    kind = kind_; C = channels; K = k; ND = nd;
+    for (int i = 0; i < ND; ++i) {
+      PackSpec sp{}; sp.Cin = C; sp.Cout = C; sp.K = K; sp.dil = dil[i];
+      c1.emplace_back(new PackedConv());
+      SVOC_TRY(pack_conv_named(*c1.back(), sp, tab, prefix + (kind == 1 ? "convs1." : "convs.") + std::to_string(i), st));
+      if (kind == 1) {
+        PackSpec s2{}; s2.Cin = C; s2.Cout = C; s2.K = K; s2.dil = 1;
+        c2.emplace_back(new PackedConv());
+        SVOC_TRY(pack_conv_named(*c2.back(), s2, tab, prefix + "convs2." + std::to_string(i), st));
+      }
+    }
+    return SVOC_OK;
+  }
+
+  // x read-only [B][C][x_ld]; A, Bf scratch [B][C][ld]; the block's result goes to `sink`
+  int run(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs, float* A,
+          float* Bf, long long bs, int ld, const ResSink& sink, int B, int L) {
+    const float* cur = x; long long cur_bs = x_bs; int cur_ld = x_ld;
+    for (int i = 0; i < ND; ++i) {
+      const bool last = i == ND - 1;
+      const float* cin = cur; long long cin_bs = cur_bs; int cin_ld = cur_ld;
+      if (kind == 1) {
+        ConvArgs a = mk_args();
+        set_in(a, cur, cur_bs, cur_ld, L);
+        a.pre_slope = 0.1f; a.in_mask = mask; a.in_mask_bs = mask_bs;
+        a.Ncols = L;
+        set_out(a.out[0], A, bs, ld, C);
+        SVOC_TRY(launch_conv(*c1[i], a, B, st));
+        cin = A; cin_bs = bs; cin_ld = ld;
+      }
+      ConvArgs a = mk_args();
+      set_in(a, cin, cin_bs, cin_ld, L);
+      a.pre_slope = 0.1f; a.in_mask = mask; a.in_mask_bs = mask_bs;
+      a.Ncols = L;
+      a.mask = mask; a.mask_bs = mask_bs;
+      if (!last) {
+        set_out(a.out[0], Bf, bs, ld, C, F_RES);
+      } else {
+        set_out(a.out[0], sink.y, sink.bs, sink.ld, C, F_RES | sink.flags | (mask ? (unsigned)F_OUTMASK : 0u));
+        a.out[0].div = sink.div;
+      }
+      set_res(a.out[0], cur, cur_bs, cur_ld);
+      SVOC_TRY(launch_conv(kind == 1 ? *c2[i] : *c1[i], a, B, st));
+      cur = Bf; cur_bs = bs; cur_ld = ld;
+    }
+    return SVOC_OK;
+  }
+
+  int forward(hipStream_t st, const float* x, const float* mask, float* y, int B, int L) {
+    const int ld = pad4(L);
+    const long long bs = (long long)C * ld;
+    SVOC_TRY(ws.ensure((size_t)(2 * bs * B) * sizeof(float)));
+    ResSink sink{y, (long long)C * L, L, 0u, 1.0f};
+    return run(st, x, (long long)C * L, L, mask, L, ws.f(), ws.f() + bs * B, bs, ld, sink, B, L);
+  }
+};
+
+// =================================================================== ResidualCouplingLayer (modules.py:298-343)
+struct Coupling {
+  int C = 0, half = 0, H = 0, mean_only = 0, flipped = 0;
+  PackedConv pre, post;
+  WNStack enc;
+  DevBuf ws;
+
+  int create(int channels, int hidden, int k, int dr, int nl, int gin, int mean_only_, int flipped_, const TensorTable& tab,
+             const std::string& prefix, hipStream_t st) {
+    if (channels <= 0 || channels % 2) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "coupling: channels should be divisible by 2");
+    C = channels; half = C / 2; H = hidden; mean_only = mean_only_; flipped = flipped_;
+    // Flip folding (modules.py:272): in flipped orientation logical x0[c] lives at physical row C-1-c
+    // (block [half,C), reversed) and logical x1[c] at physical row half-1-c (block [0,half), reversed).
+    std::vector<int> rev(half), rev2(2 * half);
+    for (int q = 0; q < half; ++q) rev[q] = half - 1 - q;
+    for (int q = 0; q < half; ++q) { rev2[q] = half - 1 - q; rev2[half + q] = half + (half - 1 - q); }
+    PackSpec ps{}; ps.Cin = half; ps.Cout = H; ps.K = 1; ps.in_perm = flipped ? rev.data() : nullptr;
+    SVOC_TRY(pack_conv_named(pre, ps, tab, prefix + "pre", st));
+    SVOC_TRY(enc.create(H, k, dr, nl, gin, tab, prefix + "enc.", st));
+    PackSpec qs{}; qs.Cin = H; qs.K = 1;
+    if (mean_only) { qs.Cout = half; qs.out_perm = flipped ? rev.data() : nullptr; }
+    else { qs.Cout = 2 * half; qs.paired = true; qs.out_perm = flipped ? rev2.data() : nullptr; }
+    SVOC_TRY(pack_conv_named(post, qs, tab, prefix + "post", st));
+    return SVOC_OK;
+  }
+
+  // src/dst: physical [B][C][ld] buffers (dst may equal src).  Only the x1 block of dst is written;
+  // when dst != src the caller copies the x0 block.
+  int run(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld,
+          const float* mask, long long mask_bs, const float* g, int g_T, int reverse, float* logdet, int B, int T) {
+    const int Tp = pad4(T);
+    const long long per = (long long)H * Tp;
+    SVOC_TRY(ws.ensure((size_t)(2 * per * B) * sizeof(float)));
+    float* h = ws.f();
+    float* wo = h + per * B;
+    const int x0_row = flipped ? half : 0, x1_row = flipped ? 0 : half;
+    {
+      ConvArgs a = mk_args();
+      set_in(a, src + (long long)x0_row * s_ld, s_bs, s_ld, T);
+      a.Ncols = T; a.mask = mask; a.mask_bs = mask_bs;
+      set_out(a.out[0], h, per, Tp, H, F_OUTMASK);
+      SVOC_TRY(launch_conv(pre, a, B, st));
+    }
+    SVOC_TRY(enc.forward(st, h, per, Tp, mask, mask_bs, g, g_T, wo, per, Tp, B, T));
+    {
+      ConvArgs a = mk_args();
+      set_in(a, wo, per, Tp, T);
+      a.Ncols = T; a.mask = mask; a.mask_bs = mask_bs;
+      set_out(a.out[0], dst + (long long)x1_row * d_ld, d_bs, d_ld, half);
+      set_res(a.out[0], src + (long long)x1_row * s_ld, s_bs, s_ld);
+      if (mean_only) {
+        a.out[0].flags = reverse ? F_CPL_REV : F_CPL_FWD;
+      } else {
+        a.mode = reverse ? EPI_CPL_FULL_REV : EPI_CPL_FULL_FWD;
+        a.logdet = reverse ? nullptr : logdet;
+      }
+      SVOC_TRY(launch_conv(post, a, B, st));
+    }
+    return SVOC_OK;
+  }
+};
+
+// =================================================================== ResidualCouplingBlock (models.py:50-80)
+struct Flow {
+  int C = 0, NF = 0;
+  std::vector<std::unique_ptr<Coupling>> rev_l, fwd_l;   // per direction (shared when the flip parity agrees)
+  std::vector<Coupling*> rev_p, fwd_p;
+  DevBuf ws;
+
+  int create(int channels, int hidden, int k, int dr, int nl, int nf, int gin, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
+    C = channels; NF = nf;
+    if (nf <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "flow: n_flows must be positive");
+    for (int i = 0; i < NF; ++i) {
+      const int f_rev = (NF - i) % 2, f_fwd = i % 2;
+      const std::string p = prefix + "flows." + std::to_string(2 * i) + ".";
+      rev_l.emplace_back(new Coupling());
+      SVOC_TRY(rev_l.back()->create(C, hidden, k, dr, nl, gin, 1, f_rev, tab, p, st));
+      rev_p.push_back(rev_l.back().get());
+      if (f_fwd == f_rev) { fwd_p.push_back(rev_l.back().get()); }
+      else {
+        fwd_l.emplace_back(new Coupling());
+        SVOC_TRY(fwd_l.back()->create(C, hidden, k, dr, nl, gin, 1, f_fwd, tab, p, st));
+        fwd_p.push_back(fwd_l.back().get());
+      }
+    }
+    return SVOC_OK;
+  }
+
+  // in-place on P [B][C][ld]; the physical buffer is never flipped except for a final flip when NF is odd
+  int run_inplace(hipStream_t st, float* P, long long bs, int ld, const float* mask, long long mask_bs, const float* g, int g_T,
+                  int reverse, int B, int T) {
+    if (reverse) { for (int i = NF - 1; i >= 0; --i) SVOC_TRY(rev_p[i]->run(st, P, bs, ld, P, bs, ld, mask, mask_bs, g, g_T, 1, nullptr, B, T)); }
+    else { for (int i = 0; i < NF; ++i) SVOC_TRY(fwd_p[i]->run(st, P, bs, ld, P, bs, ld, mask, mask_bs, g, g_T, 0, nullptr, B, T)); }
+    return SVOC_OK;
+  }
+
+  int forward(hipStream_t st, const float* x, const float* mask, const float* g, int g_T, int reverse, float* y, int B, int T) {
+    const int Tp = pad4(T);
+    const long long per = (long long)C * Tp;
+    SVOC_TRY(ws.ensure((size_t)(per * B) * sizeof(float)));
+    float* P = ws.f();
+    SVOC_TRY(k_copy2d(st, x, (long long)C * T, T, P, per, Tp, B, C, T, nullptr, 0));
+    SVOC_TRY(run_inplace(st, P, per, Tp, mask, T, g, g_T, reverse, B, T));
+    if (NF % 2 == 0) return k_copy2d(st, P, per, Tp, y, (long long)C * T, T, B, C, T, nullptr, 0);
+    // odd number of flips: one physical channel reversal on the way out
+    return k_flip_copy(st, P, per, Tp, y, (long long)C * T, T, B, C, T);
+  }
+};
+
+// =================================================================== Generator (models.py:115-167)
+struct Generator {
+  svoc_generator_config cfg{};
+  PackedConv conv_pre;
+  std::unique_ptr<PackedConv> cond;
+  std::vector<std::unique_ptr<PackedConv>> ups;
+  std::vector<std::unique_ptr<ResBlock>> rbs;
+  DevBuf conv_post_w;
+  int post_C = 0;
+  DevBuf ws;
+  int hop = 1;
+
+  int create(const svoc_generator_config& c, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
+    cfg = c;
+    if (c.n_upsamples <= 0 || c.n_upsamples > 8 || c.n_kernels <= 0 || c.n_kernels > 8) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: bad configuration");
+    PackSpec ps{}; ps.Cin = c.initial_channel; ps.Cout = c.upsample_initial_channel; ps.K = 7; ps.pad = 3;
+    SVOC_TRY(pack_conv_named(conv_pre, ps, tab, prefix + "conv_pre", st));
+    if (c.gin_channels > 0) {
+      PackSpec cs{}; cs.Cin = c.gin_channels; cs.Cout = c.upsample_initial_channel; cs.K = 1;
+      cond.reset(new PackedConv());
+      SVOC_TRY(pack_conv_named(*cond, cs, tab, prefix + "cond", st));
+    }
+    int ch = c.upsample_initial_channel;
+    hop = 1;
+    for (int i = 0; i < c.n_upsamples; ++i) {
+      const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+      if (ch % 2) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: channel count not divisible at stage %d", i);
+      PackSpec us{}; us.Cin = ch; us.Cout = ch / 2; us.K = k; us.transposed = true; us.stride = u; us.tpad = (k - u) / 2;
+      if (k < u || ((k - u) % 2) != 0) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "generator: upsample kernel %d / rate %d not supported", k, u);
+      ups.emplace_back(new PackedConv());
+      SVOC_TRY(pack_conv_named(*ups.back(), us, tab, prefix + "ups." + std::to_string(i), st));
+      ch /= 2;
+      hop *= u;
+      for (int j = 0; j < c.n_kernels; ++j) {
+        rbs.emplace_back(new ResBlock());
+        SVOC_TRY(rbs.back()->create(c.resblock_kind, ch, c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j], c.n_dilations[j],
+                                    tab, prefix + "resblocks." + std::to_string(i * c.n_kernels + j) + ".", st));
+      }
+    }
+    post_C = ch;
+    const svoc_tensor* pw = tab.find(prefix + "conv_post.weight");
+    if (!pw) SVOC_FAIL(SVOC_ERR_MISSING_TENSOR, "missing tensor %sconv_post.weight", prefix.c_str());
+    if (pw->ndim != 3 || pw->shape[0] != 1 || pw->shape[1] != ch || pw->shape[2] != 7) SVOC_FAIL(SVOC_ERR_SHAPE, "conv_post.weight has wrong shape");
+    SVOC_TRY(conv_post_w.ensure((size_t)ch * 7 * sizeof(float)));
+    SVOC_HIP(hipMemcpyAsync(conv_post_w.p, pw->data, (size_t)ch * 7 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    SVOC_HIP(hipStreamSynchronize(st));
+    return SVOC_OK;
+  }
+
+  size_t stage_floats(int T) const {   // largest [C_i][pad4(L_i)] over conv_pre output and all stages
+    size_t m = (size_t)cfg.upsample_initial_channel * pad4(T);
+    int ch = cfg.upsample_initial_channel; long long L = T;
+    for (int i = 0; i < cfg.n_upsamples; ++i) { ch /= 2; L *= cfg.upsample_rates[i]; m = std::max(m, (size_t)ch * pad4((int)L)); }
+    return m;
+  }
+  size_t workspace_bytes(int B, int T) const { return (4 * stage_floats(T) * B + (size_t)cfg.upsample_initial_channel * B) * sizeof(float); }
+
+  int forward(hipStream_t st, const float* x, int x_ld, long long x_bs, const float* in_mask, long long in_mask_bs,
+              const float* g, float* out, int B, int T) {
+    const size_t sf = stage_floats(T);
+    SVOC_TRY(ws.ensure(workspace_bytes(B, T)));
+    float* bufs[4];
+    for (int i = 0; i < 4; ++i) bufs[i] = ws.f() + (size_t)i * sf * B;
+    float* gbias = ws.f() + 4 * sf * B;
+    int r = 0;
+    int ch = cfg.upsample_initial_channel;
+    int L = T;
+    int ld = pad4(L);
+    if (g) {
+      if (!cond) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: g given but gin_channels == 0");
+      ConvArgs a = mk_args();
+      set_in(a, g, cfg.gin_channels, 1, 1);
+      a.Ncols = 1;
+      set_out(a.out[0], gbias, ch, 1, ch);
+      // gbias is [B][ch][1]
+      a.out[0].y_bs = ch; a.out[0].y_ld = 1;
+      SVOC_TRY(launch_conv(*cond, a, B, st));
+    }
+    {   // conv_pre (+ cond(g)) (models.py:142-144)
+      ConvArgs a = mk_args();
+      set_in(a, x, x_bs, x_ld, T);
+      a.in_mask = in_mask; a.in_mask_bs = in_mask_bs;
+      a.Ncols = T;
+      set_out(a.out[0], bufs[r], (long long)ch * ld, ld, ch);
+      if (g) { a.gadd = gbias; a.gadd_bs = ch; a.gadd_ld = 1; a.gadd_ts = 0; }
+      SVOC_TRY(launch_conv(conv_pre, a, B, st));
+    }
+    for (int i = 0; i < cfg.n_upsamples; ++i) {
+      const int u = cfg.upsample_rates[i];
+      float* R = bufs[r];
+      float* X = bufs[(r + 1) & 3];
+      float* XS = bufs[(r + 2) & 3];
+      float* A = bufs[(r + 3) & 3];
+      float* Bf = R;   // dead once the upsampler has consumed it
+      const int Lo = L * u, ldo = pad4(Lo), cho = ch / 2;
+      {   // lrelu(0.1) -> ConvTranspose1d as polyphase GEMM (models.py:147-148)
+        ConvArgs a = mk_args();
+        set_in(a, R, (long long)ch * ld, ld, L);
+        a.pre_slope = 0.1f;
+        a.mode = EPI_UPS;
+        a.Lout = Lo;
+        a.Ncols = (Lo - 1 + ups[i]->ups_pad) / u + 1;
+        set_out(a.out[0], X, (long long)cho * ldo, ldo, cho * u);
+        SVOC_TRY(launch_conv(*ups[i], a, B, st));
+      }
+      const long long bs = (long long)cho * ldo;
+      for (int j = 0; j < cfg.n_kernels; ++j) {   // MRF: xs = sum_j ResBlock_j(x); x = xs / n (models.py:149-155)
+        ResSink sink{XS, bs, ldo, 0u, 1.0f};
+        if (j > 0) sink.flags |= F_ACC;
+        if (j == cfg.n_kernels - 1) { sink.flags |= F_DIV; sink.div = (float)cfg.n_kernels; }
+        SVOC_TRY(rbs[i * cfg.n_kernels + j]->run(st, X, bs, ldo, nullptr, 0, A, Bf, bs, ldo, sink, B, Lo));
+      }
+      r = (r + 2) & 3;
+      ch = cho; L = Lo; ld = ldo;
+    }
+    // lrelu(0.01) -> conv_post -> tanh (models.py:156-158)
+    return k_conv_post_tanh(st, bufs[r], (long long)ch * ld, ld, conv_post_w.f(), ch, 7, 0.01f, out, B, L);
+  }
+};
+
+// =================================================================== SynthesizerTrn.infer (models.py:331-339)
+struct Synth {
+  svoc_synth_config cfg{};
+  PackedConv pre_enc, proj;
+  WNStack enc;
+  Flow flow;
+  Generator dec;
+  DevBuf ws;
+
+  int create(const svoc_synth_config& c, const TensorTable& tab, hipStream_t st) {
+    cfg = c;
+    if (c.inter_channels <= 0 || c.hidden_channels <= 0 || c.n_mel <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "synth: bad configuration");
+    PackSpec ps{}; ps.Cin = c.n_mel; ps.Cout = c.hidden_channels; ps.K = 1;
+    SVOC_TRY(pack_conv_named(pre_enc, ps, tab, "enc_p.pre_enc", st));
+    SVOC_TRY(enc.create(c.hidden_channels, c.enc_kernel_size, c.enc_dilation_rate, c.enc_n_layers, c.gin_channels, tab, "enc_p.encoder.", st));
+    PackSpec pj{}; pj.Cin = c.hidden_channels; pj.Cout = 2 * c.inter_channels; pj.K = 1; pj.paired = true;
+    SVOC_TRY(pack_conv_named(proj, pj, tab, "enc_p.proj", st));
+    SVOC_TRY(flow.create(c.inter_channels, c.hidden_channels, c.flow_kernel_size, c.flow_dilation_rate, c.flow_n_layers, c.flow_n_flows,
+                         c.gin_channels, tab, "flow.", st));
+    SVOC_TRY(dec.create(c.dec, tab, "dec.", st));
+    return SVOC_OK;
+  }
+
+  int64_t workspace_bytes(int B, int T) const {
+    const int Tp = pad4(T);
+    const size_t own = ((size_t)(2 * cfg.hidden_channels + 3 * cfg.inter_channels) * Tp + Tp) * B * sizeof(float);
+    const size_t wn = (size_t)2 * cfg.hidden_channels * Tp * B * sizeof(float);
+    return (int64_t)(own + 3 * wn + dec.workspace_bytes(B, T));
+  }
+
+  int infer(hipStream_t st, const float* mel, const int64_t* lengths, const float* eps, float noise_scale, int max_len, float* o,
+            float* x_mask, float* z, float* z_p, float* m_p, float* logs_p, int B, int T) {
+    const int H = cfg.hidden_channels, IC = cfg.inter_channels;
+    const int Tp = pad4(T);
+    const long long hper = (long long)H * Tp, iper = (long long)IC * Tp;
+    SVOC_TRY(ws.ensure((size_t)((2 * hper + 3 * iper + Tp) * B) * sizeof(float)));
+    float* xe = ws.f();                 // masked pre_enc output
+    float* eo = xe + hper * B;          // encoder (WN) output
+    float* mp = eo + hper * B;          // m_p
+    float* lp = mp + iper * B;          // logs_p
+    float* P = lp + iper * B;           // z_p, then z (flows run in place)
+    float* mask = P + iper * B;         // [B][Tp]
+    SVOC_TRY(k_sequence_mask(st, lengths, mask, B, Tp));   // row stride Tp; entries >= T are never read
+    {   // pre_enc 1x1, stored already multiplied by x_mask (models.py:38-42)
+      ConvArgs a = mk_args();
+      set_in(a, mel, (long long)cfg.n_mel * T, T, T);
+      a.Ncols = T; a.mask = mask; a.mask_bs = Tp;
+      set_out(a.out[0], xe, hper, Tp, H, F_OUTMASK);
+      SVOC_TRY(launch_conv(pre_enc, a, B, st));
+    }
+    SVOC_TRY(enc.forward(st, xe, hper, Tp, mask, Tp, nullptr, 0, eo, hper, Tp, B, T));
+    {   // proj -> (m_p, logs_p) * mask, reparameterisation z_p = m_p + eps*exp(logs_p)*noise_scale (models.py:44-46, 336)
+      ConvArgs a = mk_args();
+      set_in(a, eo, hper, Tp, T);
+      a.Ncols = T; a.mask = mask; a.mask_bs = Tp;
+      a.mode = EPI_PROJ;
+      set_out(a.out[0], mp, iper, Tp, IC);
+      a.y2 = lp; a.y3 = P;
+      a.eps = eps; a.eps_bs = (long long)IC * T; a.eps_ld = T; a.noise_scale = noise_scale;
+      SVOC_TRY(launch_conv(proj, a, B, st));
+    }
+    const long long ubs = (long long)IC * T;
+    if (m_p) SVOC_TRY(k_copy2d(st, mp, iper, Tp, m_p, ubs, T, B, IC, T, nullptr, 0));
+    if (logs_p) SVOC_TRY(k_copy2d(st, lp, iper, Tp, logs_p, ubs, T, B, IC, T, nullptr, 0));
+    if (z_p) SVOC_TRY(k_copy2d(st, P, iper, Tp, z_p, ubs, T, B, IC, T, nullptr, 0));
+    SVOC_TRY(flow.run_inplace(st, P, iper, Tp, mask, Tp, nullptr, 0, 1, B, T));
+    if (flow.NF % 2) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "synth: odd n_flows is not supported on the fused path");
+    if (z) SVOC_TRY(k_copy2d(st, P, iper, Tp, z, ubs, T, B, IC, T, nullptr, 0));
+    if (x_mask) SVOC_TRY(k_copy2d(st, mask, Tp, Tp, x_mask, T, T, B, 1, T, nullptr, 0));
+    const int Td = (max_len > 0 && max_len < T) ? max_len : T;
+    // dec((z * x_mask)[:, :, :max_len]) (models.py:338)
+    return dec.forward(st, P, Tp, iper, mask, Tp, nullptr, o, B, Td);
+  }
+};
+
+}  // namespace svoc
+
+// ======================================================================= C ABI
+using namespace svoc;
+
+struct svoc_wn { WNStack m; };
+struct svoc_resblock { ResBlock m; };
+struct svoc_coupling { Coupling m; };
+struct svoc_flow { Flow m; };
+struct svoc_generator { Generator m; };
+struct svoc_synth { Synth m; };
+
+#define SVOC_GUARD_BEGIN try {
+#define SVOC_GUARD_END } catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
+
+extern "C" {
+
+int svoc_wn_create(svoc_wn** out, int hidden_channels, int kernel_size, int dilation_rate, int n_layers, int gin_channels,
+                   const svoc_tensor* tensors, int n_tensors, const char* prefix) {
+  if (!out || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_wn_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_wn> h(new svoc_wn());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, tab, prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_wn_forward(svoc_wn* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T, float* out, int B, int T) {
+  if (!h || !x || !x_mask || !out || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_wn_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  const long long bs = (long long)h->m.H * T;
+  return h->m.forward(as_stream(stream), x, bs, T, x_mask, T, g, g_T, out, bs, T, B, T);
+  SVOC_GUARD_END
+}
+void svoc_wn_destroy(svoc_wn* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_resblock_create(svoc_resblock** out, int kind, int channels, int kernel_size, const int* dilations, int n_dilations,
+                         const svoc_tensor* tensors, int n_tensors, const char* prefix) {
+  if (!out || !tensors || !dilations) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_resblock_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_resblock> h(new svoc_resblock());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(kind, channels, kernel_size, dilations, n_dilations, tab, prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_resblock_forward(svoc_resblock* h, void* stream, const float* x, const float* x_mask, float* y, int B, int L) {
+  if (!h || !x || !y || B <= 0 || L <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_resblock_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  return h->m.forward(as_stream(stream), x, x_mask, y, B, L);
+  SVOC_GUARD_END
+}
+void svoc_resblock_destroy(svoc_resblock* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_coupling_create(svoc_coupling** out, int channels, int hidden_channels, int kernel_size, int dilation_rate, int n_layers,
+                         int gin_channels, int mean_only, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
+  if (!out || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_coupling_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_coupling> h(new svoc_coupling());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, mean_only, 0, tab, prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_coupling_forward(svoc_coupling* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T, int reverse,
+                          float* y, float* logdet, int B, int T) {
+  if (!h || !x || !x_mask || !y || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_coupling_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  hipStream_t st = as_stream(stream);
+  Coupling& m = h->m;
+  const long long bs = (long long)m.C * T;
+  if (y != x) SVOC_TRY(k_copy2d(st, x, bs, T, y, bs, T, B, m.half, T, nullptr, 0));   // x0 passes through
+  if (!reverse && logdet) SVOC_TRY(k_fill(st, logdet, (size_t)B, 0.0f));             // mean_only: logs == 0
+  return m.run(st, x, bs, T, y, bs, T, x_mask, T, g, g_T, reverse, logdet, B, T);
+  SVOC_GUARD_END
+}
+void svoc_coupling_destroy(svoc_coupling* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_flow_create(svoc_flow** out, int channels, int hidden_channels, int kernel_size, int dilation_rate, int n_layers, int n_flows,
+                     int gin_channels, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
+  if (!out || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_flow_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_flow> h(new svoc_flow());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows, gin_channels, tab, prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_flow_forward(svoc_flow* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T, int reverse, float* y,
+                      int B, int T) {
+  if (!h || !x || !x_mask || !y || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_flow_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  return h->m.forward(as_stream(stream), x, x_mask, g, g_T, reverse, y, B, T);
+  SVOC_GUARD_END
+}
+void svoc_flow_destroy(svoc_flow* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_generator_create(svoc_generator** out, const svoc_generator_config* cfg, const svoc_tensor* tensors, int n_tensors,
+                          const char* prefix) {
+  if (!out || !cfg || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_generator_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_generator> h(new svoc_generator());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(*cfg, tab, prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_generator_forward(svoc_generator* h, void* stream, const float* x, int x_ld, int64_t x_bs, const float* in_mask,
+                           int64_t in_mask_bs, const float* g, float* out, int B, int T) {
+  if (!h || !x || !out || B <= 0 || T <= 0 || x_ld < T) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_generator_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  return h->m.forward(as_stream(stream), x, x_ld, x_bs, in_mask, in_mask_bs, g, out, B, T);
+  SVOC_GUARD_END
+}
+void svoc_generator_destroy(svoc_generator* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_synth_create(svoc_synth** out, const svoc_synth_config* cfg, const svoc_tensor* tensors, int n_tensors) {
+  if (!out || !cfg || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_synth_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_synth> h(new svoc_synth());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(*cfg, tab, nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_synth_infer(svoc_synth* h, void* stream, const float* mel, const int64_t* lengths, const float* eps, float noise_scale,
+                     int max_len, float* o, float* x_mask, float* z, float* z_p, float* m_p, float* logs_p, int B, int T) {
+  if (!h || !mel || !lengths || !o || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_synth_infer: bad arguments");
+  if (!eps && noise_scale != 0.0f) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_synth_infer: eps is NULL but noise_scale != 0");
+  SVOC_GUARD_BEGIN
+  return h->m.infer(as_stream(stream), mel, lengths, eps, noise_scale, max_len, o, x_mask, z, z_p, m_p, logs_p, B, T);
+  SVOC_GUARD_END
+}
+int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T) { return h ? h->m.workspace_bytes(B, T) : 0; }
+int svoc_synth_hop(svoc_synth* h) { return h ? h->m.dec.hop : 0; }
+void svoc_synth_destroy(svoc_synth* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+// ---- single ops
+int svoc_flip_channels(void* stream, const float* x, float* y, int B, int C, int T) {
+  if (!x || !y || B <= 0 || C <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_flip_channels: bad arguments");
+  return k_flip_copy(as_stream(stream), x, (long long)C * T, T, y, (long long)C * T, T, B, C, T);
+}
+int svoc_fold_weight_norm(void* stream, const float* weight_v, const float* weight_g, float* weight, int64_t d0, int64_t inner) {
+  if (!weight_v || !weight_g || !weight || d0 <= 0 || inner <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_fold_weight_norm: bad arguments");
+  SVOC_GUARD_BEGIN
+  return fold_weight_norm(as_stream(stream), weight_v, weight_g, weight, d0, inner);
+  SVOC_GUARD_END
+}
+int svoc_conv1d(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias, const float* residual,
+                float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation, float pre_slope) {
+  if (!x || !weight_v || !y || B <= 0 || L <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_conv1d: bad arguments");
+  SVOC_GUARD_BEGIN
+  hipStream_t st = as_stream(stream);
+  PackedConv pc;
+  PackSpec sp{}; sp.Cin = Cin; sp.Cout = Cout; sp.K = kernel_size; sp.dil = dilation;
+  SVOC_TRY(pack_conv(pc, sp, weight_v, weight_g, bias, st));
+  ConvArgs a = mk_args();
+  set_in(a, x, (long long)Cin * L, L, L);
+  a.pre_slope = pre_slope;
+  a.Ncols = L;
+  set_out(a.out[0], y, (long long)Cout * L, L, Cout, residual ? (unsigned)F_RES : 0u);
+  if (residual) set_res(a.out[0], residual, (long long)Cout * L, L);
+  SVOC_TRY(launch_conv(pc, a, B, st));
+  SVOC_HIP(hipStreamSynchronize(st));   // packed weights are freed on return
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_conv_transpose1d(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias, float* y, int B,
+                          int Cin, int Cout, int L, int kernel_size, int stride, float pre_slope) {
+  if (!x || !weight_v || !y || B <= 0 || L <= 0 || stride <= 0 || kernel_size < stride || ((kernel_size - stride) % 2))
+    SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_conv_transpose1d: bad arguments");
+  SVOC_GUARD_BEGIN
+  hipStream_t st = as_stream(stream);
+  PackedConv pc;
+  PackSpec sp{}; sp.Cin = Cin; sp.Cout = Cout; sp.K = kernel_size; sp.transposed = true; sp.stride = stride; sp.tpad = (kernel_size - stride) / 2;
+  SVOC_TRY(pack_conv(pc, sp, weight_v, weight_g, bias, st));
+  const int Lo = L * stride;
+  ConvArgs a = mk_args();
+  set_in(a, x, (long long)Cin * L, L, L);
+  a.pre_slope = pre_slope;
+  a.mode = EPI_UPS;
+  a.Lout = Lo;
+  a.Ncols = (Lo - 1 + pc.ups_pad) / stride + 1;
+  set_out(a.out[0], y, (long long)Cout * Lo, Lo, Cout * stride);
+  SVOC_TRY(launch_conv(pc, a, B, st));
+  SVOC_HIP(hipStreamSynchronize(st));
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+
+}  // extern "C"

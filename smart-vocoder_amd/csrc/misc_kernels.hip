@@ -1,0 +1,232 @@
+// Small memory-bound kernels of the inference path (everything that is not a convolution GEMM).
+#include "svoc_internal.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+
+namespace svoc {
+
+// ------------------------------------------------------------------ errors / stats
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+static std::atomic<long long> g_conv_launches{0}, g_other_launches{0};
+static std::atomic<double> g_conv_flops{0.0};
+void stats_add_conv(double flops) {
+  g_conv_launches.fetch_add(1, std::memory_order_relaxed);
+  double cur = g_conv_flops.load(std::memory_order_relaxed);
+  while (!g_conv_flops.compare_exchange_weak(cur, cur + flops, std::memory_order_relaxed)) {}
+}
+void stats_add_other() { g_other_launches.fetch_add(1, std::memory_order_relaxed); }
+void stats_reset() { g_conv_launches = 0; g_other_launches = 0; g_conv_flops = 0.0; }
+void stats_get(long long* cl, double* cf, long long* ol) {
+  if (cl) *cl = g_conv_launches.load();
+  if (cf) *cf = g_conv_flops.load();
+  if (ol) *ol = g_other_launches.load();
+}
+
+// ------------------------------------------------------------------ sequence mask (commons.py:121-125, models.py:40)
+__global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float* __restrict__ mask, int B, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t < T) mask[(long long)b * T + t] = ((int64_t)t < lengths[b]) ? 1.0f : 0.0f;
+}
+int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, int T) {
+  if (B <= 0 || T <= 0) return SVOC_OK;
+  hipLaunchKernelGGL(sequence_mask_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, lengths, mask, B, T);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
+// ------------------------------------------------------------------ gate (commons.py:100-107), standalone form
+__global__ void gate_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ y, int H,
+                            long long T, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long t = i % T;
+  const long long c = (i / T) % H;
+  const long long b = i / (T * H);
+  const long long ia = (b * 2 * H + c) * T + t, ib = (b * 2 * H + H + c) * T + t;
+  const float u = a[ia] + g[ia], v = a[ib] + g[ib];
+  y[i] = tanhf(u) * (1.0f / (1.0f + expf(-v)));
+}
+int k_gate(hipStream_t st, const float* a, const float* b, float* y, int B, int H, int T) {
+  const long long total = (long long)B * H * T;
+  if (total <= 0) return SVOC_OK;
+  hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, b, y, H, (long long)T, total);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
+// ------------------------------------------------------------------ lrelu -> conv_post (C->1, k taps, no bias) -> tanh
+// (models.py:156-158).  One output row per utterance; every thread produces 4 consecutive samples.
+template <int K>
+__global__ void conv_post_tanh_kernel(const float* __restrict__ x, long long x_bs, int x_ld, const float* __restrict__ w,
+                                      int C, float slope, float* __restrict__ y, int L, int vec) {
+  extern __shared__ float ws[];   // [C][K]
+  for (int i = threadIdx.x; i < C * K; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  constexpr int P = (K - 1) / 2;
+  constexpr int LEAD = (P + 3) / 4 * 4;           // staging starts at t0 - LEAD
+  constexpr int NV = (LEAD + 3 + P) / 4 + 1;      // float4 groups covering [t0-LEAD, t0+3+P]
+  const int b = blockIdx.y;
+  const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (t0 >= L) return;
+  const float* xb = x + (long long)b * x_bs;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* row = xb + (long long)c * x_ld;
+    float v[NV * 4];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int t = t0 - LEAD + 4 * q;
+      if (vec && t >= 0 && t + 3 < L) {
+        const float4 f = *reinterpret_cast<const float4*>(row + t);
+        v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = (t + e >= 0 && t + e < L) ? row[t + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV * 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+    const float* wc = ws + c * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float wj = wc[j];
+      acc0 = fmaf(wj, v[LEAD - P + j + 0], acc0);
+      acc1 = fmaf(wj, v[LEAD - P + j + 1], acc1);
+      acc2 = fmaf(wj, v[LEAD - P + j + 2], acc2);
+      acc3 = fmaf(wj, v[LEAD - P + j + 3], acc3);
+    }
+  }
+  float* yb = y + (long long)b * L;
+  if (t0 < L) yb[t0] = tanhf(acc0);
+  if (t0 + 1 < L) yb[t0 + 1] = tanhf(acc1);
+  if (t0 + 2 < L) yb[t0 + 2] = tanhf(acc2);
+  if (t0 + 3 < L) yb[t0 + 3] = tanhf(acc3);
+}
+
+__global__ void conv_post_tanh_generic_kernel(const float* __restrict__ x, long long x_bs, int x_ld,
+                                              const float* __restrict__ w, int C, int K, float slope,
+                                              float* __restrict__ y, int L) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= L) return;
+  const int P = (K - 1) / 2;
+  const float* xb = x + (long long)b * x_bs;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c)
+    for (int j = 0; j < K; ++j) {
+      const int tt = t + j - P;
+      if (tt >= 0 && tt < L) {
+        float v = xb[(long long)c * x_ld + tt];
+        v = v > 0.f ? v : v * slope;
+        acc = fmaf(w[c * K + j], v, acc);
+      }
+    }
+  y[(long long)b * L + t] = tanhf(acc);
+}
+
+int k_conv_post_tanh(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* w, int C, int K, float slope,
+                     float* y, int B, int L) {
+  if (B <= 0 || L <= 0) return SVOC_OK;
+  if (K == 7 && C * K * 4 <= 48 * 1024) {
+    const int vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (x_ld & 3) == 0 && (x_bs & 3) == 0) ? 1 : 0;
+    const int nthr = (L + 3) / 4;
+    hipLaunchKernelGGL(conv_post_tanh_kernel<7>, dim3((nthr + 255) / 256, B), dim3(256), (size_t)C * K * sizeof(float), st,
+                       x, x_bs, x_ld, w, C, slope, y, L, vec);
+  } else {
+    hipLaunchKernelGGL(conv_post_tanh_generic_kernel, dim3((L + 255) / 256, B), dim3(256), 0, st, x, x_bs, x_ld, w, C, K,
+                       slope, y, L);
+  }
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
+// ------------------------------------------------------------------ strided 2-D copy (optionally * mask[col])
+__global__ void copy2d_kernel(const float* __restrict__ src, long long s_bs, int s_ld, float* __restrict__ dst,
+                              long long d_bs, int d_ld, int rows, int cols, const float* __restrict__ mask,
+                              long long mask_bs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  const int b = blockIdx.z;
+  if (c >= cols) return;
+  float v = src[(long long)b * s_bs + (long long)r * s_ld + c];
+  if (mask) v *= mask[(long long)b * mask_bs + c];
+  dst[(long long)b * d_bs + (long long)r * d_ld + c] = v;
+}
+int k_copy2d(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
+             int rows, int cols, const float* mask, long long mask_bs) {
+  if (B <= 0 || rows <= 0 || cols <= 0) return SVOC_OK;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((cols + 255) / 256, rows, B), dim3(256), 0, st, src, s_bs, s_ld, dst, d_bs, d_ld,
+                     rows, cols, mask, mask_bs);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
+// channel flip (modules.Flip, modules.py:272) as a strided copy: dst[b][c] = src[b][C-1-c]
+__global__ void flip_copy_kernel(const float* __restrict__ src, long long s_bs, int s_ld, float* __restrict__ dst,
+                                 long long d_bs, int d_ld, int C, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  const int b = blockIdx.z;
+  if (t >= T) return;
+  dst[(long long)b * d_bs + (long long)c * d_ld + t] = src[(long long)b * s_bs + (long long)(C - 1 - c) * s_ld + t];
+}
+int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
+                int C, int T) {
+  if (B <= 0 || C <= 0 || T <= 0) return SVOC_OK;
+  hipLaunchKernelGGL(flip_copy_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, st, src, s_bs, s_ld, dst, d_bs, d_ld, C, T);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
+__global__ void fill_kernel(float* p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int k_fill(hipStream_t st, float* p, size_t n, float v) {
+  if (n == 0) return SVOC_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
+}  // namespace svoc
+
+extern "C" {
+const char* svoc_last_error(void) { return svoc::last_error(); }
+int svoc_abi_version(void) { return 1; }
+const char* svoc_build_arch(void) { return "gfx950"; }
+int svoc_stats_reset(void) { svoc::stats_reset(); return SVOC_OK; }
+int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches) {
+  long long cl, ol; double cf;
+  svoc::stats_get(&cl, &cf, &ol);
+  if (conv_launches) *conv_launches = cl;
+  if (conv_flops) *conv_flops = cf;
+  if (other_launches) *other_launches = ol;
+  return SVOC_OK;
+}
+int svoc_sequence_mask(void* stream, const int64_t* lengths, float* mask, int B, int T) {
+  if (!lengths || !mask || B < 0 || T < 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_sequence_mask: bad arguments");
+  return svoc::k_sequence_mask(svoc::as_stream(stream), lengths, mask, B, T);
+}
+int svoc_fused_add_tanh_sigmoid_multiply(void* stream, const float* a, const float* b, float* acts, int B, int H, int T) {
+  if (!a || !b || !acts || B < 0 || H < 0 || T < 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_fused_add_tanh_sigmoid_multiply: bad arguments");
+  return svoc::k_gate(svoc::as_stream(stream), a, b, acts, B, H, T);
+}
+}

@@ -1,0 +1,455 @@
+// Module-level ops that the reference defines next to the inference path but never
+// instantiates from SynthesizerTrn: DDSConv, ConvFlow and the
+// piecewise rational-quadratic spline.  The dense 1x1 convolutions reuse the MFMA
+// kernel; depthwise conv + LayerNorm(C) + GELU and the spline are HBM-bound
+// elementwise/reduction kernels with time-contiguous (coalesced) accesses.
+#include "svoc_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace svoc {
+
+static ConvArgs mk_args2() {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pre_slope = 1.0f;
+  a.split_row = 1 << 30;
+  a.mode = EPI_PLAIN;
+  a.out[0].nrows = 1 << 30;
+  a.out[1].nrows = 1 << 30;
+  a.out[0].div = 1.0f;
+  return a;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------------------------------------
+// [optional depthwise dilated conv on x*mask] -> LayerNorm over channels -> GELU [-> x += . ; * mask]
+//   MODE 0: y = gelu(LN(dwconv(x*mask)))                      (modules.py:99-101)
+//   MODE 1: x = x + gelu(LN(y_in)); if last: x *= mask        (modules.py:103-108)
+// One block owns TT time steps x all C channels; the tile lives in LDS between the passes.
+template <int MODE>
+__global__ void __launch_bounds__(256) dds_ln_gelu_kernel(const float* __restrict__ src, long long s_bs, int s_ld,
+                                                          const float* __restrict__ mask, long long mask_bs,
+                                                          const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                          int K, int dil, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float* __restrict__ dst,
+                                                          long long d_bs, int d_ld, int C, int T, int TT, int last) {
+  extern __shared__ float tile[];          // [C][TT]
+  float* red = tile + (size_t)C * TT;      // [2][256]
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const int tl = threadIdx.x % TT;
+  const int cg = threadIdx.x / TT;
+  const int ncg = 256 / TT;
+  const int t = t0 + tl;
+  const bool tv = t < T;
+  const float* sb = src + (long long)b * s_bs;
+  const float* mb = mask + (long long)b * mask_bs;
+  float s1 = 0.f;
+  for (int c = cg; c < C; c += ncg) {
+    float v = 0.f;
+    if (tv) {
+      if (MODE == 0) {
+        const int pad = (K * dil - dil) / 2;
+        v = dw_b[c];
+        for (int j = 0; j < K; ++j) {
+          const int tt = t + j * dil - pad;
+          if (tt >= 0 && tt < T) v = fmaf(dw_w[c * K + j], sb[(long long)c * s_ld + tt] * mb[tt], v);
+        }
+      } else {
+        v = sb[(long long)c * s_ld + t];
+      }
+    }
+    tile[(size_t)c * TT + tl] = v;
+    s1 += v;
+  }
+  red[threadIdx.x] = s1;
+  __syncthreads();
+  float mean = 0.f;
+  for (int q = 0; q < ncg; ++q) mean += red[q * TT + tl];
+  mean /= (float)C;
+  float s2 = 0.f;
+  for (int c = cg; c < C; c += ncg) {
+    const float dv = tile[(size_t)c * TT + tl] - mean;
+    s2 += dv * dv;
+  }
+  red[256 + threadIdx.x] = s2;
+  __syncthreads();
+  float var = 0.f;
+  for (int q = 0; q < ncg; ++q) var += red[256 + q * TT + tl];
+  var /= (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (!tv) return;
+  float* db = dst + (long long)b * d_bs;
+  const float mk = mb[t];
+  for (int c = cg; c < C; c += ncg) {
+    const float v = gelu_erf((tile[(size_t)c * TT + tl] - mean) * rstd * gamma[c] + beta[c]);
+    float* dp = db + (long long)c * d_ld + t;
+    if (MODE == 0) {
+      *dp = v;
+    } else {
+      float r = *dp + v;
+      if (last) r *= mk;
+      *dp = r;
+    }
+  }
+}
+
+__global__ void add2d_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ dst, long long d_bs,
+                             int d_ld, int rows, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const long long i = ((long long)b * rows + r) * T + t;
+  dst[(long long)b * d_bs + (long long)r * d_ld + t] = a[i] + (g ? g[i] : 0.f);
+}
+
+struct DDS {
+  int C = 0, K = 0, NL = 0;
+  std::vector<std::unique_ptr<PackedConv>> c1x1;
+  DevBuf params;     // per layer: dw_w [C*K], dw_b [C], g1 [C], b1 [C], g2 [C], b2 [C]
+  DevBuf ws;
+  size_t stride() const { return (size_t)C * K + 5 * (size_t)C; }
+
+  int create(int channels, int k, int nl, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
+    if (channels <= 0 || k <= 0 || (k % 2) == 0 || nl <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "DDSConv: bad hyper-parameters");
+    C = channels; K = k; NL = nl;
+    SVOC_TRY(params.ensure(stride() * NL * sizeof(float)));
+    for (int i = 0; i < NL; ++i) {
+      const std::string s = std::to_string(i);
+      const char* names[6] = {"convs_sep.", "convs_sep.", "norms_1.", "norms_1.", "norms_2.", "norms_2."};
+      const char* leaf[6] = {".weight", ".bias", ".gamma", ".beta", ".gamma", ".beta"};
+      size_t off = stride() * i;
+      for (int q = 0; q < 6; ++q) {
+        const std::string nm = prefix + names[q] + s + leaf[q];
+        const svoc_tensor* t = tab.find(nm);
+        if (!t) SVOC_FAIL(SVOC_ERR_MISSING_TENSOR, "missing tensor %s", nm.c_str());
+        const size_t n = q == 0 ? (size_t)C * K : (size_t)C;
+        size_t have = 1;
+        for (int d = 0; d < t->ndim; ++d) have *= (size_t)t->shape[d];
+        if (have != n) SVOC_FAIL(SVOC_ERR_SHAPE, "tensor %s has %zu elements, expected %zu", nm.c_str(), have, n);
+        SVOC_HIP(hipMemcpyAsync(params.f() + off, t->data, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        off += n;
+      }
+      PackSpec sp{}; sp.Cin = C; sp.Cout = C; sp.K = 1;
+      c1x1.emplace_back(new PackedConv());
+      SVOC_TRY(pack_conv_named(*c1x1.back(), sp, tab, prefix + "convs_1x1." + s, st));
+    }
+    SVOC_HIP(hipStreamSynchronize(st));
+    return SVOC_OK;
+  }
+
+  int tile_tt() const {
+    int tt = 64;
+    while (tt > 1 && ((size_t)C * tt + 512) * sizeof(float) > 64 * 1024) tt >>= 1;
+    return tt;
+  }
+
+  // x [B][C][x_ld] -> y [B][C][y_ld]; g nullable, contiguous [B][C][T]
+  int forward(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs, const float* g,
+              float* y, long long y_bs, int y_ld, int B, int T) {
+    const int Tp = round_up(T, 4);
+    const long long per = (long long)C * Tp;
+    SVOC_TRY(ws.ensure((size_t)(3 * per * B) * sizeof(float)));
+    float* xw = ws.f();
+    float* y1 = xw + per * B;
+    float* y2 = y1 + per * B;
+    const int TT = tile_tt();
+    const size_t lds = ((size_t)C * TT + 512) * sizeof(float);
+    if (lds > 64 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "DDSConv: %d channels do not fit the LayerNorm tile", C);
+    // xw = x (+ g)
+    if (x_ld == T && x_bs == (long long)C * T) {
+      hipLaunchKernelGGL(add2d_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, st, x, g, xw, per, Tp, C, T);
+      SVOC_HIP(hipGetLastError());
+      stats_add_other();
+    } else {
+      if (g) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "DDSConv: g with a strided input");
+      SVOC_TRY(k_copy2d(st, x, x_bs, x_ld, xw, per, Tp, B, C, T, nullptr, 0));
+    }
+    int d = 1;
+    for (int i = 0; i < NL; ++i) {
+      const float* P = params.f() + stride() * i;
+      const float* dw_w = P; const float* dw_b = dw_w + (size_t)C * K;
+      const float* g1 = dw_b + C; const float* b1 = g1 + C; const float* g2 = b1 + C; const float* b2 = g2 + C;
+      dim3 grid((T + TT - 1) / TT, B);
+      hipLaunchKernelGGL(dds_ln_gelu_kernel<0>, grid, dim3(256), lds, st, xw, per, Tp, mask, mask_bs, dw_w, dw_b, K, d, g1, b1, 1e-5f,
+                         y1, per, Tp, C, T, TT, 0);
+      SVOC_HIP(hipGetLastError());
+      stats_add_other();
+      ConvArgs a = mk_args2();
+      a.x = y1; a.x_bs = per; a.x_ld = Tp; a.Lin = T; a.Ncols = T;
+      a.out[0].y = y2; a.out[0].y_bs = per; a.out[0].y_ld = Tp; a.out[0].nrows = C;
+      SVOC_TRY(launch_conv(*c1x1[i], a, B, st));
+      hipLaunchKernelGGL(dds_ln_gelu_kernel<1>, grid, dim3(256), lds, st, y2, per, Tp, mask, mask_bs, nullptr, nullptr, K, d, g2, b2,
+                         1e-5f, xw, per, Tp, C, T, TT, i == NL - 1 ? 1 : 0);
+      SVOC_HIP(hipGetLastError());
+      stats_add_other();
+      d *= K;
+    }
+    return k_copy2d(st, xw, per, Tp, y, y_bs, y_ld, B, C, T, nullptr, 0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Rational-quadratic spline (transforms.py:96-193) with optional linear tails (transforms.py:55-94).
+// One lane per element.  Parameter p of element e is read at prm[e_off + p * p_stride] so that both the
+// [n, bins] layout of the Python API and ConvFlow's [b, c*(3*bins-1)+p, t] layout are coalesced.
+constexpr int MAXB = 32;
+
+__device__ __forceinline__ float softplus_f(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
+
+struct SplineOut { float y, lad; };
+
+template <class LoadW, class LoadH, class LoadD>
+__device__ SplineOut rq_spline_elem(float x, int nb, bool inverse, float left, float right, float bottom, float top,
+                                    LoadW lw, LoadH lh, LoadD ld_) {
+  const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+  float cw[MAXB + 1], chh[MAXB + 1];
+  {   // knots from softmax widths / heights
+    float mx = -INFINITY;
+    for (int k = 0; k < nb; ++k) mx = fmaxf(mx, lw(k));
+    float sum = 0.f;
+    for (int k = 0; k < nb; ++k) sum += expf(lw(k) - mx);
+    float run = 0.f;
+    cw[0] = left;
+    for (int k = 0; k < nb; ++k) {
+      const float w = min_w + (1.0f - min_w * nb) * (expf(lw(k) - mx) / sum);
+      run += w;
+      cw[k + 1] = (right - left) * run + left;
+    }
+    cw[nb] = right;
+    mx = -INFINITY;
+    for (int k = 0; k < nb; ++k) mx = fmaxf(mx, lh(k));
+    sum = 0.f;
+    for (int k = 0; k < nb; ++k) sum += expf(lh(k) - mx);
+    run = 0.f;
+    chh[0] = bottom;
+    for (int k = 0; k < nb; ++k) {
+      const float h = min_h + (1.0f - min_h * nb) * (expf(lh(k) - mx) / sum);
+      run += h;
+      chh[k + 1] = (top - bottom) * run + bottom;
+    }
+    chh[nb] = top;
+  }
+  // bin search: sum(x >= knot) - 1 with the last knot nudged by 1e-6 (transforms.py:47-52)
+  int idx = -1;
+  for (int k = 0; k <= nb; ++k) {
+    float kn = inverse ? chh[k] : cw[k];
+    if (k == nb) kn += 1e-6f;
+    idx += (x >= kn) ? 1 : 0;
+  }
+  idx = idx < 0 ? 0 : (idx > nb - 1 ? nb - 1 : idx);
+  float x_k = cw[0], x_k1 = cw[1], y_k = chh[0], y_k1 = chh[1];
+  for (int k = 0; k < nb; ++k)
+    if (k == idx) { x_k = cw[k]; x_k1 = cw[k + 1]; y_k = chh[k]; y_k1 = chh[k + 1]; }
+  const float w_k = x_k1 - x_k, h_k = y_k1 - y_k;
+  const float s_k = h_k / w_k;
+  const float d0 = min_d + softplus_f(ld_(idx));
+  const float d1 = min_d + softplus_f(ld_(idx + 1));
+  SplineOut o;
+  float th;
+  if (inverse) {
+    const float dy = x - y_k;
+    const float tq = dy * (d0 + d1 - 2.0f * s_k);
+    const float a = tq + h_k * (s_k - d0);
+    const float bq = h_k * d0 - tq;
+    const float c = -s_k * dy;
+    const float disc = bq * bq - 4.0f * a * c;
+    th = (2.0f * c) / (-bq - sqrtf(disc));
+    o.y = th * w_k + x_k;
+  } else {
+    th = (x - x_k) / w_k;
+  }
+  const float tt = th * (1.0f - th);
+  const float den = s_k + (d0 + d1 - 2.0f * s_k) * tt;
+  const float num = s_k * s_k * (d1 * th * th + 2.0f * s_k * tt + d0 * (1.0f - th) * (1.0f - th));
+  const float lad = logf(num) - 2.0f * logf(den);
+  if (inverse) {
+    o.lad = -lad;
+  } else {
+    o.y = y_k + h_k * (s_k * th * th + d0 * tt) / den;
+    o.lad = lad;
+  }
+  return o;
+}
+
+// derivative loader for linear tails: index 0 and nb are the constant log(exp(1-1e-3)-1) (transforms.py:72-75)
+__global__ void rq_spline_kernel(const float* __restrict__ x, const float* __restrict__ uw, const float* __restrict__ uh,
+                                 const float* __restrict__ ud, long long n, int nb, int inverse, int linear_tails, float bound,
+                                 float tail_const, float* __restrict__ y, float* __restrict__ lad) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float xv = x[e];
+  if (linear_tails && !(xv >= -bound && xv <= bound)) { y[e] = xv; lad[e] = 0.f; return; }
+  const float* pw = uw + e * nb;
+  const float* ph = uh + e * nb;
+  const float* pd = ud + e * (linear_tails ? nb - 1 : nb + 1);
+  const float lo = linear_tails ? -bound : 0.f, hi = linear_tails ? bound : 1.f;
+  SplineOut o = rq_spline_elem(
+      xv, nb, inverse != 0, lo, hi, lo, hi, [&](int k) { return pw[k]; }, [&](int k) { return ph[k]; },
+      [&](int k) { return linear_tails ? ((k == 0 || k == nb) ? tail_const : pd[k - 1]) : pd[k]; });
+  y[e] = o.y;
+  lad[e] = o.lad;
+}
+
+// ConvFlow tail (modules.py:374-390): h [B][half*(3nb-1)][ld] -> spline on x1, cat, * mask, logdet
+__global__ void convflow_spline_kernel(const float* __restrict__ x, const float* __restrict__ h, long long h_bs, int h_ld,
+                                       const float* __restrict__ mask, int half, int T, int nb, float inv_sqrt_fc_den,
+                                       int inverse, float bound, float tail_const, float* __restrict__ y,
+                                       float* __restrict__ logdet) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  float contrib = 0.f;
+  if (t < T) {
+    const int C = 2 * half;
+    const float mk = mask[(long long)b * T + t];
+    const long long i0 = ((long long)b * C + c) * T + t, i1 = ((long long)b * C + half + c) * T + t;
+    y[i0] = x[i0] * mk;
+    const float xv = x[i1];
+    float out = xv, lad = 0.f;
+    if (xv >= -bound && xv <= bound) {
+      const int P = 3 * nb - 1;
+      const float* hp = h + (long long)b * h_bs + (long long)c * P * h_ld + t;
+      const float dn = inv_sqrt_fc_den;
+      SplineOut o = rq_spline_elem(
+          xv, nb, inverse != 0, -bound, bound, -bound, bound, [&](int k) { return hp[(long long)k * h_ld] / dn; },
+          [&](int k) { return hp[(long long)(nb + k) * h_ld] / dn; },
+          [&](int k) { return (k == 0 || k == nb) ? tail_const : hp[(long long)(2 * nb + k - 1) * h_ld]; });
+      out = o.y;
+      lad = o.lad;
+    }
+    y[i1] = out * mk;
+    contrib = lad * mk;
+  }
+  if (logdet) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(logdet + b, contrib);
+  }
+}
+
+static float tail_constant() { return (float)std::log(std::exp(1.0 - 1e-3) - 1.0); }
+
+struct ConvFlow {
+  int Cin = 0, half = 0, F = 0, K = 0, NL = 0, nb = 10;
+  float bound = 5.0f;
+  PackedConv pre, proj;
+  DDS dds;
+  DevBuf ws;
+
+  int create(int in_channels, int filter_channels, int k, int nl, int num_bins, float tail_bound, const TensorTable& tab,
+             const std::string& prefix, hipStream_t st) {
+    if (in_channels <= 0 || in_channels % 2 || num_bins <= 0 || num_bins > MAXB) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "ConvFlow: bad hyper-parameters");
+    Cin = in_channels; half = Cin / 2; F = filter_channels; K = k; NL = nl; nb = num_bins; bound = tail_bound;
+    PackSpec ps{}; ps.Cin = half; ps.Cout = F; ps.K = 1;
+    SVOC_TRY(pack_conv_named(pre, ps, tab, prefix + "pre", st));
+    SVOC_TRY(dds.create(F, k, nl, tab, prefix + "convs.", st));
+    PackSpec qs{}; qs.Cin = F; qs.Cout = half * (3 * nb - 1); qs.K = 1;
+    SVOC_TRY(pack_conv_named(proj, qs, tab, prefix + "proj", st));
+    return SVOC_OK;
+  }
+
+  int forward(hipStream_t st, const float* x, const float* mask, const float* g, int reverse, float* y, float* logdet, int B, int T) {
+    const int Tp = round_up(T, 4);
+    const long long fper = (long long)F * Tp;
+    const int P = half * (3 * nb - 1);
+    const long long pper = (long long)P * Tp;
+    SVOC_TRY(ws.ensure((size_t)((2 * fper + pper) * B) * sizeof(float)));
+    float* h0 = ws.f();
+    float* h1 = h0 + fper * B;
+    float* hp = h1 + fper * B;
+    {
+      ConvArgs a = mk_args2();
+      a.x = x; a.x_bs = (long long)Cin * T; a.x_ld = T; a.Lin = T; a.Ncols = T;
+      a.out[0].y = h0; a.out[0].y_bs = fper; a.out[0].y_ld = Tp; a.out[0].nrows = F;
+      SVOC_TRY(launch_conv(pre, a, B, st));
+    }
+    if (g) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "ConvFlow: g conditioning is not supported");
+    SVOC_TRY(dds.forward(st, h0, fper, Tp, mask, T, nullptr, h1, fper, Tp, B, T));
+    {
+      ConvArgs a = mk_args2();
+      a.x = h1; a.x_bs = fper; a.x_ld = Tp; a.Lin = T; a.Ncols = T;
+      a.mask = mask; a.mask_bs = T;
+      a.out[0].y = hp; a.out[0].y_bs = pper; a.out[0].y_ld = Tp; a.out[0].nrows = P; a.out[0].flags = F_OUTMASK;
+      SVOC_TRY(launch_conv(proj, a, B, st));
+    }
+    if (logdet) SVOC_TRY(k_fill(st, logdet, (size_t)B, 0.f));
+    hipLaunchKernelGGL(convflow_spline_kernel, dim3((T + 63) / 64, half, B), dim3(64), 0, st, x, hp, pper, Tp, mask, half, T, nb,
+                       sqrtf((float)F), reverse, bound, tail_constant(), y, reverse ? nullptr : logdet);
+    SVOC_HIP(hipGetLastError());
+    stats_add_other();
+    return SVOC_OK;
+  }
+};
+
+}  // namespace svoc
+
+using namespace svoc;
+struct svoc_dds { DDS m; };
+struct svoc_convflow { ConvFlow m; };
+
+#define SVOC_GUARD_BEGIN try {
+#define SVOC_GUARD_END } catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
+
+extern "C" {
+
+int svoc_dds_create(svoc_dds** out, int channels, int kernel_size, int n_layers, const svoc_tensor* tensors, int n_tensors,
+                    const char* prefix) {
+  if (!out || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_dds_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_dds> h(new svoc_dds());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(channels, kernel_size, n_layers, tab, prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_dds_forward(svoc_dds* h, void* stream, const float* x, const float* x_mask, const float* g, float* y, int B, int T) {
+  if (!h || !x || !x_mask || !y || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_dds_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  const long long bs = (long long)h->m.C * T;
+  return h->m.forward(as_stream(stream), x, bs, T, x_mask, T, g, y, bs, T, B, T);
+  SVOC_GUARD_END
+}
+void svoc_dds_destroy(svoc_dds* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_convflow_create(svoc_convflow** out, int in_channels, int filter_channels, int kernel_size, int n_layers, int num_bins,
+                         float tail_bound, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
+  if (!out || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_convflow_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_convflow> h(new svoc_convflow());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(in_channels, filter_channels, kernel_size, n_layers, num_bins, tail_bound, tab, prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const float* x_mask, const float* g, int reverse, float* y,
+                          float* logdet, int B, int T) {
+  if (!h || !x || !x_mask || !y || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_convflow_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  return h->m.forward(as_stream(stream), x, x_mask, g, reverse, y, logdet, B, T);
+  SVOC_GUARD_END
+}
+void svoc_convflow_destroy(svoc_convflow* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_rq_spline(void* stream, const float* inputs, const float* unnorm_widths, const float* unnorm_heights,
+                   const float* unnorm_derivs, int64_t n, int num_bins, int inverse, int linear_tails, float tail_bound,
+                   float* outputs, float* logabsdet) {
+  if (!inputs || !unnorm_widths || !unnorm_heights || !unnorm_derivs || !outputs || !logabsdet || n < 0 || num_bins <= 0 ||
+      num_bins > MAXB)
+    SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_rq_spline: bad arguments (num_bins must be in 1..%d)", MAXB);
+  if (n == 0) return SVOC_OK;
+  hipLaunchKernelGGL(rq_spline_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, as_stream(stream), inputs, unnorm_widths,
+                     unnorm_heights, unnorm_derivs, (long long)n, num_bins, inverse, linear_tails, tail_bound, tail_constant(),
+                     outputs, logabsdet);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
+}  // extern "C"

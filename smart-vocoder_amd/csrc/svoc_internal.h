@@ -1,0 +1,144 @@
+// Internal declarations shared by the HIP translation units of libsvoc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <memory>
+
+#include "../../include/svoc.h"
+
+namespace svoc {
+
+// ------------------------------------------------------------------ errors
+void set_error(const char* fmt, ...);
+#define SVOC_FAIL(code, ...) do { ::svoc::set_error(__VA_ARGS__); return (code); } while (0)
+#define SVOC_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    ::svoc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return SVOC_ERR_HIP; } } while (0)
+#define SVOC_TRY(expr) do { int r_ = (expr); if (r_ != SVOC_OK) return r_; } while (0)
+
+// ------------------------------------------------------------------ device buffers
+struct DevBuf {
+  void* p = nullptr; size_t bytes = 0;
+  DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int ensure(size_t n) {           // grow-only
+    if (n <= bytes) return SVOC_OK;
+    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; bytes = 0; }
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); p = nullptr; return SVOC_ERR_NOMEM; }
+    bytes = n; return SVOC_OK;
+  }
+  float* f() const { return (float*)p; }
+};
+
+// ------------------------------------------------------------------ state-dict table
+struct TensorTable {
+  std::map<std::string, const svoc_tensor*> m;
+  TensorTable(const svoc_tensor* t, int n) { for (int i = 0; i < n; ++i) if (t[i].name) m[t[i].name] = &t[i]; }
+  const svoc_tensor* find(const std::string& name) const { auto it = m.find(name); return it == m.end() ? nullptr : it->second; }
+};
+
+// ------------------------------------------------------------------ implicit-GEMM convolution
+constexpr int KC = 32;           // input channels staged in LDS per chunk
+
+enum EpiFlags : unsigned {
+  F_RES      = 1u << 0,   // val += res[row][col]
+  F_ACC      = 1u << 1,   // val = y_old + val
+  F_DIV      = 1u << 2,   // val = val / div
+  F_OUTMASK  = 1u << 3,   // val *= mask[col]
+  F_CPL_REV  = 1u << 4,   // val = (res - val*mask) * mask              (mean-only coupling, reverse)
+  F_CPL_FWD  = 1u << 5,   // val = val*mask + res*mask                   (mean-only coupling, forward)
+};
+enum EpiMode : int {
+  EPI_PLAIN = 0,          // per-element flags above, optional row split
+  EPI_UPS = 1,            // polyphase ConvTranspose1d scatter: row=(o*s+r), col=m -> y[o][m*s+r-pad]
+  EPI_GATE = 2,           // tile pairs: y = tanh(v0+g0) * sigmoid(v1+g1)
+  EPI_PROJ = 3,           // tile pairs: m=v0*mask, logs=v1*mask, z_p = m + eps*exp(logs)*noise
+  EPI_CPL_FULL_REV = 4,   // tile pairs: x1 = (x1 - v0*mask) * exp(-(v1*mask)) * mask
+  EPI_CPL_FULL_FWD = 5,   // tile pairs: x1 = v0*mask + x1*exp(v1*mask)*mask ; logdet += sum(v1*mask)
+};
+
+struct EpiOut {
+  float* y; long long y_bs; int y_ld; int nrows;     // nrows: valid rows of this output set
+  const float* res; long long res_bs; int res_ld;
+  unsigned flags; float div;
+};
+
+struct ConvArgs {
+  // input activations [B][Cin][x_ld]; positions outside [0,Lin) read as zero
+  const float* x; long long x_bs; int x_ld; int Cin; int Lin;
+  const float* in_mask; long long in_mask_bs;      // optional multiplier [B][>=Lin], applied after the activation
+  float pre_slope;                                   // leaky-relu slope applied while staging (1 = none)
+  int vec4;                                          // 1: rows are 16-byte aligned -> float4 staging loads
+  // packed weights / bias
+  const float* wp; const float* bias;
+  int nchunks; int ktaps; int dil; int pad;          // tap j reads x[n + j*dil - pad]
+  int mtiles;                                        // valid 32-row tiles
+  int ksg_total;                                     // groups of 4 k-steps per m-tile
+  int xoff0; int row_len;                            // LDS tile: starts at n0+xoff0 (multiple of 4), row_len floats
+  int Ncols;                                         // output columns
+  // epilogue
+  int mode;
+  const float* mask; long long mask_bs;              // [B][>=Ncols] output-side mask
+  int split_row;                                     // rows >= split_row use out[1] (row index rebased)
+  EpiOut out[2];
+  const float* gadd; long long gadd_bs; int gadd_ld; int gadd_ts;   // per-(batch,row[,col]) additive term (g conditioning)
+  int half_rows;                                     // paired modes: channels per half (H)
+  int ups_s; int ups_pad; int Lout;                  // EPI_UPS
+  const float* eps; long long eps_bs; int eps_ld; float noise_scale;  // EPI_PROJ
+  float* y2; float* y3;                              // EPI_PROJ: logs_p, z_p (same strides as out[0])
+  float* logdet;                                     // EPI_CPL_FULL_FWD
+};
+
+// One convolution layer repacked for the MFMA kernel.
+struct PackedConv {
+  DevBuf wp, bias;
+  int Cin = 0, CinP = 0, Cout = 0, rows = 0, mtiles = 0, ktaps = 0, dil = 1, pad = 0;
+  int ksg_total = 0;
+  bool paired = false; int half_rows = 0;
+  int split_row = 1 << 30;        // first packed row of the second row group (PackSpec::split_at)
+  bool transposed = false; int ups_s = 1, ups_pad = 0;
+  double flops_per_col = 0;       // algorithmic 2*MAC per output column (per batch element)
+};
+
+struct PackSpec {
+  int Cin, Cout, K;               // source tensor dims (Conv1d: [Cout][Cin][K]; ConvTranspose1d: [Cin][Cout][K])
+  int dil = 1;                    // Conv1d dilation
+  int pad = -1;                   // -1: "same" padding (K*dil-dil)/2
+  bool transposed = false; int stride = 1; int tpad = 0;    // ConvTranspose1d(stride, padding)
+  bool paired = false;            // rows [0,Cout/2) and [Cout/2,Cout) interleaved tile-wise
+  int split_at = 0;               // >0: rows [0,split_at) and [split_at,Cout) each padded to a multiple of 32
+  const int* out_perm = nullptr;  // packed logical out-channel o reads source channel out_perm[o]
+  const int* in_perm = nullptr;   // packed in-channel c reads source channel in_perm[c]
+};
+
+int pack_conv(PackedConv& pc, const PackSpec& spec, const float* w_or_v, const float* g, const float* bias, hipStream_t st);
+int pack_conv_named(PackedConv& pc, PackSpec spec, const TensorTable& tab, const std::string& prefix, hipStream_t st,
+                    bool bias_required = true);
+
+int fold_weight_norm(hipStream_t st, const float* v, const float* g, float* w, long long d0, long long inner);
+
+// Fills geometry fields (wp, bias, taps, tiles, LDS tile) of `a` from `pc`; caller sets x/epilogue fields first.
+int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st);
+
+// ------------------------------------------------------------------ small kernels (misc_kernels.hip)
+int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, int T);
+int k_gate(hipStream_t st, const float* a, const float* b, float* y, int B, int H, int T);
+int k_conv_post_tanh(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* w, int C, int K, float slope,
+                     float* y, int B, int L);
+int k_copy2d(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
+             int rows, int cols, const float* mask, long long mask_bs);
+int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
+                int C, int T);
+int k_fill(hipStream_t st, float* p, size_t n, float v);
+
+// stats
+void stats_add_conv(double flops);
+void stats_add_other();
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+}  // namespace svoc

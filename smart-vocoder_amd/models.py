@@ -1,0 +1,270 @@
+"""Model classes with the reference's names, constructor signatures, attribute names and state_dict
+layout (reference models.py), running SynthesizerTrn.infer on MI355X through libsvoc_hip.so.
+
+``SynthesizerTrn(...).cuda().eval()``, ``utils.load_checkpoint(path, net_g, None)`` and
+``net_g.infer(mel, lengths, noise_scale=.667)`` behave as in the reference's inference.ipynb.
+The whole of ``infer`` is ONE call into the C ABI (svoc_synth_infer): mel encoder (16-layer WN),
+reparameterisation, 4 reverse coupling layers with folded Flips, HiFi-GAN decoder.
+
+Training-side classes (DiscriminatorP/S, MultiPeriodDiscriminator) and ``SynthesizerTrn.forward``
+are out of scope; PosteriorEncoder is kept as a parameter container so the
+state_dict has the reference's 659 keys.
+"""
+import torch
+from torch import nn
+
+try:
+    from . import _native as N
+    from . import commons, modules
+    from .commons import get_padding, init_weights
+    from .modules import _Conv1dParams, _WNConvTranspose1dParams, _HipModule, _fold_in_place, _g_args, _mask_arg
+except ImportError:
+    import _native as N
+    import commons
+    import modules
+    from commons import get_padding, init_weights
+    from modules import _Conv1dParams, _WNConvTranspose1dParams, _HipModule, _fold_in_place, _g_args, _mask_arg
+
+
+class MelEncoder(nn.Module):
+    """reference models.py:15-47.  Runs as part of SynthesizerTrn.infer's single native call."""
+
+    def __init__(self, out_channels, hidden_channels, filter_channels, n_layers, kernel_size, dilation_rate, gin_channels):
+        super().__init__()
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.filter_channels = filter_channels
+        self.n_layers = n_layers
+        self.kernel_size = kernel_size
+        self.dilation_rate = dilation_rate
+        self.encoder = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
+        self.pre_enc = _Conv1dParams(80, hidden_channels, 1)
+        self.proj = _Conv1dParams(hidden_channels, out_channels * 2, 1)
+
+    def forward(self, x, x_lengths, g=None):
+        raise NotImplementedError("MelEncoder runs inside SynthesizerTrn.infer (one fused native call); "
+                                  "use SynthesizerTrn.infer(...)[2] for m_p/logs_p")
+
+
+class ResidualCouplingBlock(_HipModule):
+    """reference models.py:50-80: n_flows x (ResidualCouplingLayer(mean_only=True), Flip)."""
+    _destroy = "svoc_flow_destroy"
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows=4, gin_channels=0):
+        super().__init__()
+        self.channels = channels
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.dilation_rate = dilation_rate
+        self.n_layers = n_layers
+        self.n_flows = n_flows
+        self.gin_channels = gin_channels
+        self.flows = nn.ModuleList()
+        for i in range(n_flows):
+            self.flows.append(modules.ResidualCouplingLayer(channels, hidden_channels, kernel_size, dilation_rate, n_layers,
+                                                            gin_channels=gin_channels, mean_only=True))
+            self.flows.append(modules.Flip())
+
+    def _create(self, h, tab):
+        N.check(N.lib().svoc_flow_create(h.out(), self.channels, self.hidden_channels, self.kernel_size, self.dilation_rate,
+                                         self.n_layers, self.n_flows, self.gin_channels, tab.arr, tab.n, b""))
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        x = N.f32(x)
+        B, Cc, T = x.shape
+        m = _mask_arg(x_mask, B, T, x.device)
+        g, gT = _g_args(g, T)
+        y = torch.empty_like(x)
+        N.check(N.lib().svoc_flow_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
+                                          1 if reverse else 0, N.ptr(y), B, T))
+        return y
+
+
+class PosteriorEncoder(nn.Module):
+    """reference models.py:83-112 — training-only; kept so that ``enc_q.*`` stays in the state_dict."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.dilation_rate = dilation_rate
+        self.n_layers = n_layers
+        self.gin_channels = gin_channels
+        self.pre = _Conv1dParams(in_channels, hidden_channels, 1)
+        self.enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
+        self.proj = _Conv1dParams(hidden_channels, out_channels * 2, 1)
+
+    def forward(self, x, x_lengths, g=None):
+        raise NotImplementedError("PosteriorEncoder is training-only and outside the inference path")
+
+
+def _gen_config(initial_channel, resblock, rks, rds, ur, uic, uks, gin):
+    c = N.svoc_generator_config()
+    if len(rks) > 8 or len(ur) > 8 or any(len(d) > 8 for d in rds):
+        raise ValueError("at most 8 resblock kernels / dilations / upsamples are supported")
+    c.initial_channel = initial_channel
+    c.resblock_kind = 1 if resblock == '1' else 2
+    c.n_kernels = len(rks)
+    for j, (k, d) in enumerate(zip(rks, rds)):
+        c.resblock_kernel_sizes[j] = k
+        c.n_dilations[j] = len(d)
+        for q, dd in enumerate(d):
+            c.resblock_dilation_sizes[j][q] = dd
+    c.n_upsamples = len(ur)
+    for i, (u, k) in enumerate(zip(ur, uks)):
+        c.upsample_rates[i] = u
+        c.upsample_kernel_sizes[i] = k
+    c.upsample_initial_channel = uic
+    c.gin_channels = gin
+    return c
+
+
+class Generator(_HipModule):
+    """HiFi-GAN V1 style decoder (reference models.py:115-167)."""
+    _destroy = "svoc_generator_destroy"
+
+    def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0):
+        super(Generator, self).__init__()
+        self.num_kernels = len(resblock_kernel_sizes)
+        self.num_upsamples = len(upsample_rates)
+        self._cfg_args = (initial_channel, resblock, list(resblock_kernel_sizes), [list(d) for d in resblock_dilation_sizes],
+                          list(upsample_rates), upsample_initial_channel, list(upsample_kernel_sizes), gin_channels)
+        self.gin_channels = gin_channels
+        self.conv_pre = _Conv1dParams(initial_channel, upsample_initial_channel, 7)
+        rb = modules.ResBlock1 if resblock == '1' else modules.ResBlock2
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            self.ups.append(_WNConvTranspose1dParams(upsample_initial_channel // (2 ** i),
+                                                     upsample_initial_channel // (2 ** (i + 1)), k))
+        self.resblocks = nn.ModuleList()
+        for i in range(len(self.ups)):
+            ch = upsample_initial_channel // (2 ** (i + 1))
+            for j, (k, d) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
+                self.resblocks.append(rb(ch, k, d))
+        self.conv_post = _Conv1dParams(ch, 1, 7, bias=False)
+        if gin_channels != 0:
+            self.cond = _Conv1dParams(gin_channels, upsample_initial_channel, 1)
+        self.hop = 1
+        for u in upsample_rates:
+            self.hop *= u
+
+    def _config(self):
+        return _gen_config(*self._cfg_args)
+
+    def _create(self, h, tab):
+        cfg = self._config()
+        N.check(N.lib().svoc_generator_create(h.out(), cfg, tab.arr, tab.n, b""))
+
+    def forward(self, x, g=None):
+        x = N.f32(x)
+        B, Cc, T = x.shape
+        if g is not None:
+            g = N.f32(g)
+            if g.dim() != 3 or g.shape[2] != 1:
+                raise ValueError("g must be [B, gin_channels, 1]")
+        out = torch.empty(B, 1, T * self.hop, dtype=torch.float32, device=x.device)
+        N.check(N.lib().svoc_generator_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), T, Cc * T, None, 0,
+                                               N.ptr(g), N.ptr(out), B, T))
+        return out
+
+    def remove_weight_norm(self):
+        print('Removing weight norm...')
+        for l in self.ups:
+            _fold_in_place(l)
+        for l in self.resblocks:
+            l.remove_weight_norm()
+
+
+class SynthesizerTrn(_HipModule):
+    """reference models.py:261-349.  Only the inference entry point is implemented."""
+    _destroy = "svoc_synth_destroy"
+
+    def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
+                 kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0, **kwargs):
+        super().__init__()
+        self.spec_channels = spec_channels
+        self.inter_channels = inter_channels
+        self.hidden_channels = hidden_channels
+        self.filter_channels = filter_channels
+        self.n_heads = n_heads
+        self.n_layers = n_layers
+        self.kernel_size = kernel_size
+        self.p_dropout = p_dropout
+        self.resblock = resblock
+        self.resblock_kernel_sizes = resblock_kernel_sizes
+        self.resblock_dilation_sizes = resblock_dilation_sizes
+        self.upsample_rates = upsample_rates
+        self.upsample_initial_channel = upsample_initial_channel
+        self.upsample_kernel_sizes = upsample_kernel_sizes
+        self.segment_size = segment_size
+        self.n_speakers = n_speakers
+        self.gin_channels = gin_channels
+        # sizes hard-coded by the reference (models.py:305-314), not taken from the config
+        self.enc_p = MelEncoder(inter_channels, hidden_channels, filter_channels, n_layers=16, kernel_size=5,
+                                dilation_rate=1, gin_channels=gin_channels)
+        self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                             upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
+        self.enc_q = PosteriorEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
+        self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 8, gin_channels=gin_channels)
+
+    # enc_q is not part of infer: keep it out of the native table and of the change signature
+    def _infer_state(self):
+        return {k: v for k, v in self.state_dict(keep_vars=True).items() if not k.startswith("enc_q.")}
+
+    def _sig(self):
+        return tuple((p.data_ptr(), p._version) for p in self._infer_state().values())
+
+    def _table(self):
+        return N.TensorTable(self._infer_state())
+
+    def _create(self, h, tab):
+        c = N.svoc_synth_config()
+        c.n_mel = 80
+        c.inter_channels = self.inter_channels
+        c.hidden_channels = self.hidden_channels
+        c.enc_n_layers, c.enc_kernel_size, c.enc_dilation_rate = 16, 5, 1
+        c.flow_n_layers, c.flow_kernel_size, c.flow_dilation_rate, c.flow_n_flows = 8, 5, 1, 4
+        c.gin_channels = self.gin_channels
+        c.dec = self.dec._config()
+        N.check(N.lib().svoc_synth_create(h.out(), c, tab.arr, tab.n))
+
+    def forward(self, x, x_lengths, y, y_lengths, sid=None):
+        raise NotImplementedError("training forward is outside the MI355X inference path; use infer()")
+
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1., max_len=None, eps=None):
+        """mel [B,80,T], lengths [B] -> (o [B,1,min(T,max_len)*hop], x_mask [B,1,T], (z, z_p, m_p, logs_p)).
+
+        As in the reference, speaker conditioning is off (g=None, models.py:332) and sid/length_scale/noise_scale_w
+        are ignored.  `eps` (extension, keyword only in spirit) injects the N(0,1) draw the reference takes with
+        randn_like (models.py:336); by default it is drawn with torch.randn on the device.
+        """
+        x = N.f32(x)
+        if x.dim() != 3 or x.shape[1] != 80:
+            raise ValueError(f"expected mel [B, 80, T], got {tuple(x.shape)}")
+        B, _, T = x.shape
+        ln = x_lengths.to(device=x.device, dtype=torch.int64).contiguous()
+        if eps is None:
+            eps = torch.randn(B, self.inter_channels, T, dtype=torch.float32, device=x.device)
+        eps = N.f32(eps)
+        if tuple(eps.shape) != (B, self.inter_channels, T):
+            raise ValueError("eps must be [B, inter_channels, T]")
+        Td = T if max_len is None else max(0, min(T, int(max_len) if max_len >= 0 else T + int(max_len)))
+        dev = x.device
+        IC = self.inter_channels
+        o = torch.empty(B, 1, Td * self.dec.hop, dtype=torch.float32, device=dev)
+        x_mask = torch.empty(B, 1, T, dtype=torch.float32, device=dev)
+        z, z_p, m_p, logs_p = (torch.empty(B, IC, T, dtype=torch.float32, device=dev) for _ in range(4))
+        if Td == 0:
+            raise ValueError("max_len leaves no frames to decode")
+        N.check(N.lib().svoc_synth_infer(self._native(), N.stream_ptr(dev), N.ptr(x), N.ptr(ln), N.ptr(eps),
+                                         float(noise_scale), Td, N.ptr(o), N.ptr(x_mask), N.ptr(z), N.ptr(z_p),
+                                         N.ptr(m_p), N.ptr(logs_p), B, T))
+        return o, x_mask, (z, z_p, m_p, logs_p)
+
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
+        # the reference's implementation dereferences a non-existent self.emb_g (models.py:343)
+        raise AttributeError("'SynthesizerTrn' object has no attribute 'emb_g'")

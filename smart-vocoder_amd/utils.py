@@ -1,0 +1,110 @@
+"""Config and checkpoint I/O with the reference's names and on-disk formats (reference utils.py).
+
+In scope: HParams, get_hparams_from_file/_from_dir, load_checkpoint /
+save_checkpoint ({'model','iteration','optimizer','learning_rate'}), latest_checkpoint_path,
+load_wav_to_torch.  TensorBoard/matplotlib/logging helpers of the reference are training-side and absent.
+"""
+import glob
+import json
+import logging
+import os
+import sys
+
+import numpy as np
+import torch
+
+logging.basicConfig(stream=sys.stdout, level=logging.INFO)
+logger = logging.getLogger("smart_vocoder_amd")
+
+
+class HParams():
+    """Recursive attribute dict (reference utils.py:229-258): attr access, [] access and ** via keys()."""
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            if type(v) == dict:
+                v = HParams(**v)
+            self[k] = v
+
+    def keys(self):
+        return self.__dict__.keys()
+
+    def items(self):
+        return self.__dict__.items()
+
+    def values(self):
+        return self.__dict__.values()
+
+    def __len__(self):
+        return len(self.__dict__)
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+    def __setitem__(self, key, value):
+        return setattr(self, key, value)
+
+    def __contains__(self, key):
+        return key in self.__dict__
+
+    def __repr__(self):
+        return self.__dict__.__repr__()
+
+
+def get_hparams_from_file(config_path):
+    """reference utils.py:185-191"""
+    with open(config_path, "r") as f:
+        config = json.loads(f.read())
+    return HParams(**config)
+
+
+def get_hparams_from_dir(model_dir):
+    """reference utils.py:174-182"""
+    hparams = get_hparams_from_file(os.path.join(model_dir, "config.json"))
+    hparams.model_dir = model_dir
+    return hparams
+
+
+def load_checkpoint(checkpoint_path, model, optimizer=None):
+    """reference utils.py:18-43: tolerant load — keys missing from the file keep the model's value."""
+    assert os.path.isfile(checkpoint_path)
+    checkpoint_dict = torch.load(checkpoint_path, map_location="cpu")
+    iteration = checkpoint_dict["iteration"]
+    learning_rate = checkpoint_dict["learning_rate"]
+    if optimizer is not None:
+        optimizer.load_state_dict(checkpoint_dict["optimizer"])
+    saved_state_dict = checkpoint_dict["model"]
+    target = model.module if hasattr(model, "module") else model
+    new_state_dict = {}
+    for k, v in target.state_dict().items():
+        if k in saved_state_dict:
+            new_state_dict[k] = saved_state_dict[k]
+        else:
+            logger.info("%s is not in the checkpoint" % k)
+            new_state_dict[k] = v
+    target.load_state_dict(new_state_dict)
+    logger.info("Loaded checkpoint '{}' (iteration {})".format(checkpoint_path, iteration))
+    return model, optimizer, learning_rate, iteration
+
+
+def save_checkpoint(model, optimizer, learning_rate, iteration, checkpoint_path):
+    """reference utils.py:46-56"""
+    logger.info("Saving model and optimizer state at iteration {} to {}".format(iteration, checkpoint_path))
+    target = model.module if hasattr(model, "module") else model
+    torch.save({"model": target.state_dict(), "iteration": iteration,
+                "optimizer": optimizer.state_dict() if optimizer is not None else None,
+                "learning_rate": learning_rate}, checkpoint_path)
+
+
+def latest_checkpoint_path(dir_path, regex="G_*.pth"):
+    """reference utils.py:70-75: newest by the digits in the file name"""
+    f_list = glob.glob(os.path.join(dir_path, regex))
+    f_list.sort(key=lambda f: int("".join(filter(str.isdigit, f))))
+    return f_list[-1]
+
+
+def load_wav_to_torch(full_path):
+    """reference utils.py:133-135"""
+    from scipy.io.wavfile import read
+    sampling_rate, data = read(full_path)
+    return torch.FloatTensor(data.astype(np.float32)), sampling_rate
