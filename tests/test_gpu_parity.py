@@ -96,11 +96,10 @@ def test_conv_transpose(M, name):
     sd = sdT(sw.fill_state_dict(cases.ups_shapes(c["Ci"], c["Co"], c["k"]), c["seed"], 1.0))
     x = T(cases.rnd(c["seed"], "x", (c["B"], c["Ci"], c["L"]), 0.5))
     N = M.native
-    xc = x.cuda()
+    xc, vc, gc, bc = x.cuda(), sd["weight_v"].cuda(), sd["weight_g"].cuda(), sd["bias"].cuda()   # keep alive across the call
     y = torch.empty(c["B"], c["Co"], c["L"] * c["s"], device="cuda")
-    N.check(N.lib().svoc_conv_transpose1d(N.stream_ptr(), N.ptr(xc), N.ptr(sd["weight_v"].cuda()), N.ptr(sd["weight_g"].cuda()),
-                                          N.ptr(sd["bias"].cuda()), N.ptr(y), c["B"], c["Ci"], c["Co"], c["L"], c["k"], c["s"],
-                                          ctypes.c_float(0.1)))
+    N.check(N.lib().svoc_conv_transpose1d(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), N.ptr(y), c["B"], c["Ci"],
+                                          c["Co"], c["L"], c["k"], c["s"], ctypes.c_float(0.1)))
     check(name, y, cases.golden(name)["y"])
 
 
