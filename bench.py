@@ -31,26 +31,37 @@ SAMPLE_RATE = 22050
 
 def cpu_baseline(sd_np, B, T, seed):
     """The CPU oracle (oracle/vocoder_oracle.py, a port of the reference forward) timed on the host cores on a
-    bounded sample of the same workload: B utterances of T frames."""
+    bounded sample of the same workload: B utterances of T frames.  torch's intra-op thread count is chosen by a
+    short probe (more threads than ~16-32 make oneDNN's small convolutions slower on a 2x64-core host, see
+    profiles/r01_cpu_threads_probe.txt); `cores` reports the count actually used."""
     from oracle import vocoder_oracle as O
     from cases import sw
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     with torch.no_grad():
-        mel = torch.from_numpy(sw.synthetic_mel(seed, 1, 32)); eps = torch.from_numpy(sw.synthetic_eps(seed, 1, 32))
-        O.infer(sd, mel, torch.tensor([32]), eps, 0.667)          # thread-pool / allocator warm-up
+        pm = torch.from_numpy(sw.synthetic_mel(seed, 1, 96)); pe = torch.from_numpy(sw.synthetic_eps(seed, 1, 96))
+        best, cores = None, 1
+        for n in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(n)
+            O.infer(sd, pm[:, :, :16], torch.tensor([16]), pe[:, :, :16], 0.667)      # thread-pool warm-up
+            t0 = time.perf_counter()
+            O.infer(sd, pm, torch.tensor([96]), pe, 0.667)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, cores = dt, n
+        torch.set_num_threads(cores)
         mel = torch.from_numpy(sw.synthetic_mel(seed, B, T)); eps = torch.from_numpy(sw.synthetic_eps(seed, B, T))
         ln = torch.full((B,), T, dtype=torch.int64)
         t0 = time.perf_counter()
         o, *_ = O.infer(sd, mel, ln, eps, 0.667)
         dt = time.perf_counter() - t0
     return dict(value=o.numel() / dt, unit="samples/s", cores=cores, kind="port",
-                sample=f"{B}x{T} frames of the same synthetic workload, one pass, {dt:.2f} s, torch {torch.__version__} fp32 oneDNN")
+                sample=f"{B}x{T} frames of the same synthetic workload, one pass, {dt:.2f} s, {cores} of {avail} host threads "
+                       f"(best of a 8/16/32/64 probe), torch {torch.__version__} fp32 oneDNN")
 
 
 def main():
@@ -61,7 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=512, help="mel frames per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
     args = ap.parse_args()
 
     import cases
