@@ -63,6 +63,10 @@ const char* svoc_build_arch(void);       /* "gfx950" */
 int svoc_stats_reset(void);
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches);
 
+/* Diagnostics: bracket every convolution launch with HIP events and aggregate by layer shape. */
+int svoc_profile_enable(int on);
+int svoc_profile_report(char* buf, int buflen);
+
 /* ---- modules.WN (modules.py:111-185) ------------------------------------- */
 typedef struct svoc_wn svoc_wn;
 /* tensors: in_layers.{i}.{bias,weight_g,weight_v}, res_skip_layers.{i}.*, cond_layer.* if gin_channels>0 */

@@ -50,6 +50,8 @@ SIGNATURES = {
     "svoc_build_arch": (C.c_char_p, []),
     "svoc_stats_reset": (_I, []),
     "svoc_stats_get": (_I, [C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(_L)]),
+    "svoc_profile_enable": (_I, [_I]),
+    "svoc_profile_report": (_I, [C.c_char_p, _I]),
     "svoc_wn_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, *_TAB, C.c_char_p]),
     "svoc_wn_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I]),
     "svoc_wn_destroy": (None, [_P]),
@@ -190,3 +192,13 @@ def stats_get():
     a, b, c = _L(0), C.c_double(0), _L(0)
     lib().svoc_stats_get(C.byref(a), C.byref(b), C.byref(c))
     return dict(conv_launches=a.value, conv_flops=b.value, other_launches=c.value)
+
+
+def profile_enable(on=True):
+    lib().svoc_profile_enable(1 if on else 0)
+
+
+def profile_report():
+    buf = C.create_string_buffer(1 << 16)
+    lib().svoc_profile_report(buf, len(buf))
+    return buf.value.decode()

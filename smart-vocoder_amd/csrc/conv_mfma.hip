@@ -27,6 +27,7 @@
 #include "svoc_internal.h"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace svoc {
 
@@ -41,7 +42,7 @@ __device__ __forceinline__ float pick4(const float4& v, int s) {
 }
 
 template <int WM, int WN, int MR, int NR>
-__global__ void __launch_bounds__(WM* WN * 64) conv_mfma_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma_kernel(const ConvArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BN = WN * NR * 32;
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_mfma_kernel(const ConvArgs p
   for (int mr = 0; mr < MR; ++mr) {
     const int mt = min(mt0 + mr, p.mtiles - 1);
     abase[mr] = (long long)mt * p.ksg_total * 64 + lane;
-    a_cur[mr] = wp4[abase[mr]];
+    a_nxt[mr] = wp4[abase[mr]];
   }
   int ksg = 0;
   const int ksg_last = p.ksg_total - 1;
@@ -124,31 +125,51 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_mfma_kernel(const ConvArgs p
     __syncthreads();
 
     if (wave_active) {
-      for (int j = 0; j < p.ktaps; ++j) {
-        const float* bp = bp0 + j * p.dil;
+      // Group-level software pipeline (a group = 4 k-steps = 8 input channels of one tap): at the top of
+      // iteration gi the fragments of group gi (requested one iteration earlier) are moved into the "cur"
+      // registers, then the weight fragments (global/L2) and activation fragments (LDS) of group gi+1 are
+      // requested, then the MFMAs of group gi run.  sched_barrier pins the requests above the MFMAs; the
+      // weight stream keeps running ahead across the chunk barrier.
+      const int ngroups = p.ktaps * (KC / 8);
+      const float* bp = bp0;
+      float b_cur[4][NR], b_nxt[4][NR];
 #pragma unroll
-        for (int g = 0; g < KC / 8; ++g) {
-          ++ksg;
-          const int kn = ksg < ksg_last ? ksg : ksg_last;
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) a_nxt[mr] = wp4[abase[mr] + (long long)kn * 64];
+        for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bp[(2 * s) * p.row_len + nr * 32];
+      int g = 0;
+      for (int gi = 0; gi < ngroups; ++gi) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const float* br = bp + (g * 8 + 2 * s) * p.row_len;
-            float bf[NR];
+        for (int mr = 0; mr < MR; ++mr) a_cur[mr] = a_nxt[mr];
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) bf[nr] = br[nr * 32];
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-              const float av = pick4(a_cur[mr], s);
+          for (int nr = 0; nr < NR; ++nr) b_cur[s][nr] = b_nxt[s][nr];
+        ++ksg;
+        const int kn = ksg < ksg_last ? ksg : ksg_last;
 #pragma unroll
-              for (int nr = 0; nr < NR; ++nr)
-                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[nr], acc[mr][nr], 0, 0, 0);
-            }
-          }
+        for (int mr = 0; mr < MR; ++mr) a_nxt[mr] = wp4[abase[mr] + (long long)kn * 64];
+        const float* bpn = (g == KC / 8 - 1) ? bp + p.dil - (KC - 8) * p.row_len : bp + 8 * p.row_len;
+        if (gi + 1 < ngroups) {
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) a_cur[mr] = a_nxt[mr];
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bpn[(2 * s) * p.row_len + nr * 32];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) {
+            const float av = pick4(a_cur[mr], s);
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+              acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[s][nr], acc[mr][nr], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bp = bpn;
+        g = (g + 1) & (KC / 8 - 1);
       }
     }
   }
@@ -381,7 +402,16 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   a.xoff0 = minoff & ~3;                                  // floor to a multiple of 4 (two's complement)
   a.row_len = round_up(BN + maxoff - a.xoff0, 4);
 
-  stats_add_conv(pc.flops_per_col * (double)B * (double)(pc.transposed ? a.Lin : a.Ncols));
+  const double flops = pc.flops_per_col * (double)B * (double)(pc.transposed ? a.Lin : a.Ncols);
+  stats_add_conv(flops);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%dx%dx%d m%d", pc.transposed ? "convT" : "conv ", pc.Cin, pc.Cout,
+             pc.transposed ? pc.ktaps * pc.ups_s : pc.ktaps, pc.dil, a.Ncols, B, c.WM, c.WN, c.MR, c.NR, a.mode);
+    prof_idx = prof_begin(st, d, flops);
+  }
+  struct ProfEnd { hipStream_t st; int i; ~ProfEnd() { prof_end(st, i); } } prof_end_guard{st, prof_idx};
 
 #define SVOC_LAUNCH(C) if (c.WM == C.WM && c.WN == C.WN && c.MR == C.MR && c.NR == C.NR) return launch_cfg<C.WM, C.WN, C.MR, C.NR>(a, B, st)
   SVOC_LAUNCH(CFG_A);

@@ -4,6 +4,8 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
+#include <algorithm>
 
 namespace svoc {
 
@@ -30,6 +32,52 @@ void stats_get(long long* cl, double* cf, long long* ol) {
   if (cl) *cl = g_conv_launches.load();
   if (cf) *cf = g_conv_flops.load();
   if (ol) *ol = g_other_launches.load();
+}
+
+// ------------------------------------------------------------------ per-launch profiler (diagnostics only)
+// When enabled, every convolution launch is bracketed with HIP events on its stream; the report aggregates
+// by layer shape.  Off by default (events serialise nothing but cost a few microseconds per launch).
+struct ProfRec { std::string desc; hipEvent_t e0, e1; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+bool prof_enabled() { return g_prof_on; }
+void prof_enable(bool on) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_on = on;
+}
+int prof_begin(hipStream_t st, const std::string& desc, double flops) {
+  ProfRec r; r.desc = desc; r.flops = flops;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+  (void)hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+  return (int)g_prof.size() - 1;
+}
+void prof_end(hipStream_t st, int idx) { if (idx >= 0) (void)hipEventRecord(g_prof[idx].e1, st); }
+std::string prof_report() {
+  std::map<std::string, std::pair<int, std::pair<double, double>>> agg;   // desc -> (n, (ms, flops))
+  std::vector<std::string> order;
+  for (auto& r : g_prof) {
+    (void)hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    auto it = agg.find(r.desc);
+    if (it == agg.end()) { order.push_back(r.desc); agg[r.desc] = {1, {ms, r.flops}}; }
+    else { it->second.first++; it->second.second.first += ms; it->second.second.second += r.flops; }
+  }
+  std::string out = "layer-shape                                                      n   total_ms    mean_us   TFLOP/s\n";
+  char line[256];
+  double tms = 0, tfl = 0;
+  for (auto& d : order) {
+    auto& a = agg[d];
+    snprintf(line, sizeof(line), "%-62s %5d %10.3f %10.1f %9.1f\n", d.c_str(), a.first, a.second.first,
+             a.second.first * 1e3 / a.first, a.second.second / (a.second.first * 1e-3) / 1e12);
+    out += line;
+    tms += a.second.first; tfl += a.second.second;
+  }
+  snprintf(line, sizeof(line), "%-62s %5zu %10.3f %10s %9.1f\n", "TOTAL", g_prof.size(), tms, "", tms > 0 ? tfl / (tms * 1e-3) / 1e12 : 0.0);
+  out += line;
+  return out;
 }
 
 // ------------------------------------------------------------------ sequence mask (commons.py:121-125, models.py:40)
@@ -219,6 +267,15 @@ int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_la
   if (conv_launches) *conv_launches = cl;
   if (conv_flops) *conv_flops = cf;
   if (other_launches) *other_launches = ol;
+  return SVOC_OK;
+}
+int svoc_profile_enable(int on) { svoc::prof_enable(on != 0); return SVOC_OK; }
+int svoc_profile_report(char* buf, int buflen) {
+  if (!buf || buflen <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_profile_report: bad buffer");
+  const std::string r = svoc::prof_report();
+  const int n = (int)std::min<size_t>(r.size(), (size_t)buflen - 1);
+  memcpy(buf, r.data(), n);
+  buf[n] = 0;
   return SVOC_OK;
 }
 int svoc_sequence_mask(void* stream, const int64_t* lengths, float* mask, int B, int T) {

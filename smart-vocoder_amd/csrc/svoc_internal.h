@@ -134,7 +134,10 @@ int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, floa
                 int C, int T);
 int k_fill(hipStream_t st, float* p, size_t n, float v);
 
-// stats
+// stats / profiler
+bool prof_enabled();
+int prof_begin(hipStream_t st, const std::string& desc, double flops);
+void prof_end(hipStream_t st, int idx);
 void stats_add_conv(double flops);
 void stats_add_other();
 
