@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace svoc {
 
@@ -86,41 +87,77 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
   const float slope = p.pre_slope;
   const bool act = slope != 1.0f;
   const float* bp0 = xs + hi * p.row_len + (wn * NR * 32 + l31 - p.pad - p.xoff0);
+  constexpr int SU = 8;
+  const int stage_total = KC * R4;
+  const int wc0 = tid / R4, wg0 = tid - wc0 * R4;
+  const int stage_dc = NT / R4, stage_dg = NT - stage_dc * R4;
+
+  // Phase stagger: identical co-resident workgroups start together and then stay phase-locked (all stage, all
+  // MFMA, all store), so memory time adds to MFMA time instead of hiding under it.  The workgroups that fill
+  // the 2nd/3rd slot of each CU in the first dispatch round are delayed by a fraction of a block period;
+  // successors inherit the offset because every workgroup of a launch takes the same time.
+  if (p.stagger_cycles > 0) {
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int slot = lin / p.stagger_round;
+    if (slot > 0 && slot < p.stagger_slots) {
+      const long long t_end = __builtin_readcyclecounter() + (long long)slot * p.stagger_cycles;
+      while ((long long)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
+  }
 
   for (int ch = 0; ch < p.nchunks; ++ch) {
     __syncthreads();
-    // ---- stage [KC][row_len] activations, zero-filled outside [0,Lin) and beyond Cin
+    // ---- stage [KC][row_len] activations, zero-filled outside [0,Lin) and beyond Cin.  SU float4 groups per
+    // thread are requested back-to-back before any is consumed, so one memory latency covers SU loads.
     const int c0 = ch * KC;
-    for (int idx = tid; idx < KC * R4; idx += NT) {
-      const int c = idx / R4;
-      const int g4 = idx - c * R4;
-      const int gc = c0 + c;
-      const int t = xs_start + 4 * g4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
-        const float* row = xb + (long long)gc * p.x_ld;
-        if (p.vec4 && t >= 0 && t + 3 < p.Lin) {
-          v = *reinterpret_cast<const float4*>(row + t);
-        } else {
-          if (t >= 0 && t < p.Lin) v.x = row[t];
-          if (t + 1 >= 0 && t + 1 < p.Lin) v.y = row[t + 1];
-          if (t + 2 >= 0 && t + 2 < p.Lin) v.z = row[t + 2];
-          if (t + 3 >= 0 && t + 3 < p.Lin) v.w = row[t + 3];
+    {
+      int wc = wc0, wg = wg0;   // (channel, float4-group) walker for idx = tid + i*NT, no divisions
+      for (int base = tid; base < stage_total; base += NT * SU) {
+        float4 v[SU];
+        int lds_off[SU];
+        int tt[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int gc = c0 + wc;
+          const int t = xs_start + 4 * wg;
+          tt[u] = t;
+          lds_off[u] = (base + u * NT < stage_total) ? wc * p.row_len + 4 * wg : -1;
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (lds_off[u] >= 0 && gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
+            const float* row = xb + (long long)gc * p.x_ld;
+            if (p.vec4 && t >= 0 && t + 3 < p.Lin) {
+              v[u] = *reinterpret_cast<const float4*>(row + t);
+            } else {
+              if (t >= 0 && t < p.Lin) v[u].x = row[t];
+              if (t + 1 >= 0 && t + 1 < p.Lin) v[u].y = row[t + 1];
+              if (t + 2 >= 0 && t + 2 < p.Lin) v[u].z = row[t + 2];
+              if (t + 3 >= 0 && t + 3 < p.Lin) v[u].w = row[t + 3];
+            }
+          }
+          wc += stage_dc;
+          wg += stage_dg;
+          if (wg >= R4) { wg -= R4; ++wc; }
         }
-        if (act) {
-          v.x = v.x > 0.f ? v.x : v.x * slope;
-          v.y = v.y > 0.f ? v.y : v.y * slope;
-          v.z = v.z > 0.f ? v.z : v.z * slope;
-          v.w = v.w > 0.f ? v.w : v.w * slope;
-        }
-        if (mb) {
-          if (t >= 0 && t < p.Lin) v.x *= mb[t];
-          if (t + 1 >= 0 && t + 1 < p.Lin) v.y *= mb[t + 1];
-          if (t + 2 >= 0 && t + 2 < p.Lin) v.z *= mb[t + 2];
-          if (t + 3 >= 0 && t + 3 < p.Lin) v.w *= mb[t + 3];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          if (lds_off[u] < 0) continue;
+          float4 q = v[u];
+          if (act) {
+            q.x = q.x > 0.f ? q.x : q.x * slope;
+            q.y = q.y > 0.f ? q.y : q.y * slope;
+            q.z = q.z > 0.f ? q.z : q.z * slope;
+            q.w = q.w > 0.f ? q.w : q.w * slope;
+          }
+          if (mb) {
+            const int t = tt[u];
+            q.x *= (t >= 0 && t < p.Lin) ? mb[t] : 0.f;
+            q.y *= (t + 1 >= 0 && t + 1 < p.Lin) ? mb[t + 1] : 0.f;
+            q.z *= (t + 2 >= 0 && t + 2 < p.Lin) ? mb[t + 2] : 0.f;
+            q.w *= (t + 3 >= 0 && t + 3 < p.Lin) ? mb[t + 3] : 0.f;
+          }
+          *reinterpret_cast<float4*>(xs + lds_off[u]) = q;
         }
       }
-      *reinterpret_cast<float4*>(xs + c * p.row_len + 4 * g4) = v;
     }
     __syncthreads();
 
@@ -338,6 +375,7 @@ constexpr TileCfg CFG_A{4, 1, 2, 4};   // 256 rows x 128 cols
 constexpr TileCfg CFG_B{2, 2, 2, 2};   // 128 x 128
 constexpr TileCfg CFG_C{2, 2, 1, 4};   //  64 x 256
 constexpr TileCfg CFG_D{1, 4, 1, 4};   //  32 x 512
+constexpr TileCfg CFG_D2{1, 4, 1, 2};  //  32 x 256
 constexpr TileCfg CFG_E{2, 2, 2, 1};   // 128 x  64  (short sequences, paired)
 constexpr TileCfg CFG_F{2, 2, 1, 1};   //  64 x  64  (short sequences)
 constexpr TileCfg CFG_G{1, 4, 1, 1};   //  32 x 128  (short sequences, odd tile counts)
@@ -394,7 +432,7 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   else if (mt % 8 == 0) c = CFG_A;
   else if (mt % 4 == 0) c = CFG_B;
   else if (mt % 2 == 0) c = CFG_C;
-  else c = CFG_D;
+  else c = CFG_D2;
 
   const int BN = c.WN * c.NR * 32;
   const int off_first = -pc.pad, off_last = (pc.ktaps - 1) * pc.dil - pc.pad;
@@ -402,6 +440,14 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   a.xoff0 = minoff & ~3;                                  // floor to a multiple of 4 (two's complement)
   a.row_len = round_up(BN + maxoff - a.xoff0, 4);
 
+  {
+    static const char* env = getenv("SVOC_STAGGER");          // fraction of the per-block MFMA time, default below
+    const double frac = env ? atof(env) : 0.0;
+    const int occ = (c.MR * c.NR >= 8) ? 2 : (c.MR * c.NR >= 4 ? 3 : 4);
+    a.stagger_slots = occ;
+    a.stagger_round = 256;
+    a.stagger_cycles = (int)(frac * (double)a.nchunks * a.ktaps * 16.0 * c.MR * c.NR * 64.0);
+  }
   const double flops = pc.flops_per_col * (double)B * (double)(pc.transposed ? a.Lin : a.Ncols);
   stats_add_conv(flops);
   int prof_idx = -1;
@@ -418,6 +464,7 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   SVOC_LAUNCH(CFG_B);
   SVOC_LAUNCH(CFG_C);
   SVOC_LAUNCH(CFG_D);
+  SVOC_LAUNCH(CFG_D2);
   SVOC_LAUNCH(CFG_E);
   SVOC_LAUNCH(CFG_F);
   SVOC_LAUNCH(CFG_G);
