@@ -43,7 +43,7 @@ __device__ __forceinline__ float pick4(const float4& v, int s) {
 }
 
 template <int WM, int WN, int MR, int NR>
-__global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma_kernel(const ConvArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BN = WN * NR * 32;
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mr][nr][i] = 0.0f;
+      for (int i = 0; i < 16; ++i)   // bias folded into the accumulator (no dependent loads in the epilogue)
+        acc[mr][nr][i] = p.bias[min(mt0 + mr, p.mtiles - 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
 
   // ---- weight fragment stream (prefetched one group of 4 k-steps ahead)
   const float4* wp4 = reinterpret_cast<const float4*>(p.wp);
@@ -87,8 +88,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
   const float slope = p.pre_slope;
   const bool act = slope != 1.0f;
   const float* bp0 = xs + hi * p.row_len + (wn * NR * 32 + l31 - p.pad - p.xoff0);
-  constexpr int SU = 8;
-  const int stage_total = KC * R4;
+  constexpr int SU = 9;
+  const int stage_total = p.kcs * R4;
   const int wc0 = tid / R4, wg0 = tid - wc0 * R4;
   const int stage_dc = NT / R4, stage_dg = NT - stage_dc * R4;
 
@@ -105,7 +106,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
     }
   }
 
-  for (int ch = 0; ch < p.nchunks; ++ch) {
+  const int sub_per_stage = p.kcs / KC;
+  for (int ch = 0; ch < p.nchunks; ch += sub_per_stage) {
     __syncthreads();
     // ---- stage [KC][row_len] activations, zero-filled outside [0,Lin) and beyond Cin.  SU float4 groups per
     // thread are requested back-to-back before any is consumed, so one memory latency covers SU loads.
@@ -114,16 +116,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
       int wc = wc0, wg = wg0;   // (channel, float4-group) walker for idx = tid + i*NT, no divisions
       for (int base = tid; base < stage_total; base += NT * SU) {
         float4 v[SU];
-        int lds_off[SU];
-        int tt[SU];
+        const int wc_s = wc, wg_s = wg;
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           const int gc = c0 + wc;
           const int t = xs_start + 4 * wg;
-          tt[u] = t;
-          lds_off[u] = (base + u * NT < stage_total) ? wc * p.row_len + 4 * wg : -1;
           v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (lds_off[u] >= 0 && gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
+          if (base + u * NT < stage_total && gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
             const float* row = xb + (long long)gc * p.x_ld;
             if (p.vec4 && t >= 0 && t + 3 < p.Lin) {
               v[u] = *reinterpret_cast<const float4*>(row + t);
@@ -138,24 +137,29 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
           wg += stage_dg;
           if (wg >= R4) { wg -= R4; ++wc; }
         }
+        int wc2 = wc_s, wg2 = wg_s;   // second pass of the same walk: activation, mask, LDS write
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
-          if (lds_off[u] < 0) continue;
-          float4 q = v[u];
-          if (act) {
-            q.x = q.x > 0.f ? q.x : q.x * slope;
-            q.y = q.y > 0.f ? q.y : q.y * slope;
-            q.z = q.z > 0.f ? q.z : q.z * slope;
-            q.w = q.w > 0.f ? q.w : q.w * slope;
+          if (base + u * NT < stage_total) {
+            float4 q = v[u];
+            if (act) {
+              q.x = q.x > 0.f ? q.x : q.x * slope;
+              q.y = q.y > 0.f ? q.y : q.y * slope;
+              q.z = q.z > 0.f ? q.z : q.z * slope;
+              q.w = q.w > 0.f ? q.w : q.w * slope;
+            }
+            if (mb) {
+              const int t = xs_start + 4 * wg2;
+              q.x *= (t >= 0 && t < p.Lin) ? mb[t] : 0.f;
+              q.y *= (t + 1 >= 0 && t + 1 < p.Lin) ? mb[t + 1] : 0.f;
+              q.z *= (t + 2 >= 0 && t + 2 < p.Lin) ? mb[t + 2] : 0.f;
+              q.w *= (t + 3 >= 0 && t + 3 < p.Lin) ? mb[t + 3] : 0.f;
+            }
+            *reinterpret_cast<float4*>(xs + wc2 * p.row_len + 4 * wg2) = q;
           }
-          if (mb) {
-            const int t = tt[u];
-            q.x *= (t >= 0 && t < p.Lin) ? mb[t] : 0.f;
-            q.y *= (t + 1 >= 0 && t + 1 < p.Lin) ? mb[t + 1] : 0.f;
-            q.z *= (t + 2 >= 0 && t + 2 < p.Lin) ? mb[t + 2] : 0.f;
-            q.w *= (t + 3 >= 0 && t + 3 < p.Lin) ? mb[t + 3] : 0.f;
-          }
-          *reinterpret_cast<float4*>(xs + lds_off[u]) = q;
+          wc2 += stage_dc;
+          wg2 += stage_dg;
+          if (wg2 >= R4) { wg2 -= R4; ++wc2; }
         }
       }
     }
@@ -167,7 +171,10 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
       // registers, then the weight fragments (global/L2) and activation fragments (LDS) of group gi+1 are
       // requested, then the MFMAs of group gi run.  sched_barrier pins the requests above the MFMAs; the
       // weight stream keeps running ahead across the chunk barrier.
-      const int ngroups = p.ktaps * (KC / 8);
+      const int nsub = min(sub_per_stage, p.nchunks - ch);
+      const int ngroups = nsub * p.ktaps * (KC / 8);
+      const int groups_per_sub = p.ktaps * (KC / 8);
+      int gsub = 0;                       // groups done in the current 32-channel sub-chunk
       const float* bp = bp0;
       float b_cur[4][NR], b_nxt[4][NR];
 #pragma unroll
@@ -186,7 +193,12 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
         const int kn = ksg < ksg_last ? ksg : ksg_last;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) a_nxt[mr] = wp4[abase[mr] + (long long)kn * 64];
-        const float* bpn = (g == KC / 8 - 1) ? bp + p.dil - (KC - 8) * p.row_len : bp + 8 * p.row_len;
+        // next group: +8 channels; after 32 channels next tap; after the last tap the next 32-channel sub-chunk
+        ++gsub;
+        const float* bpn = (g != KC / 8 - 1) ? bp + 8 * p.row_len
+                           : (gsub != groups_per_sub ? bp + p.dil - (KC - 8) * p.row_len
+                                                     : bp + 8 * p.row_len - (p.ktaps - 1) * p.dil);
+        if (gsub == groups_per_sub) gsub = 0;
         if (gi + 1 < ngroups) {
 #pragma unroll
           for (int s = 0; s < 4; ++s)
@@ -245,7 +257,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
           const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
           const int rr = rbase + lr;
           if (rr >= onrows) continue;
-          float v = acc[mr][nr][r] + p.bias[trow0 + lr];
+          float v = acc[mr][nr][r];
           if (gaddb) v += gaddb[(long long)rr * p.gadd_ld + (long long)col * p.gadd_ts];
           float* yp = oy + (long long)b * oy_bs + (long long)rr * oy_ld + col;
           if (fl & (F_RES | F_CPL_REV | F_CPL_FWD)) {
@@ -283,10 +295,10 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
             const int oc = row0 >> 3;
             const int n = col * 8 + (row0 & 7) - p.ups_pad;
             float4 v;
-            v.x = acc[mr][nr][4 * q + 0] + p.bias[row0 + 0];
-            v.y = acc[mr][nr][4 * q + 1] + p.bias[row0 + 1];
-            v.z = acc[mr][nr][4 * q + 2] + p.bias[row0 + 2];
-            v.w = acc[mr][nr][4 * q + 3] + p.bias[row0 + 3];
+            v.x = acc[mr][nr][4 * q + 0];
+            v.y = acc[mr][nr][4 * q + 1];
+            v.z = acc[mr][nr][4 * q + 2];
+            v.w = acc[mr][nr][4 * q + 3];
             float* yp = yb + (long long)oc * o.y_ld + n;
             if (n >= 0 && n + 3 < p.Lout) {
               *reinterpret_cast<float4*>(yp) = v;
@@ -302,7 +314,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
               const int row = row0 + i;
               const int oc = row / s;
               const int n = col * s + (row - oc * s) - p.ups_pad;
-              if (row < o.nrows && n >= 0 && n < p.Lout) yb[(long long)oc * o.y_ld + n] = acc[mr][nr][4 * q + i] + p.bias[row];
+              if (row < o.nrows && n >= 0 && n < p.Lout) yb[(long long)oc * o.y_ld + n] = acc[mr][nr][4 * q + i];
             }
           }
         }
@@ -331,8 +343,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 1)) conv_mfma
           const int chn = pi * 32 + rr;
           if (chn >= H) continue;
           const int rowA = (mt0 + mr) * 32 + rr;
-          float vA = acc[mr][nr][r] + p.bias[rowA];
-          float vB = acc[mr + 1][nr][r] + p.bias[rowA + 32];
+          float vA = acc[mr][nr][r];
+          float vB = acc[mr + 1][nr][r];
           const long long yo = (long long)b * o.y_bs + (long long)chn * o.y_ld + col;
           if (p.mode == EPI_GATE) {
             if (gaddb) {
@@ -386,11 +398,11 @@ int launch_cfg(const ConvArgs& a, int B, hipStream_t st) {
   auto kern = conv_mfma_kernel<WM, WN, MR, NR>;
   static bool attr_set = false;
   if (!attr_set) {
-    SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const size_t lds = (size_t)KC * a.row_len * sizeof(float);
-  if (lds > 96 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "conv LDS tile of %zu bytes exceeds 96 KiB (kernel %d taps, dilation %d)", lds, a.ktaps, a.dil);
+  const size_t lds = (size_t)a.kcs * a.row_len * sizeof(float);
+  if (lds > 160 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "conv LDS tile of %zu bytes exceeds 160 KiB (kernel %d taps, dilation %d)", lds, a.ktaps, a.dil);
   dim3 grid((a.Ncols + BN - 1) / BN, (a.mtiles + WM * MR - 1) / (WM * MR), B);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, a);
   SVOC_HIP(hipGetLastError());
@@ -439,6 +451,13 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   const int minoff = std::min(off_first, off_last), maxoff = std::max(off_first, off_last);
   a.xoff0 = minoff & ~3;                                  // floor to a multiple of 4 (two's complement)
   a.row_len = round_up(BN + maxoff - a.xoff0, 4);
+  {   // input channels staged per memory round trip: as many 32-channel chunks as fit the per-block LDS budget
+    // ... and one batch of staging loads (9 float4 per thread x 256 threads)
+    static const int budget = getenv("SVOC_LDS_BUDGET") ? atoi(getenv("SVOC_LDS_BUDGET")) : 9 * 256 * 16;
+    const int per32 = KC * a.row_len * (int)sizeof(float);
+    const int nfit = std::max(1, budget / per32);
+    a.kcs = KC * std::min(a.nchunks, nfit);
+  }
 
   {
     static const char* env = getenv("SVOC_STAGGER");          // fraction of the per-block MFMA time, default below

@@ -5,6 +5,7 @@
 #include "svoc_internal.h"
 
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 namespace svoc {
@@ -25,6 +26,12 @@ static void set_out(EpiOut& o, float* y, long long bs, int ld, int nrows, unsign
 }
 static void set_res(EpiOut& o, const float* r, long long bs, int ld) { o.res = r; o.res_bs = bs; o.res_ld = ld; }
 static inline int pad4(int n) { return round_up(n, 4); }
+// Row stride of the decoder's stage tensors.  Their natural lengths are powers of two times T; padding the
+// stride by a few cache lines keeps the 32 channel rows of a tile from mapping to the same HBM channels.
+static inline int stage_ld(int n) {
+  static const int extra = getenv("SVOC_LDPAD") ? atoi(getenv("SVOC_LDPAD")) : 0;
+  return round_up(n, 4) + extra;
+}
 
 // =================================================================== WN (modules.py:111-185)
 struct WNStack {
@@ -334,10 +341,10 @@ struct Generator {
     return SVOC_OK;
   }
 
-  size_t stage_floats(int T) const {   // largest [C_i][pad4(L_i)] over conv_pre output and all stages
-    size_t m = (size_t)cfg.upsample_initial_channel * pad4(T);
+  size_t stage_floats(int T) const {   // largest [C_i][stage_ld(L_i)] over conv_pre output and all stages
+    size_t m = (size_t)cfg.upsample_initial_channel * stage_ld(T);
     int ch = cfg.upsample_initial_channel; long long L = T;
-    for (int i = 0; i < cfg.n_upsamples; ++i) { ch /= 2; L *= cfg.upsample_rates[i]; m = std::max(m, (size_t)ch * pad4((int)L)); }
+    for (int i = 0; i < cfg.n_upsamples; ++i) { ch /= 2; L *= cfg.upsample_rates[i]; m = std::max(m, (size_t)ch * stage_ld((int)L)); }
     return m;
   }
   size_t workspace_bytes(int B, int T) const { return (4 * stage_floats(T) * B + (size_t)cfg.upsample_initial_channel * B) * sizeof(float); }
@@ -352,7 +359,7 @@ struct Generator {
     int r = 0;
     int ch = cfg.upsample_initial_channel;
     int L = T;
-    int ld = pad4(L);
+    int ld = stage_ld(L);
     if (g) {
       if (!cond) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: g given but gin_channels == 0");
       ConvArgs a = mk_args();
@@ -379,7 +386,7 @@ struct Generator {
       float* XS = bufs[(r + 2) & 3];
       float* A = bufs[(r + 3) & 3];
       float* Bf = R;   // dead once the upsampler has consumed it
-      const int Lo = L * u, ldo = pad4(Lo), cho = ch / 2;
+      const int Lo = L * u, ldo = stage_ld(Lo), cho = ch / 2;
       {   // lrelu(0.1) -> ConvTranspose1d as polyphase GEMM (models.py:147-148)
         ConvArgs a = mk_args();
         set_in(a, R, (long long)ch * ld, ld, L);

@@ -74,7 +74,7 @@ struct ConvArgs {
   int vec4;                                          // 1: rows are 16-byte aligned -> float4 staging loads
   // packed weights / bias
   const float* wp; const float* bias;
-  int nchunks; int ktaps; int dil; int pad;          // tap j reads x[n + j*dil - pad]
+  int nchunks; int kcs; int ktaps; int dil; int pad;   // kcs: channels staged per round trip (multiple of 32);          // tap j reads x[n + j*dil - pad]
   int mtiles;                                        // valid 32-row tiles
   int ksg_total;                                     // groups of 4 k-steps per m-tile
   int xoff0; int row_len;                            // LDS tile: starts at n0+xoff0 (multiple of 4), row_len floats
