@@ -66,6 +66,10 @@ int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_la
 /* Diagnostics: bracket every convolution launch with HIP events and aggregate by layer shape. */
 int svoc_profile_enable(int on);
 int svoc_profile_report(char* buf, int buflen);
+/* Diagnostics: run lrelu->Conv1d(C->C,k,d)[+residual] twice with per-workgroup cycle stamps; out4 = mean cycles of
+ * {staging of the first stage, MFMA (+later stages), epilogue} and the span of the last launch. */
+int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                           int B, int C, int L, int kernel_size, int dilation, double* out4);
 
 /* ---- modules.WN (modules.py:111-185) ------------------------------------- */
 typedef struct svoc_wn svoc_wn;

@@ -93,19 +93,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
   const int wc0 = tid / R4, wg0 = tid - wc0 * R4;
   const int stage_dc = NT / R4, stage_dg = NT - stage_dc * R4;
 
-  // Phase stagger: identical co-resident workgroups start together and then stay phase-locked (all stage, all
-  // MFMA, all store), so memory time adds to MFMA time instead of hiding under it.  The workgroups that fill
-  // the 2nd/3rd slot of each CU in the first dispatch round are delayed by a fraction of a block period;
-  // successors inherit the offset because every workgroup of a launch takes the same time.
-  if (p.stagger_cycles > 0) {
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int slot = lin / p.stagger_round;
-    if (slot > 0 && slot < p.stagger_slots) {
-      const long long t_end = __builtin_readcyclecounter() + (long long)slot * p.stagger_cycles;
-      while ((long long)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-
+  long long tstamp[4] = {0, 0, 0, 0};
+  if (p.dbg) tstamp[0] = __builtin_readcyclecounter();
   const int sub_per_stage = p.kcs / KC;
   for (int ch = 0; ch < p.nchunks; ch += sub_per_stage) {
     __syncthreads();
@@ -164,6 +153,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
       }
     }
     __syncthreads();
+    if (p.dbg && ch == 0) tstamp[1] = __builtin_readcyclecounter();
 
     if (wave_active) {
       // Group-level software pipeline (a group = 4 k-steps = 8 input channels of one tap): at the top of
@@ -223,8 +213,10 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
     }
   }
 
+  if (p.dbg) tstamp[2] = __builtin_readcyclecounter();
   if (!wave_active) return;
 
+  auto run_epilogue = [&]() {
   // ------------------------------------------------------------------ epilogues
   const float* maskb = p.mask ? p.mask + (long long)b * p.mask_bs : nullptr;
   const float* gaddb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
@@ -377,6 +369,14 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
       if (lane == 0) atomicAdd(p.logdet + b, lsum);
     }
   }
+  };
+  run_epilogue();
+  if (p.dbg && threadIdx.x == 0) {
+    tstamp[3] = __builtin_readcyclecounter();
+    const long long lin = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    long long* d = p.dbg + 4 * lin;
+    d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -459,14 +459,6 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
     a.kcs = KC * std::min(a.nchunks, nfit);
   }
 
-  {
-    static const char* env = getenv("SVOC_STAGGER");          // fraction of the per-block MFMA time, default below
-    const double frac = env ? atof(env) : 0.0;
-    const int occ = (c.MR * c.NR >= 8) ? 2 : (c.MR * c.NR >= 4 ? 3 : 4);
-    a.stagger_slots = occ;
-    a.stagger_round = 256;
-    a.stagger_cycles = (int)(frac * (double)a.nchunks * a.ktaps * 16.0 * c.MR * c.NR * 64.0);
-  }
   const double flops = pc.flops_per_col * (double)B * (double)(pc.transposed ? a.Lin : a.Ncols);
   stats_add_conv(flops);
   int prof_idx = -1;

@@ -142,7 +142,8 @@ struct ResBlock {
 
   // x read-only [B][C][x_ld]; A, Bf scratch [B][C][ld]; the block's result goes to `sink`
   int run(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs, float* A,
-          float* Bf, long long bs, int ld, const ResSink& sink, int B, int L) {
+          float* Bf, long long bs, int ld, const ResSink& sink, int B, int L, hipEvent_t wait_before_last = nullptr,
+          hipEvent_t record_after_last = nullptr) {
     const float* cur = x; long long cur_bs = x_bs; int cur_ld = x_ld;
     for (int i = 0; i < ND; ++i) {
       const bool last = i == ND - 1;
@@ -168,7 +169,9 @@ struct ResBlock {
         a.out[0].div = sink.div;
       }
       set_res(a.out[0], cur, cur_bs, cur_ld);
+      if (last && wait_before_last) SVOC_HIP(hipStreamWaitEvent(st, wait_before_last, 0));
       SVOC_TRY(launch_conv(kind == 1 ? *c2[i] : *c1[i], a, B, st));
+      if (last && record_after_last) SVOC_HIP(hipEventRecord(record_after_last, st));
       cur = Bf; cur_bs = bs; cur_ld = ld;
     }
     return SVOC_OK;
@@ -303,9 +306,32 @@ struct Generator {
   int post_C = 0;
   DevBuf ws;
   int hop = 1;
+  // The n_kernels ResBlock chains of one MRF stage are independent until their last conv; they run on separate
+  // streams so that workgroups of different kernels (different durations) share the CUs: identical co-resident
+  // workgroups of ONE kernel stay phase-locked (all stage, all MFMA, all store) and their memory time adds to
+  // their MFMA time.  Also fills each kernel's tail.  Ordered with events (hipGraph-capturable fork/join).
+  std::vector<hipStream_t> chain_st;
+  std::vector<hipEvent_t> chain_done;
+  hipEvent_t ev_fork = nullptr;
+  bool use_streams = true;
+  ~Generator() {
+    for (auto s : chain_st) if (s) (void)hipStreamDestroy(s);
+    for (auto e : chain_done) if (e) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+  }
 
   int create(const svoc_generator_config& c, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
     cfg = c;
+    use_streams = !(getenv("SVOC_STREAMS") && atoi(getenv("SVOC_STREAMS")) == 0) && c.n_kernels > 1;
+    if (use_streams) {
+      chain_st.assign(c.n_kernels, nullptr);
+      chain_done.assign(c.n_kernels, nullptr);
+      for (int j = 0; j < c.n_kernels; ++j) {
+        SVOC_HIP(hipStreamCreateWithFlags(&chain_st[j], hipStreamNonBlocking));
+        SVOC_HIP(hipEventCreateWithFlags(&chain_done[j], hipEventDisableTiming));
+      }
+      SVOC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    }
     if (c.n_upsamples <= 0 || c.n_upsamples > 8 || c.n_kernels <= 0 || c.n_kernels > 8) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: bad configuration");
     PackSpec ps{}; ps.Cin = c.initial_channel; ps.Cout = c.upsample_initial_channel; ps.K = 7; ps.pad = 3;
     SVOC_TRY(pack_conv_named(conv_pre, ps, tab, prefix + "conv_pre", st));
@@ -347,27 +373,29 @@ struct Generator {
     for (int i = 0; i < cfg.n_upsamples; ++i) { ch /= 2; L *= cfg.upsample_rates[i]; m = std::max(m, (size_t)ch * stage_ld((int)L)); }
     return m;
   }
-  size_t workspace_bytes(int B, int T) const { return (4 * stage_floats(T) * B + (size_t)cfg.upsample_initial_channel * B) * sizeof(float); }
+  int n_bufs() const { return use_streams ? 3 + 2 * cfg.n_kernels : 4; }
+  size_t workspace_bytes(int B, int T) const { return ((size_t)n_bufs() * stage_floats(T) * B + (size_t)cfg.upsample_initial_channel * B) * sizeof(float); }
 
   int forward(hipStream_t st, const float* x, int x_ld, long long x_bs, const float* in_mask, long long in_mask_bs,
               const float* g, float* out, int B, int T) {
     const size_t sf = stage_floats(T);
     SVOC_TRY(ws.ensure(workspace_bytes(B, T)));
-    float* bufs[4];
-    for (int i = 0; i < 4; ++i) bufs[i] = ws.f() + (size_t)i * sf * B;
-    float* gbias = ws.f() + 4 * sf * B;
-    int r = 0;
+    const int nb = n_bufs();
+    std::vector<float*> bufs(nb);
+    for (int i = 0; i < nb; ++i) bufs[i] = ws.f() + (size_t)i * sf * B;
+    float* gbias = ws.f() + (size_t)nb * sf * B;
     int ch = cfg.upsample_initial_channel;
     int L = T;
     int ld = stage_ld(L);
+    // single-stream plan: 4 rotating buffers (R, X, XS, A; Bf reuses R).  multi-stream plan: P0/P1 ping-pong
+    // for the stage results, one X, and (A, Bf) per chain.
+    int r = use_streams ? 1 : 0;
     if (g) {
       if (!cond) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: g given but gin_channels == 0");
       ConvArgs a = mk_args();
       set_in(a, g, cfg.gin_channels, 1, 1);
       a.Ncols = 1;
       set_out(a.out[0], gbias, ch, 1, ch);
-      // gbias is [B][ch][1]
-      a.out[0].y_bs = ch; a.out[0].y_ld = 1;
       SVOC_TRY(launch_conv(*cond, a, B, st));
     }
     {   // conv_pre (+ cond(g)) (models.py:142-144)
@@ -381,11 +409,9 @@ struct Generator {
     }
     for (int i = 0; i < cfg.n_upsamples; ++i) {
       const int u = cfg.upsample_rates[i];
-      float* R = bufs[r];
-      float* X = bufs[(r + 1) & 3];
-      float* XS = bufs[(r + 2) & 3];
-      float* A = bufs[(r + 3) & 3];
-      float* Bf = R;   // dead once the upsampler has consumed it
+      float *R, *X, *XS;
+      if (use_streams) { R = bufs[r]; XS = bufs[r ^ 1]; X = bufs[2]; }
+      else { R = bufs[r]; X = bufs[(r + 1) & 3]; XS = bufs[(r + 2) & 3]; }
       const int Lo = L * u, ldo = stage_ld(Lo), cho = ch / 2;
       {   // lrelu(0.1) -> ConvTranspose1d as polyphase GEMM (models.py:147-148)
         ConvArgs a = mk_args();
@@ -398,13 +424,21 @@ struct Generator {
         SVOC_TRY(launch_conv(*ups[i], a, B, st));
       }
       const long long bs = (long long)cho * ldo;
+      if (use_streams) SVOC_HIP(hipEventRecord(ev_fork, st));
       for (int j = 0; j < cfg.n_kernels; ++j) {   // MRF: xs = sum_j ResBlock_j(x); x = xs / n (models.py:149-155)
         ResSink sink{XS, bs, ldo, 0u, 1.0f};
         if (j > 0) sink.flags |= F_ACC;
         if (j == cfg.n_kernels - 1) { sink.flags |= F_DIV; sink.div = (float)cfg.n_kernels; }
-        SVOC_TRY(rbs[i * cfg.n_kernels + j]->run(st, X, bs, ldo, nullptr, 0, A, Bf, bs, ldo, sink, B, Lo));
+        if (use_streams) {
+          SVOC_HIP(hipStreamWaitEvent(chain_st[j], ev_fork, 0));
+          SVOC_TRY(rbs[i * cfg.n_kernels + j]->run(chain_st[j], X, bs, ldo, nullptr, 0, bufs[3 + 2 * j], bufs[4 + 2 * j], bs, ldo, sink, B, Lo,
+                                                   j > 0 ? chain_done[j - 1] : nullptr, chain_done[j]));
+        } else {
+          SVOC_TRY(rbs[i * cfg.n_kernels + j]->run(st, X, bs, ldo, nullptr, 0, bufs[(r + 3) & 3], R, bs, ldo, sink, B, Lo));
+        }
       }
-      r = (r + 2) & 3;
+      if (use_streams) { SVOC_HIP(hipStreamWaitEvent(st, chain_done[cfg.n_kernels - 1], 0)); r ^= 1; }
+      else r = (r + 2) & 3;
       ch = cho; L = Lo; ld = ldo;
     }
     // lrelu(0.01) -> conv_post -> tanh (models.py:156-158)
@@ -635,6 +669,44 @@ int svoc_synth_infer(svoc_synth* h, void* stream, const float* mel, const int64_
 int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T) { return h ? h->m.workspace_bytes(B, T) : 0; }
 int svoc_synth_hop(svoc_synth* h) { return h ? h->m.dec.hop : 0; }
 void svoc_synth_destroy(svoc_synth* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+// ---- diagnostics: phase timing of one convolution launch (cycle stamps per workgroup)
+int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                           int B, int C, int L, int kernel_size, int dilation, double* out4) {
+  if (!x || !weight || !y || !out4) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_debug_conv_timing: bad arguments");
+  SVOC_GUARD_BEGIN
+  hipStream_t st = as_stream(stream);
+  PackedConv pc;
+  PackSpec sp{}; sp.Cin = C; sp.Cout = C; sp.K = kernel_size; sp.dil = dilation;
+  SVOC_TRY(pack_conv(pc, sp, weight, nullptr, bias, st));
+  const size_t maxblocks = 1 << 20;
+  DevBuf dbg;
+  SVOC_TRY(dbg.ensure(maxblocks * 4 * sizeof(long long)));
+  SVOC_HIP(hipMemsetAsync(dbg.p, 0, maxblocks * 4 * sizeof(long long), st));
+  ConvArgs a = mk_args();
+  set_in(a, x, (long long)C * L, L, L);
+  a.pre_slope = 0.1f;
+  a.Ncols = L;
+  a.dbg = (long long*)dbg.p;
+  set_out(a.out[0], y, (long long)C * L, L, C, residual ? (unsigned)F_RES : 0u);
+  if (residual) set_res(a.out[0], residual, (long long)C * L, L);
+  for (int it = 0; it < 2; ++it) SVOC_TRY(launch_conv(pc, a, B, st));
+  SVOC_HIP(hipStreamSynchronize(st));
+  std::vector<long long> h(maxblocks * 4);
+  SVOC_HIP(hipMemcpy(h.data(), dbg.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  double s0 = 0, s1 = 0, s2 = 0; long long n = 0, tmin = 0, tmax = 0;
+  for (size_t i = 0; i < maxblocks; ++i) {
+    const long long* d = &h[4 * i];
+    if (d[3] == 0) continue;
+    s0 += (double)(d[1] - d[0]); s1 += (double)(d[2] - d[1]); s2 += (double)(d[3] - d[2]);
+    if (n == 0 || d[0] < tmin) tmin = d[0];
+    if (n == 0 || d[3] > tmax) tmax = d[3];
+    ++n;
+  }
+  out4[0] = n ? s0 / n : 0; out4[1] = n ? s1 / n : 0; out4[2] = n ? s2 / n : 0; out4[3] = (double)(tmax - tmin);
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
 
 // ---- single ops
 int svoc_flip_channels(void* stream, const float* x, float* y, int B, int C, int T) {

@@ -79,7 +79,7 @@ struct ConvArgs {
   int ksg_total;                                     // groups of 4 k-steps per m-tile
   int xoff0; int row_len;                            // LDS tile: starts at n0+xoff0 (multiple of 4), row_len floats
   int Ncols;                                         // output columns
-  int stagger_cycles; int stagger_round; int stagger_slots;   // phase stagger of co-resident workgroups
+  long long* dbg;                                    // optional [nblocks][4] cycle stamps (diagnostics)
   // epilogue
   int mode;
   const float* mask; long long mask_bs;              // [B][>=Ncols] output-side mask
