@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
   const float slope = p.pre_slope;
   const bool act = slope != 1.0f;
   const float* bp0 = xs + hi * p.row_len + (wn * NR * 32 + l31 - p.pad - p.xoff0);
-  constexpr int SU = 9;
+  constexpr int SU = (MR * NR >= 8) ? 6 : 9;   // float4 staging loads in flight per thread
   const int stage_total = p.kcs * R4;
   const int wc0 = tid / R4, wg0 = tid - wc0 * R4;
   const int stage_dc = NT / R4, stage_dg = NT - stage_dc * R4;
@@ -239,6 +239,36 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
       const float odiv = sel ? p.out[1].div : p.out[0].div;
       const int onrows = sel ? p.out[1].nrows : p.out[0].nrows;
       const int rbase = sel ? trow0 - p.split_row : trow0;
+      const bool full_rows = rbase + 32 <= onrows;
+      const bool simple = full_rows && gaddb == nullptr && (fl & ~(unsigned)(F_RES | F_ACC | F_DIV)) == 0;
+      if (simple) {
+        // fast paths (decoder ResBlocks): every load of an accumulator tile is issued before its first use
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+          const int col = ncol0 + nr * 32 + l31;
+          if (col >= p.Ncols) continue;
+          float* ybase = oy + (long long)b * oy_bs + (long long)(rbase + 4 * hi) * oy_ld + col;
+          float rv[16], yo[16];
+          if (fl & F_RES) {
+            const float* rbase_p = ores + (long long)b * ores_bs + (long long)(rbase + 4 * hi) * ores_ld + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = rbase_p[(long long)((r & 3) + 8 * (r >> 2)) * ores_ld];
+          }
+          if (fl & F_ACC) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * oy_ld];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mr][nr][r];
+            if (fl & F_RES) v = v + rv[r];
+            if (fl & F_ACC) v = yo[r] + v;
+            if (fl & F_DIV) v = v / odiv;
+            ybase[(long long)((r & 3) + 8 * (r >> 2)) * oy_ld] = v;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr) {
         const int col = ncol0 + nr * 32 + l31;
@@ -334,7 +364,6 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
           const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
           const int chn = pi * 32 + rr;
           if (chn >= H) continue;
-          const int rowA = (mt0 + mr) * 32 + rr;
           float vA = acc[mr][nr][r];
           float vB = acc[mr + 1][nr][r];
           const long long yo = (long long)b * o.y_bs + (long long)chn * o.y_ld + col;
@@ -453,7 +482,7 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   a.row_len = round_up(BN + maxoff - a.xoff0, 4);
   {   // input channels staged per memory round trip: as many 32-channel chunks as fit the per-block LDS budget
     // ... and one batch of staging loads (9 float4 per thread x 256 threads)
-    static const int budget = getenv("SVOC_LDS_BUDGET") ? atoi(getenv("SVOC_LDS_BUDGET")) : 9 * 256 * 16;
+    const int budget = ((c.MR * c.NR >= 8) ? 6 : 9) * 256 * 16;
     const int per32 = KC * a.row_len * (int)sizeof(float);
     const int nfit = std::max(1, budget / per32);
     a.kcs = KC * std::min(a.nchunks, nfit);
