@@ -106,31 +106,50 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
       for (int base = tid; base < stage_total; base += NT * SU) {
         float4 v[SU];
         const int wc_s = wc, wg_s = wg;
+        if (p.vec4) {
+          // branch-free: clamp to a valid address and always issue the 16-byte load, so the SU loads go out
+          // back-to-back; the zero padding is applied below when the tile is written to LDS
 #pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int gc = c0 + wc;
-          const int t = xs_start + 4 * wg;
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (base + u * NT < stage_total && gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
-            const float* row = xb + (long long)gc * p.x_ld;
-            if (p.vec4 && t >= 0 && t + 3 < p.Lin) {
-              v[u] = *reinterpret_cast<const float4*>(row + t);
-            } else {
+          for (int u = 0; u < SU; ++u) {
+            const int gc = min(c0 + wc, p.Cin - 1);
+            int t = xs_start + 4 * wg;
+            t = (t >= 0 && t < p.Lin) ? t : 0;
+            v[u] = *reinterpret_cast<const float4*>(xb + (long long)gc * p.x_ld + t);
+            wc += stage_dc;
+            wg += stage_dg;
+            if (wg >= R4) { wg -= R4; ++wc; }
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int gc = c0 + wc;
+            const int t = xs_start + 4 * wg;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base + u * NT < stage_total && gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
+              const float* row = xb + (long long)gc * p.x_ld;
               if (t >= 0 && t < p.Lin) v[u].x = row[t];
               if (t + 1 >= 0 && t + 1 < p.Lin) v[u].y = row[t + 1];
               if (t + 2 >= 0 && t + 2 < p.Lin) v[u].z = row[t + 2];
               if (t + 3 >= 0 && t + 3 < p.Lin) v[u].w = row[t + 3];
             }
+            wc += stage_dc;
+            wg += stage_dg;
+            if (wg >= R4) { wg -= R4; ++wc; }
           }
-          wc += stage_dc;
-          wg += stage_dg;
-          if (wg >= R4) { wg -= R4; ++wc; }
         }
         int wc2 = wc_s, wg2 = wg_s;   // second pass of the same walk: activation, mask, LDS write
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           if (base + u * NT < stage_total) {
             float4 q = v[u];
+            {
+              const int t = xs_start + 4 * wg2;
+              const bool cok = c0 + wc2 < p.Cin;
+              q.x = (cok && t >= 0 && t < p.Lin) ? q.x : 0.f;
+              q.y = (cok && t + 1 >= 0 && t + 1 < p.Lin) ? q.y : 0.f;
+              q.z = (cok && t + 2 >= 0 && t + 2 < p.Lin) ? q.z : 0.f;
+              q.w = (cok && t + 3 >= 0 && t + 3 < p.Lin) ? q.w : 0.f;
+            }
             if (act) {
               q.x = q.x > 0.f ? q.x : q.x * slope;
               q.y = q.y > 0.f ? q.y : q.y * slope;
@@ -499,6 +518,14 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   }
   struct ProfEnd { hipStream_t st; int i; ~ProfEnd() { prof_end(st, i); } } prof_end_guard{st, prof_idx};
 
+  {   // experimental persistent wave-specialised kernel (conv_ws.hip), opt-in with SVOC_WS=1: at parity with the
+      // kernel below for k >= 7 and slower for small k
+    static const bool use_ws = getenv("SVOC_WS") && atoi(getenv("SVOC_WS")) != 0;
+    if (use_ws) {
+      const int r = launch_conv_ws(a, B, c.WM, c.WN, c.MR, c.NR, st);
+      if (r <= 0) return r;
+    }
+  }
 #define SVOC_LAUNCH(C) if (c.WM == C.WM && c.WN == C.WN && c.MR == C.MR && c.NR == C.NR) return launch_cfg<C.WM, C.WN, C.MR, C.NR>(a, B, st)
   SVOC_LAUNCH(CFG_A);
   SVOC_LAUNCH(CFG_B);

@@ -1,0 +1,550 @@
+// Persistent, wave-specialised variant of the implicit-GEMM convolution (same math, packing and
+// epilogues as conv_mfma.hip).
+//
+// Why: with identical workgroups the chip runs read -> MFMA -> write bulk-synchronously, and a
+// wave that both streams activations and consumes weight fragments serialises them on its single in-order
+// vmcnt queue.  Here one 8-wave workgroup per CU walks a list of output tiles and splits the roles:
+//   waves 0-3  consumers : LDS fragments -> v_mfma_f32_32x32x2_f32 -> fused epilogue stores (fire and forget);
+//                          bias lives in registers, the residual of the ResBlock fast path is prefetched during
+//                          the last channel chunk; no other vector-memory loads, so nothing queues behind stores
+//   waves 4-5  weight producers    : per (chunk, tap) sub-stage copy BM x 32 packed weights L2 -> LDS
+//   waves 6-7  activation producers: per 32-channel chunk copy the [32][BN+halo] tile HBM -> LDS
+//                                    (leaky-relu / mask / zero padding applied on the way), requested one chunk ahead
+// One s_barrier per sub-stage hands double-buffered LDS tiles from producers to consumers.
+#include "svoc_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace svoc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int WS_HALO_MAX = 56;
+constexpr unsigned F_VECST_WS = 1u << 16;
+
+__device__ __forceinline__ float ws_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float ws_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Workgroup barriers without the memory fence of __syncthreads(): a fence would make the consumers wait for their
+// global stores (and the producers for their in-flight global loads) at every hand-off.  LDS data is published by
+// waiting for the writer's own ds_writes (lgkmcnt) before the barrier.
+__device__ __forceinline__ void ws_publish_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ void ws_consume_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS reads have returned (they feed the MFMAs anyway)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Epilogue of one finished tile (bias is already inside acc).  res_pre: residual values prefetched by the caller
+// (valid only when use_pre).
+template <int MR, int NR>
+__device__ __forceinline__ void ws_epilogue(const ConvArgs& p, f32x16 (&acc)[MR][NR], int b, int mt0, int ncol0, int lane,
+                                            const float (&res_pre)[MR][NR][16], bool use_pre) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  const float* maskb = p.mask ? p.mask + (long long)b * p.mask_bs : nullptr;
+  const float* gaddb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
+
+  if (p.mode == EPI_PLAIN) {
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      if (mt0 + mr >= p.mtiles) break;
+      const int trow0 = (mt0 + mr) * 32;
+      const bool sel = trow0 >= p.split_row;
+      float* const oy = sel ? p.out[1].y : p.out[0].y;
+      if (oy == nullptr) continue;
+      const long long oy_bs = sel ? p.out[1].y_bs : p.out[0].y_bs;
+      const int oy_ld = sel ? p.out[1].y_ld : p.out[0].y_ld;
+      const float* const ores = sel ? p.out[1].res : p.out[0].res;
+      const long long ores_bs = sel ? p.out[1].res_bs : p.out[0].res_bs;
+      const int ores_ld = sel ? p.out[1].res_ld : p.out[0].res_ld;
+      const unsigned fl = sel ? p.out[1].flags : p.out[0].flags;
+      const float odiv = sel ? p.out[1].div : p.out[0].div;
+      const int onrows = sel ? p.out[1].nrows : p.out[0].nrows;
+      const int rbase = sel ? trow0 - p.split_row : trow0;
+      const bool full_rows = rbase + 32 <= onrows;
+      const bool simple = full_rows && gaddb == nullptr && (fl & ~(unsigned)(F_RES | F_ACC | F_DIV)) == 0;
+      if (simple) {
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+          const int col = ncol0 + nr * 32 + l31;
+          if (col >= p.Ncols) continue;
+          float* ybase = oy + (long long)b * oy_bs + (long long)(rbase + 4 * hi) * oy_ld + col;
+          float rv[16], yo[16];
+          if (fl & F_RES) {
+            if (use_pre) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) rv[r] = res_pre[mr][nr][r];
+            } else {
+              const float* rp = ores + (long long)b * ores_bs + (long long)(rbase + 4 * hi) * ores_ld + col;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) rv[r] = rp[(long long)((r & 3) + 8 * (r >> 2)) * ores_ld];
+            }
+          }
+          if (fl & F_ACC) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * oy_ld];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mr][nr][r];
+            if (fl & F_RES) v = v + rv[r];
+            if (fl & F_ACC) v = yo[r] + v;
+            if (fl & F_DIV) v = v / odiv;
+            ybase[(long long)((r & 3) + 8 * (r >> 2)) * oy_ld] = v;
+          }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) {
+        const int col = ncol0 + nr * 32 + l31;
+        if (col >= p.Ncols) continue;
+        const float mk = maskb ? maskb[col] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int rr = rbase + lr;
+          if (rr >= onrows) continue;
+          float v = acc[mr][nr][r];
+          if (gaddb) v += gaddb[(long long)rr * p.gadd_ld + (long long)col * p.gadd_ts];
+          float* yp = oy + (long long)b * oy_bs + (long long)rr * oy_ld + col;
+          if (fl & (F_RES | F_CPL_REV | F_CPL_FWD)) {
+            const float rv = ores[(long long)b * ores_bs + (long long)rr * ores_ld + col];
+            if (fl & F_RES) v = v + rv;
+            else if (fl & F_CPL_REV) v = (rv - v * mk) * mk;
+            else v = v * mk + rv * mk;
+          }
+          if (fl & F_ACC) v = *yp + v;
+          if (fl & F_DIV) v = v / odiv;
+          if (fl & F_OUTMASK) v *= mk;
+          *yp = v;
+        }
+      }
+    }
+  } else if (p.mode == EPI_UPS) {
+    const EpiOut& o = p.out[0];
+    const int s = p.ups_s;
+    float* yb = o.y + (long long)b * o.y_bs;
+    const bool vec = (o.flags & F_VECST_WS) != 0;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      if (mt0 + mr >= p.mtiles) break;
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) {
+        const int col = ncol0 + nr * 32 + l31;
+        if (col >= p.Ncols) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row0 = (mt0 + mr) * 32 + 8 * q + 4 * hi;
+          if (vec && row0 + 3 < o.nrows) {
+            const int oc = row0 >> 3;
+            const int n = col * 8 + (row0 & 7) - p.ups_pad;
+            float4 v = make_float4(acc[mr][nr][4 * q], acc[mr][nr][4 * q + 1], acc[mr][nr][4 * q + 2], acc[mr][nr][4 * q + 3]);
+            float* yp = yb + (long long)oc * o.y_ld + n;
+            if (n >= 0 && n + 3 < p.Lout) {
+              *reinterpret_cast<float4*>(yp) = v;
+            } else {
+              if (n >= 0 && n < p.Lout) yp[0] = v.x;
+              if (n + 1 >= 0 && n + 1 < p.Lout) yp[1] = v.y;
+              if (n + 2 >= 0 && n + 2 < p.Lout) yp[2] = v.z;
+              if (n + 3 >= 0 && n + 3 < p.Lout) yp[3] = v.w;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = row0 + i;
+              const int oc = row / s;
+              const int n = col * s + (row - oc * s) - p.ups_pad;
+              if (row < o.nrows && n >= 0 && n < p.Lout) yb[(long long)oc * o.y_ld + n] = acc[mr][nr][4 * q + i];
+            }
+          }
+        }
+      }
+    }
+  } else {
+    if constexpr (MR % 2 == 0) {
+      const int H = p.half_rows;
+      const EpiOut& o = p.out[0];
+      float lsum = 0.0f;
+#pragma unroll
+      for (int mr = 0; mr < MR; mr += 2) {
+        if (mt0 + mr >= p.mtiles) break;
+        const int pi = (mt0 + mr) >> 1;
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+          const int col = ncol0 + nr * 32 + l31;
+          if (col >= p.Ncols) continue;
+          const float mk = maskb ? maskb[col] : 1.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int chn = pi * 32 + rr;
+            if (chn >= H) continue;
+            float vA = acc[mr][nr][r];
+            float vB = acc[mr + 1][nr][r];
+            const long long yo = (long long)b * o.y_bs + (long long)chn * o.y_ld + col;
+            if (p.mode == EPI_GATE) {
+              if (gaddb) {
+                vA += gaddb[(long long)chn * p.gadd_ld + (long long)col * p.gadd_ts];
+                vB += gaddb[(long long)(H + chn) * p.gadd_ld + (long long)col * p.gadd_ts];
+              }
+              o.y[yo] = tanhf(vA) * ws_sigmoid(vB);
+            } else if (p.mode == EPI_PROJ) {
+              const float m = vA * mk, lg = vB * mk;
+              const float e = p.eps ? p.eps[(long long)b * p.eps_bs + (long long)chn * p.eps_ld + col] : 0.0f;
+              if (o.y) o.y[yo] = m;
+              if (p.y2) p.y2[yo] = lg;
+              if (p.y3) p.y3[yo] = m + e * expf(lg) * p.noise_scale;
+            } else {
+              const float m = vA * mk, lg = vB * mk;
+              const float x1 = o.res[(long long)b * o.res_bs + (long long)chn * o.res_ld + col];
+              if (p.mode == EPI_CPL_FULL_REV) {
+                o.y[yo] = (x1 - m) * expf(-lg) * mk;
+              } else {
+                o.y[yo] = m + x1 * expf(lg) * mk;
+                lsum += lg;
+              }
+            }
+          }
+        }
+      }
+      if (p.mode == EPI_CPL_FULL_FWD && p.logdet) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+        if (lane == 0) atomicAdd(p.logdet + b, lsum);
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int MR, int NR>
+__global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p) {
+  static_assert(WM * WN == 4, "four consumer waves");
+  constexpr int BN = WN * NR * 32;
+  constexpr int RING = 4;                                         // activation tiles in LDS (3 chunks of lookahead)
+  constexpr int XREG = (KC * ((BN + WS_HALO_MAX) / 4) + 63) / 64;  // float4 per producer lane for one whole chunk
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int total_tiles = p.ntn * p.B;
+  if ((int)blockIdx.x >= total_tiles) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xbuf_floats = KC * p.row_len;
+  float* const XS = lds;                                         // [RING][KC][row_len]
+  const int mblk = blockIdx.y;
+  const int ntl = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
+  const int total_cc = ntl * p.nchunks;                          // chunks this workgroup walks through
+
+  if (wave >= 4) {
+    // ======================================================================= activation producers
+    // Wave 4+w owns the chunks cc == w (mod 4): it requests chunk cc at the start of chunk cc-3 (as soon as ring
+    // slot cc%4 has been released), keeps it in registers across two barriers and publishes it during chunk cc-1.
+    const int pw = wave - 4;
+    const int R4 = p.row_len >> 2;
+    const int xtotal = KC * R4;
+    const int wc0 = lane / R4, wg0 = lane - wc0 * R4;
+    const int xdc = 64 / R4, xdg = 64 - xdc * R4;
+    const float slope = p.pre_slope;
+    const bool act = slope != 1.0f;
+
+    auto chunk_coords = [&](int cc, int& b, int& n0, int& ch) {
+      const int ti = cc / p.nchunks;
+      ch = cc - ti * p.nchunks;
+      const int tile = blockIdx.x + ti * gridDim.x;
+      b = tile / p.ntn;
+      n0 = (tile - b * p.ntn) * BN;
+    };
+    // Branch-free request: clamp (channel, time) to a valid address and always issue the 16-byte load, so the XREG
+    // loads of a chunk go out back-to-back; the zero padding is applied when the tile is written to LDS.
+    auto x_issue = [&](int b, int n0, int ch, float4(&xv)[XREG]) {
+      const float* xb = p.x + (long long)b * p.x_bs;
+      const int xs_start = n0 + p.xoff0;
+      const int c0 = ch * KC;
+      int wc = wc0, wg = wg0;
+      if (p.vec4) {
+#pragma unroll
+        for (int u = 0; u < XREG; ++u) {
+          const int gc = min(c0 + wc, p.Cin - 1);
+          int t = xs_start + 4 * wg;
+          t = (t >= 0 && t < p.Lin) ? t : 0;
+          xv[u] = *reinterpret_cast<const float4*>(xb + (long long)gc * p.x_ld + t);
+          wc += xdc; wg += xdg;
+          if (wg >= R4) { wg -= R4; ++wc; }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < XREG; ++u) {
+          const int gc = c0 + wc;
+          const int t = xs_start + 4 * wg;
+          xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (lane + u * 64 < xtotal && gc < p.Cin && t + 3 >= 0 && t < p.Lin) {
+            const float* row = xb + (long long)gc * p.x_ld;
+            if (t >= 0 && t < p.Lin) xv[u].x = row[t];
+            if (t + 1 >= 0 && t + 1 < p.Lin) xv[u].y = row[t + 1];
+            if (t + 2 >= 0 && t + 2 < p.Lin) xv[u].z = row[t + 2];
+            if (t + 3 >= 0 && t + 3 < p.Lin) xv[u].w = row[t + 3];
+          }
+          wc += xdc; wg += xdg;
+          if (wg >= R4) { wg -= R4; ++wc; }
+        }
+      }
+    };
+    auto x_write = [&](float* buf, int b, int n0, int ch, const float4(&xv)[XREG]) {
+      const float* mb = p.in_mask ? p.in_mask + (long long)b * p.in_mask_bs : nullptr;
+      const int xs_start = n0 + p.xoff0;
+      const int c0 = ch * KC;
+      int wc = wc0, wg = wg0;
+#pragma unroll
+      for (int u = 0; u < XREG; ++u) {
+        if (lane + u * 64 < xtotal) {
+          const int t = xs_start + 4 * wg;
+          const bool cok = c0 + wc < p.Cin;
+          float4 q = xv[u];
+          q.x = (cok && t >= 0 && t < p.Lin) ? q.x : 0.f;
+          q.y = (cok && t + 1 >= 0 && t + 1 < p.Lin) ? q.y : 0.f;
+          q.z = (cok && t + 2 >= 0 && t + 2 < p.Lin) ? q.z : 0.f;
+          q.w = (cok && t + 3 >= 0 && t + 3 < p.Lin) ? q.w : 0.f;
+          if (act) {
+            q.x = q.x > 0.f ? q.x : q.x * slope;
+            q.y = q.y > 0.f ? q.y : q.y * slope;
+            q.z = q.z > 0.f ? q.z : q.z * slope;
+            q.w = q.w > 0.f ? q.w : q.w * slope;
+          }
+          if (mb) {
+            q.x *= (t >= 0 && t < p.Lin) ? mb[t] : 0.f;
+            q.y *= (t + 1 >= 0 && t + 1 < p.Lin) ? mb[t + 1] : 0.f;
+            q.z *= (t + 2 >= 0 && t + 2 < p.Lin) ? mb[t + 2] : 0.f;
+            q.w *= (t + 3 >= 0 && t + 3 < p.Lin) ? mb[t + 3] : 0.f;
+          }
+          *reinterpret_cast<float4*>(buf + wc * p.row_len + 4 * wg) = q;
+        }
+        wc += xdc; wg += xdg;
+        if (wg >= R4) { wg -= R4; ++wc; }
+      }
+    };
+
+    float4 xv[XREG];
+    // prologue: every producer wave loads and publishes its first chunk (cc = pw), chunks 0..3 fill the ring
+    int mine = pw;                       // the chunk currently held / next to publish by this wave
+    if (mine < total_cc) {
+      int b, n0, ch;
+      chunk_coords(mine, b, n0, ch);
+      x_issue(b, n0, ch, xv);
+      x_write(XS + (mine % RING) * xbuf_floats, b, n0, ch, xv);
+    }
+    mine += 4;
+    bool holding = false;
+    long long t_iss = 0, t_pub = 0, t_pbar = 0;
+    ws_publish_barrier();
+    for (int cc = 0; cc < total_cc; ++cc) {
+      // during chunk cc the consumers read slot cc%4; slots of chunks cc+1..cc+3 are free to fill
+      if (mine < total_cc) {
+        int b, n0, ch;
+        if (!holding && mine - 3 <= cc) {          // slot (mine%4) was released by the barrier that ended chunk mine-4
+          const long long ta = __builtin_readcyclecounter();
+          chunk_coords(mine, b, n0, ch);
+          x_issue(b, n0, ch, xv);
+          holding = true;
+          t_iss += __builtin_readcyclecounter() - ta;
+        }
+        if (holding && mine - 1 <= cc) {           // publish one chunk before it is consumed
+          chunk_coords(mine, b, n0, ch);
+          const long long tb = __builtin_readcyclecounter();
+          x_write(XS + (mine % RING) * xbuf_floats, b, n0, ch, xv);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          t_pub += __builtin_readcyclecounter() - tb;
+          holding = false;
+          mine += 4;
+        }
+      }
+      const long long tc = __builtin_readcyclecounter();
+      ws_publish_barrier();
+      t_pbar += __builtin_readcyclecounter() - tc;
+    }
+    if (p.dbg && tid == 256) {
+      long long* d = p.dbg + 4 * (blockIdx.x + (long long)gridDim.x * blockIdx.y) + 4 * (long long)gridDim.x * gridDim.y;
+      d[0] = 0; d[1] = t_iss; d[2] = t_iss + t_pub; d[3] = t_iss + t_pub + t_pbar;
+    }
+    return;
+  }
+
+  // ========================================================================= consumers
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int mt0 = (mblk * WM + wm) * MR;
+  const bool m_ok = mt0 < p.mtiles;
+  const int bcol = wn * NR * 32 + l31 - p.pad - p.xoff0;
+
+  float biasr[MR][16];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) biasr[mr][i] = p.bias[min(mt0 + mr, p.mtiles - 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mr][nr][i] = biasr[mr][i];
+
+  // weight fragment stream straight from L2 (packed order), one group ahead; wraps to group 0 at the tile end
+  const float4* wp4 = reinterpret_cast<const float4*>(p.wp);
+  long long abase[MR];
+  float4 a0[MR], a1[MR];                 // ping-pong weight fragments (a0 = group to run next)
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    abase[mr] = (long long)min(mt0 + mr, p.mtiles - 1) * p.ksg_total * 64 + lane;
+    a0[mr] = wp4[abase[mr]];
+  }
+  float res_pre[MR][NR][16];
+  const int ngroups = p.ktaps * (KC / 8);
+
+  ws_consume_barrier();   // prologue barrier (matches the producers')
+
+  int tile = blockIdx.x;
+  int cc = 0;
+  long long t_bar = 0, t_mma = 0, t_epi = 0;
+  const long long t_begin = __builtin_readcyclecounter();
+  while (true) {
+    const int b = tile / p.ntn;
+    const int n0 = (tile - b * p.ntn) * BN;
+    const int ncol0 = n0 + wn * NR * 32;
+    const bool wave_active = m_ok && ncol0 < p.Ncols;
+    int ksg = 0;
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+      const long long t0 = __builtin_readcyclecounter();
+      if (wave_active) {
+        const float* xs = XS + (cc % RING) * xbuf_floats;
+        const float* bp = xs + hi * p.row_len + bcol;
+        float b0[4][NR], b1[4][NR];             // ping-pong activation fragments
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr) b0[s][nr] = bp[(2 * s) * p.row_len + nr * 32];
+        int g = 0;
+        // One group = 4 k-steps = 4*MR*NR MFMAs.  The next group's fragment requests are issued after the first
+        // k-step's MFMAs so that they overlap MFMA execution (a lone wave per SIMD has nothing else to fill the
+        // pipe); two register sets alternate, so no moves.  ngroups is a multiple of 4.
+        auto run_group = [&](float4(&ac)[MR], float(&bc)[4][NR], float4(&an)[MR], float(&bn)[4][NR], bool last_group) {
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) {
+            const float av = ac[mr].x;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[0][nr], acc[mr][nr], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          ++ksg;
+          const int kn = ksg < p.ksg_total ? ksg : 0;      // wraps to group 0 = first group of the next tile
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) an[mr] = wp4[abase[mr] + (long long)kn * 64];
+          const float* bpn = (g == KC / 8 - 1) ? bp + p.dil - (KC - 8) * p.row_len : bp + 8 * p.row_len;
+          if (!last_group) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bpn[(2 * s) * p.row_len + nr * 32];
+          }
+          bp = bpn;
+          g = (g + 1) & (KC / 8 - 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 1; s < 4; ++s) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+              const float av = ws_pick4(ac[mr], s);
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[mr][nr], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int gi = 0; gi < ngroups; gi += 2) {
+          run_group(a0, b0, a1, b1, false);
+          run_group(a1, b1, a0, b0, gi + 2 >= ngroups);
+        }
+      }
+      const long long t1 = __builtin_readcyclecounter();
+      ws_consume_barrier();
+      const long long t2 = __builtin_readcyclecounter();
+      t_mma += t1 - t0; t_bar += t2 - t1;
+      ++cc;
+    }
+    const long long t3 = __builtin_readcyclecounter();
+    if (wave_active) {
+      int opq = 0;
+      asm volatile("" : "+s"(opq));      // keep tile-invariant epilogue address math out of the persistent loop
+      ws_epilogue<MR, NR>(p, acc, b, mt0 + opq, ncol0, lane, res_pre, false);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mr][nr][i] = biasr[mr][i];
+    }
+    t_epi += __builtin_readcyclecounter() - t3;
+    tile += gridDim.x;
+    if (tile >= total_tiles) break;
+  }
+  if (p.dbg && tid == 0) {
+    long long* d = p.dbg + 4 * (blockIdx.x + (long long)gridDim.x * blockIdx.y);
+    d[0] = 0; d[1] = t_bar; d[2] = t_bar + t_mma; d[3] = t_bar + t_mma + t_epi;   // decoded as (barrier wait, MFMA, epilogue)
+    (void)t_begin;
+  }
+}
+
+namespace {
+int ws_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int WM, int WN, int MR, int NR>
+int launch_ws_cfg(ConvArgs& a, int B, hipStream_t st) {
+  constexpr int BN = WN * NR * 32;
+  constexpr int MTB = WM * MR;
+  auto kern = conv_ws_kernel<WM, WN, MR, NR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const size_t lds = 4 * (size_t)KC * a.row_len * sizeof(float);
+  if (a.row_len > BN + WS_HALO_MAX || lds > 160 * 1024) return 1;   // caller falls back to the non-persistent kernel
+  a.ntn = (a.Ncols + BN - 1) / BN;
+  a.B = B;
+  const int gy = (a.mtiles + MTB - 1) / MTB;
+  const long long total = (long long)a.ntn * B;
+  const long long slots = std::max<long long>(1, ws_num_cus() / gy);
+  const long long tpb = (total + slots - 1) / slots;
+  const int gx = (int)((total + tpb - 1) / tpb);
+  hipLaunchKernelGGL(kern, dim3(gx, gy, 1), dim3(512), lds, st, a);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+}  // namespace
+
+// returns SVOC_OK, a negative error, or 1 when this launch is not eligible
+int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st) {
+#define SVOC_WS(wm, wn, mr, nr) if (WM == wm && WN == wn && MR == mr && NR == nr) return launch_ws_cfg<wm, wn, mr, nr>(a, B, st)
+  SVOC_WS(2, 2, 2, 2);
+  SVOC_WS(2, 2, 2, 1);
+  SVOC_WS(2, 2, 1, 1);
+  SVOC_WS(1, 4, 1, 1);
+#undef SVOC_WS
+  return 1;
+}
+
+}  // namespace svoc

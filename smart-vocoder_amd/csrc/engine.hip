@@ -695,6 +695,15 @@ int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, co
   std::vector<long long> h(maxblocks * 4);
   SVOC_HIP(hipMemcpy(h.data(), dbg.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
   double s0 = 0, s1 = 0, s2 = 0; long long n = 0, tmin = 0, tmax = 0;
+  if (getenv("SVOC_DBG_DUMP")) {   // first 3 records of each half (consumer wave 0, producer wave 4 of the persistent kernel)
+    long long nrec = 0;
+    for (size_t i = 0; i < maxblocks; ++i) if (h[4 * i + 3] != 0) ++nrec;
+    for (size_t i = 0, shown = 0; i < maxblocks && shown < 6; ++i) {
+      const long long* d = &h[4 * i];
+      if (d[3] == 0) continue;
+      if (shown < 3 || i >= (size_t)nrec / 2) { fprintf(stderr, "dbg[%zu] %lld %lld %lld\n", i, d[1] - d[0], d[2] - d[1], d[3] - d[2]); ++shown; }
+    }
+  }
   for (size_t i = 0; i < maxblocks; ++i) {
     const long long* d = &h[4 * i];
     if (d[3] == 0) continue;

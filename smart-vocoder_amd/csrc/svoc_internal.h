@@ -79,6 +79,7 @@ struct ConvArgs {
   int ksg_total;                                     // groups of 4 k-steps per m-tile
   int xoff0; int row_len;                            // LDS tile: starts at n0+xoff0 (multiple of 4), row_len floats
   int Ncols;                                         // output columns
+  int ntn; int B;                                    // persistent kernel: time tiles per batch element, batch size
   long long* dbg;                                    // optional [nblocks][4] cycle stamps (diagnostics)
   // epilogue
   int mode;
@@ -123,6 +124,8 @@ int fold_weight_norm(hipStream_t st, const float* v, const float* g, float* w, l
 
 // Fills geometry fields (wp, bias, taps, tiles, LDS tile) of `a` from `pc`; caller sets x/epilogue fields first.
 int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st);
+
+int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);   // conv_ws.hip; 1 = not eligible
 
 // ------------------------------------------------------------------ small kernels (misc_kernels.hip)
 int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, int T);
