@@ -147,15 +147,34 @@ struct ResBlock {
     const float* cur = x; long long cur_bs = x_bs; int cur_ld = x_ld;
     for (int i = 0; i < ND; ++i) {
       const bool last = i == ND - 1;
+      if (kind == 1 && mask == nullptr) {
+        // fused iteration (resblock_fused.hip): reads `cur` with halos, so it must not write in place -> ping-pong Bf/A
+        float* dst = last ? sink.y : ((i & 1) ? A : Bf);
+        const long long dbs = last ? sink.bs : bs;
+        const int dld = last ? sink.ld : ld;
+        if (last && wait_before_last) SVOC_HIP(hipStreamWaitEvent(st, wait_before_last, 0));
+        const int r = launch_resblock_fused(*c1[i], *c2[i], cur, cur_bs, cur_ld, dst, dbs, dld, last ? sink.flags : 0u,
+                                            last ? sink.div : 1.0f, B, L, st);
+        if (r < 0) return r;
+        if (r == 0) {
+          if (last && record_after_last) SVOC_HIP(hipEventRecord(record_after_last, st));
+          cur = dst; cur_bs = dbs; cur_ld = dld;
+          continue;
+        }
+      }
       const float* cin = cur; long long cin_bs = cur_bs; int cin_ld = cur_ld;
+      // unfused: c1 -> scratch, c2 (+ residual) -> next.  The scratch must differ from `cur` (which may be A or Bf
+      // after fused iterations).
+      float* scratch = (cur == A) ? Bf : A;
+      float* nxt = (cur == A || cur == Bf) ? const_cast<float*>(cur) : Bf;   // in place is safe here (elementwise residual)
       if (kind == 1) {
         ConvArgs a = mk_args();
         set_in(a, cur, cur_bs, cur_ld, L);
         a.pre_slope = 0.1f; a.in_mask = mask; a.in_mask_bs = mask_bs;
         a.Ncols = L;
-        set_out(a.out[0], A, bs, ld, C);
+        set_out(a.out[0], scratch, bs, ld, C);
         SVOC_TRY(launch_conv(*c1[i], a, B, st));
-        cin = A; cin_bs = bs; cin_ld = ld;
+        cin = scratch; cin_bs = bs; cin_ld = ld;
       }
       ConvArgs a = mk_args();
       set_in(a, cin, cin_bs, cin_ld, L);
@@ -163,7 +182,7 @@ struct ResBlock {
       a.Ncols = L;
       a.mask = mask; a.mask_bs = mask_bs;
       if (!last) {
-        set_out(a.out[0], Bf, bs, ld, C, F_RES);
+        set_out(a.out[0], nxt, bs, ld, C, F_RES);
       } else {
         set_out(a.out[0], sink.y, sink.bs, sink.ld, C, F_RES | sink.flags | (mask ? (unsigned)F_OUTMASK : 0u));
         a.out[0].div = sink.div;
@@ -172,7 +191,7 @@ struct ResBlock {
       if (last && wait_before_last) SVOC_HIP(hipStreamWaitEvent(st, wait_before_last, 0));
       SVOC_TRY(launch_conv(kind == 1 ? *c2[i] : *c1[i], a, B, st));
       if (last && record_after_last) SVOC_HIP(hipEventRecord(record_after_last, st));
-      cur = Bf; cur_bs = bs; cur_ld = ld;
+      cur = nxt; cur_bs = bs; cur_ld = ld;
     }
     return SVOC_OK;
   }

@@ -1,0 +1,265 @@
+// One ResBlock1 iteration in one kernel (reference modules.py:211-218):
+//     y = c2( lrelu( c1( lrelu(x) ) ) ) + x          c1: k taps, dilation d;  c2: k taps, dilation 1
+// for the narrow decoder stages (C = 32, 64), where conv-by-conv execution is bound by HBM traffic (each conv
+// writes its full 268 MB output; the write path tops out at ~2.7 TB/s, profiles/r01_membw_probe.txt).  Here the
+// intermediate activation never leaves the CU: the raw x tile (all C channels, time tile + both halos) is staged
+// into LDS once, phase A computes c1 on N_A = WN*NR*32 columns and writes lrelu(.) (zeroed outside [0,L): c2's own
+// zero padding) into a second LDS tile, phase B runs c2 on it for the N2 = N_A-(k-1) interior columns, and the
+// residual is read back from the staged raw tile.  HBM traffic per iteration: read x once + write y once
+// (was: 2 writes + 3 reads).  Same MFMA instruction, packed-weight streams and numerics as conv_mfma.hip.
+#include "svoc_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace svoc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FusedArgs {
+  const float* x; long long x_bs; int x_ld; int L;
+  const float* wp1; const float* bias1; int ksg1; int dil1; int pad1;
+  const float* wp2; const float* bias2; int ksg2; int pad2;
+  int ktaps; int nchunks; int C;
+  float* y; long long y_bs; int y_ld; unsigned flags; float div;
+  int n2; int xoff0; int xrow; int yrow;
+  float slope;
+};
+
+__device__ __forceinline__ float fz_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+
+// acc[nr] += W[rows of m-tile mt][K] * B, B fragments read from an LDS tile `tile` ([channels][row_len]) at column
+// offset col0 + tap*dil; ACT applies leaky-relu to the fragments as they are read.
+template <int NR, bool ACT>
+__device__ __forceinline__ void fused_gemm(f32x16 (&acc)[NR], const float4* __restrict__ wp4, long long abase, int ksg_total,
+                                           const float* tile, int row_len, int col0, int ktaps, int dil, int nchunks,
+                                           int hi, float slope) {
+  // a group here is only 4*NR MFMAs (512 cycles at NR=2), shorter than an L2 round trip: weights run two groups ahead
+  float4 a_cur, a_nxt = wp4[abase], a_nx2 = wp4[abase + (ksg_total > 1 ? 64 : 0)];
+  int ksg = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* bp = tile + (ch * KC + hi) * row_len + col0;
+    float b_cur[4][NR], b_nxt[4][NR];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bp[(2 * s) * row_len + nr * 32];
+    const int ngroups = ktaps * (KC / 8);
+    int g = 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      a_cur = a_nxt;
+      a_nxt = a_nx2;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+          const float v = b_nxt[s][nr];
+          b_cur[s][nr] = ACT ? fmaxf(v, v * slope) : v;       // lrelu for slope in (0,1)
+        }
+      ++ksg;
+      {
+        int kn = ksg + 1;
+        if (kn >= ksg_total) kn = ksg_total - 1;
+        a_nx2 = wp4[abase + (long long)kn * 64];
+      }
+      const float* bpn = (g == KC / 8 - 1) ? bp + dil - (KC - 8) * row_len : bp + 8 * row_len;
+      if (gi + 1 < ngroups) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bpn[(2 * s) * row_len + nr * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = fz_pick4(a_cur, s);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[s][nr], acc[nr], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bp = bpn;
+      g = (g + 1) & (KC / 8 - 1);
+    }
+  }
+}
+
+template <int WM, int WN, int NR>
+__global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs p) {
+  constexpr int SU = 13;                                   // one batch of staging loads per thread
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const XT = lds;                                   // raw x tile  [C][xrow]
+  float* const YT = lds;                                   // lrelu(c1(.)) tile [C][yrow], ALIASES the x tile (see below)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * p.n2;                        // first output sample of this tile
+  const int h2 = p.pad2;
+
+  // ---- stage the raw x tile: all C channels, columns [t0 + xoff0, +xrow); zero outside [0, L)
+  {
+    const int R4 = p.xrow >> 2;
+    const int total = p.C * R4;
+    const int xs_start = t0 + p.xoff0;
+    const float* xb = p.x + (long long)b * p.x_bs;
+    int wc = tid / R4, wg = tid - wc * R4;
+    const int dc = 256 / R4, dg = 256 - dc * R4;
+    for (int base = tid; base < total; base += 256 * SU) {
+      float4 v[SU];
+      const int wc_s = wc, wg_s = wg;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int c = min(wc, p.C - 1);
+        int t = xs_start + 4 * wg;
+        t = (t >= 0 && t < p.L) ? t : 0;
+        v[u] = *reinterpret_cast<const float4*>(xb + (long long)c * p.x_ld + t);
+        wc += dc; wg += dg;
+        if (wg >= R4) { wg -= R4; ++wc; }
+      }
+      int wc2 = wc_s, wg2 = wg_s;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (base + u * 256 < total) {
+          const int t = xs_start + 4 * wg2;
+          float4 q = v[u];
+          q.x = (t >= 0 && t < p.L) ? q.x : 0.f;
+          q.y = (t + 1 >= 0 && t + 1 < p.L) ? q.y : 0.f;
+          q.z = (t + 2 >= 0 && t + 2 < p.L) ? q.z : 0.f;
+          q.w = (t + 3 >= 0 && t + 3 < p.L) ? q.w : 0.f;
+          *reinterpret_cast<float4*>(XT + wc2 * p.xrow + 4 * wg2) = q;
+        }
+        wc2 += dc; wg2 += dg;
+        if (wg2 >= R4) { wg2 -= R4; ++wc2; }
+      }
+    }
+  }
+  const int mt = wm;                                       // this wave's 32-row tile (WM tiles cover C)
+  f32x16 acc[NR];
+  // ---- phase A: c1 on columns m in [0, NA) <-> global time t0 - h2 + m
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias1[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+  __syncthreads();
+  {
+    const int col0 = wn * NR * 32 + l31 - h2 - p.pad1 - p.xoff0;
+    fused_gemm<NR, true>(acc, reinterpret_cast<const float4*>(p.wp1), (long long)mt * p.ksg1 * 64 + lane, p.ksg1, XT, p.xrow, col0,
+                         p.ktaps, p.dil1, p.nchunks, hi, p.slope);
+  }
+  // The x tile is now only needed for the residual: every wave pulls its own residual values into registers, then
+  // (after a barrier) the same LDS region is overwritten with lrelu(c1(.)) as c2's B operand.  Halving the LDS
+  // footprint doubles the number of resident workgroups.
+  const int ncol0 = wn * NR * 32;
+  float resv[NR][16];
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int n = ncol0 + nr * 32 + l31;
+    const int cidx = min(n - p.xoff0, p.xrow - 1);
+    const float* rbase = XT + (mt * 32 + 4 * hi) * p.xrow + cidx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) resv[nr][r] = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
+  }
+  __syncthreads();
+  // lrelu, zero outside [0, L) (c2 zero-pads ITS input)
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int m = wn * NR * 32 + nr * 32 + l31;
+    const int tA = t0 - h2 + m;
+    const bool ok = tA >= 0 && tA < p.L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v = acc[nr][r];
+      v = fmaxf(v, v * p.slope);
+      YT[row * p.yrow + m] = ok ? v : 0.f;
+    }
+  }
+  // ---- phase B: c2 on the interior columns n in [0, n2) <-> global time t0 + n
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias2[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+  __syncthreads();
+  if (ncol0 >= p.n2 || t0 + ncol0 >= p.L) return;
+  fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp2), (long long)mt * p.ksg2 * 64 + lane, p.ksg2, YT, p.yrow,
+                        ncol0 + l31, p.ktaps, 1, p.nchunks, hi, 1.0f);
+  // ---- epilogue: + residual (raw x from LDS), sink flags, store
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int n = ncol0 + nr * 32 + l31;
+    const int t = t0 + n;
+    if (n >= p.n2 || t >= p.L) continue;
+    float* ybase = p.y + (long long)b * p.y_bs + (long long)(mt * 32 + 4 * hi) * p.y_ld + t;
+    float yo[16];
+    if (p.flags & F_ACC) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = (r & 3) + 8 * (r >> 2);
+      float v = acc[nr][r] + resv[nr][r];
+      if (p.flags & F_ACC) v = yo[r] + v;
+      if (p.flags & F_DIV) v = v / p.div;
+      ybase[(long long)lr * p.y_ld] = v;
+    }
+  }
+}
+
+// Eligibility + launch.  Returns 1 if the fused kernel does not apply (caller runs the two convolutions).
+int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const float* x, long long x_bs, int x_ld, float* y,
+                          long long y_bs, int y_ld, unsigned flags, float div, int B, int L, hipStream_t st) {
+  static const bool enabled = !(getenv("SVOC_FUSE") && atoi(getenv("SVOC_FUSE")) == 0);
+  if (!enabled) return 1;
+  const int C = c1.Cin;
+  if (!(C == 32 || C == 64) || c1.Cout != C || c2.Cin != C || c2.Cout != C) return 1;
+  if (c1.ktaps != c2.ktaps || c2.dil != 1 || c1.transposed || c2.transposed || c1.paired || c2.paired) return 1;
+  if ((x_ld & 3) || (x_bs & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return 1;
+  if (flags & ~(unsigned)(F_ACC | F_DIV)) return 1;
+  const int k = c1.ktaps;
+  const int NA = (C == 32) ? 256 : 128;
+  FusedArgs a;
+  a.x = x; a.x_bs = x_bs; a.x_ld = x_ld; a.L = L;
+  a.wp1 = c1.wp.f(); a.bias1 = c1.bias.f(); a.ksg1 = c1.ksg_total; a.dil1 = c1.dil; a.pad1 = c1.pad;
+  a.wp2 = c2.wp.f(); a.bias2 = c2.bias.f(); a.ksg2 = c2.ksg_total; a.pad2 = c2.pad;
+  a.ktaps = k; a.nchunks = C / KC; a.C = C;
+  a.y = y; a.y_bs = y_bs; a.y_ld = y_ld; a.flags = flags; a.div = div;
+  a.n2 = (NA - (k - 1)) & ~3;
+  if (a.n2 <= 0) return 1;
+  a.xoff0 = (-(c2.pad + c1.pad)) & ~3;                                  // floor to a multiple of 4
+  const int last_col = NA - 1 - c2.pad + (k - 1) * c1.dil - c1.pad - a.xoff0;   // largest x-tile column read by phase A
+  a.xrow = round_up(std::max(last_col + 1, a.n2 - a.xoff0), 4);
+  a.yrow = round_up(NA + k - 1, 4) + 1;                                // odd stride: both half-waves hit distinct banks
+  a.slope = 0.1f;
+  const size_t lds = (size_t)C * std::max(a.xrow, a.yrow) * sizeof(float);
+  if (lds > 160 * 1024) return 1;
+  const int ntn = (L + a.n2 - 1) / a.n2;
+  dim3 grid(ntn, 1, B);
+  stats_add_conv((c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "fusedRB C%-4d k%-2d d%-2d N%-7d B%-3d NA%d", C, k, c1.dil, L, B, NA);
+    prof_idx = prof_begin(st, d, (c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L);
+  }
+  if (C == 32) {
+    auto kern = resblock_fused_kernel<1, 4, 2>;
+    static bool attr = false;
+    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  } else {
+    auto kern = resblock_fused_kernel<2, 2, 2>;
+    static bool attr = false;
+    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  }
+  prof_end(st, prof_idx);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+
+}  // namespace svoc

@@ -127,6 +127,10 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st);
 
 int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);   // conv_ws.hip; 1 = not eligible
 
+// resblock_fused.hip: one ResBlock1 iteration (c1 -> lrelu -> c2 -> + x) in one kernel; returns 1 when not eligible
+int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const float* x, long long x_bs, int x_ld, float* y,
+                          long long y_bs, int y_ld, unsigned flags, float div, int B, int L, hipStream_t st);
+
 // ------------------------------------------------------------------ small kernels (misc_kernels.hip)
 int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, int T);
 int k_gate(hipStream_t st, const float* a, const float* b, float* y, int B, int H, int T);
