@@ -483,16 +483,31 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   const bool needs_pair = a.mode >= EPI_GATE;
   if (needs_pair && !pc.paired) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "paired epilogue on an unpaired convolution");
 
-  // tile configuration: rows per block must not leave whole waves idle; short sequences get narrow tiles
+  // Tile configuration.  Rows per workgroup must not leave whole waves idle (mt % WM*MR); among the eligible
+  // shapes take the largest one that still yields at least one workgroup per CU, otherwise the one with the
+  // most workgroups: a big tile is a long chain of dependent MFMAs, which is pure latency when it cannot be
+  // overlapped with other tiles (small batches / short utterances).
   const int mt = pc.mtiles;
-  const bool shortN = a.Ncols <= 1024;
-  TileCfg c;
-  if (needs_pair) c = shortN ? CFG_E : CFG_B;
-  else if (shortN) c = (mt % 2 == 0) ? CFG_F : CFG_G;
-  else if (mt % 8 == 0) c = CFG_A;
-  else if (mt % 4 == 0) c = CFG_B;
-  else if (mt % 2 == 0) c = CFG_C;
-  else c = CFG_D2;
+  static const int ncu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  TileCfg cand[6];
+  int ncand = 0;
+  if (needs_pair) { cand[ncand++] = CFG_B; cand[ncand++] = CFG_E; }
+  else {
+    if (mt % 8 == 0) cand[ncand++] = CFG_A;
+    if (mt % 4 == 0) cand[ncand++] = CFG_B;
+    if (mt % 2 == 0) cand[ncand++] = CFG_C;
+    if (mt % 2 != 0) cand[ncand++] = CFG_D2;
+    if (mt % 2 == 0) cand[ncand++] = CFG_F;
+    cand[ncand++] = CFG_G;
+  }
+  TileCfg c = cand[0];
+  long long best = -1;
+  for (int i = 0; i < ncand; ++i) {
+    const int bn = cand[i].WN * cand[i].NR * 32, bm = cand[i].WM * cand[i].MR;
+    const long long nb = (long long)((a.Ncols + bn - 1) / bn) * ((mt + bm - 1) / bm) * B;
+    if (nb >= ncu) { c = cand[i]; best = nb; break; }
+    if (nb > best) { c = cand[i]; best = nb; }
+  }
 
   const int BN = c.WN * c.NR * 32;
   const int off_first = -pc.pad, off_last = (pc.ktaps - 1) * pc.dil - pc.pad;

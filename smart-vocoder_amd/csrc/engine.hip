@@ -69,9 +69,10 @@ struct WNStack {
     const long long per = (long long)H * Tp;
     const int gTp = g ? pad4(g_T) : 0;
     const long long gper = (long long)2 * H * NL * gTp;
-    SVOC_TRY(ws.ensure((size_t)(2 * per * B + gper * B) * sizeof(float)));
-    float* xw = ws.f();
-    float* acts = xw + per * B;
+    SVOC_TRY(ws.ensure((size_t)(3 * per * B + gper * B) * sizeof(float)));
+    float* xa = ws.f();
+    float* xb = xa + per * B;
+    float* acts = xb + per * B;
     float* gc = acts + per * B;
     if (g) {
       if (!cond) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "WN: g given but the module has gin_channels == 0");
@@ -82,18 +83,26 @@ struct WNStack {
       set_out(a.out[0], gc, gper, gTp, 2 * H * NL);
       SVOC_TRY(launch_conv(*cond, a, B, st));
     }
+    // x is ping-ponged between xa and xb: layer i reads `src` (with a (k-1)d/2 halo) and writes `dst`
+    const float* src = x; long long src_bs = x_bs; int src_ld = x_ld;
     for (int i = 0; i < NL; ++i) {
       const bool last = i == NL - 1;
-      const float* xin = i == 0 ? x : xw;
-      const long long xin_bs = i == 0 ? x_bs : per;
-      const int xin_ld = i == 0 ? x_ld : Tp;
+      float* dst = (i & 1) ? xb : xa;
+      const float* gl = g ? gc + (long long)i * 2 * H * gTp : nullptr;
+      const int gts = g_T == 1 ? 0 : 1;
+      {   // whole layer in one kernel (wn_fused.hip) when eligible
+        const int r = launch_wn_layer_fused(*in_l[i], *rs_l[i], H, src, src_bs, src_ld, dst, per, Tp, out, out_bs, out_ld, mask, mask_bs,
+                                            gl, gper, gTp, gts, i == 0 ? 1 : 0, last ? 1 : 0, B, T, st);
+        if (r < 0) return r;
+        if (r == 0) { src = dst; src_bs = per; src_ld = Tp; continue; }
+      }
       {   // in_layer + fused_add_tanh_sigmoid_multiply (commons.py:100-107)
         ConvArgs a = mk_args();
-        set_in(a, xin, xin_bs, xin_ld, T);
+        set_in(a, src, src_bs, src_ld, T);
         a.Ncols = T;
         a.mode = EPI_GATE;
         set_out(a.out[0], acts, per, Tp, H);
-        if (g) { a.gadd = gc + (long long)i * 2 * H * gTp; a.gadd_bs = gper; a.gadd_ld = gTp; a.gadd_ts = g_T == 1 ? 0 : 1; }
+        if (g) { a.gadd = gl; a.gadd_bs = gper; a.gadd_ld = gTp; a.gadd_ts = gts; }
         SVOC_TRY(launch_conv(*in_l[i], a, B, st));
       }
       {   // res_skip 1x1 + residual/skip bookkeeping (modules.py:168-175)
@@ -103,14 +112,15 @@ struct WNStack {
         a.mask = mask; a.mask_bs = mask_bs;
         if (!last) {
           a.split_row = rs_l[i]->split_row;
-          set_out(a.out[0], xw, per, Tp, H, F_RES | F_OUTMASK);
-          set_res(a.out[0], xin, xin_bs, xin_ld);
+          set_out(a.out[0], dst, per, Tp, H, F_RES | F_OUTMASK);
+          set_res(a.out[0], src, src_bs, src_ld);
           set_out(a.out[1], out, out_bs, out_ld, H, i == 0 ? 0u : (unsigned)F_ACC);
         } else {
           set_out(a.out[0], out, out_bs, out_ld, H, (i == 0 ? 0u : (unsigned)F_ACC) | F_OUTMASK);
         }
         SVOC_TRY(launch_conv(*rs_l[i], a, B, st));
       }
+      src = dst; src_bs = per; src_ld = Tp;
     }
     return SVOC_OK;
   }

@@ -131,6 +131,12 @@ int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream
 int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const float* x, long long x_bs, int x_ld, float* y,
                           long long y_bs, int y_ld, unsigned flags, float div, int B, int L, hipStream_t st);
 
+// wn_fused.hip: one WN layer (in_layer -> gate -> res_skip -> residual/skip) in one kernel; returns 1 when not eligible
+int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H, const float* x, long long x_bs, int x_ld,
+                          float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs, int out_ld, const float* mask,
+                          long long mask_bs, const float* gadd, long long gadd_bs, int gadd_ld, int gadd_ts, int first, int last,
+                          int B, int T, hipStream_t st);
+
 // ------------------------------------------------------------------ small kernels (misc_kernels.hip)
 int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, int T);
 int k_gate(hipStream_t st, const float* a, const float* b, float* y, int B, int H, int T);

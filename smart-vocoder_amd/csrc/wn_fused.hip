@@ -1,0 +1,303 @@
+// One WN layer in one kernel (reference modules.py:160-175, commons.py:100-107):
+//     x_in = in_layer(x)            Conv1d(H -> 2H, k, dilation d)
+//     acts = tanh(x_in[:H] + g[:H]) * sigmoid(x_in[H:] + g[H:])
+//     rs   = res_skip(acts)         Conv1d(H -> 2H, 1)   (last layer: H -> H)
+//     x    = (x + rs[:H]) * mask ;  out += rs[H:]        (last layer: out = (out + rs) * mask)
+// The 48 WN layers of the path work on only B*T columns (8192 at the headline config), so conv-by-conv execution
+// is launch/occupancy bound.  Here one workgroup owns a time tile for ALL channels: wave w computes the (tanh,
+// sigmoid) row pair w of the in_layer GEMM (K = H*k), the gate runs on the accumulators, the acts tile is parked in
+// LDS (aliasing the x tile) and becomes the B operand of the 1x1 res_skip GEMM (K = H), whose two row tiles per wave
+// (x-part w, skip-part w) feed the residual/skip epilogue.  acts never goes to HBM and one launch replaces two.
+// x is ping-ponged between two buffers by the caller: a tile reads a halo that its neighbours overwrite.
+#include "svoc_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace svoc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WnArgs {
+  const float* x; long long x_bs; int x_ld;            // layer input  [B][H][x_ld]
+  float* xo; long long xo_bs; int xo_ld;               // layer output x (unused on the last layer)
+  float* out; long long out_bs; int out_ld;            // skip accumulator
+  const float* mask; long long mask_bs;
+  const float* gadd; long long gadd_bs; int gadd_ld; int gadd_ts;   // conditioning slice of this layer: rows [0,2H)
+  const float* wp1; const float* bias1; int ksg1; int dil; int pad;  // in_layer (paired packing)
+  const float* wp2; const float* bias2; int ksg2;                     // res_skip (split packing, or plain on the last layer)
+  int H; int ktaps; int nchunks; int npairs; int T;
+  int xoff0; int xrow; int arow;
+  int first; int last;
+};
+
+__device__ __forceinline__ float wn_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float wn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// acc[2][NR] += W[two 32-row tiles][K] * B with B fragments from an LDS tile ([channels][row_len]); NT2 = number of
+// row tiles actually used (1 on the last layer's res_skip).
+template <int NR>
+__device__ __forceinline__ void wn_gemm(f32x16 (&acc)[2][NR], const float4* __restrict__ wp4, long long abase0, long long abase1,
+                                        bool two, int ksg_total, const float* tile, int row_len, int col0, int ktaps, int dil,
+                                        int nchunks, int hi) {
+  float4 a_cur[2], a_nxt[2];
+  a_nxt[0] = wp4[abase0];
+  a_nxt[1] = wp4[abase1];
+  int ksg = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* bp = tile + (ch * KC + hi) * row_len + col0;
+    float b_cur[4][NR], b_nxt[4][NR];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bp[(2 * s) * row_len + nr * 32];
+    const int ngroups = ktaps * (KC / 8);
+    int g = 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      a_cur[0] = a_nxt[0];
+      a_cur[1] = a_nxt[1];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) b_cur[s][nr] = b_nxt[s][nr];
+      ++ksg;
+      const long long kn = (long long)(ksg < ksg_total ? ksg : 0) * 64;
+      a_nxt[0] = wp4[abase0 + kn];
+      a_nxt[1] = wp4[abase1 + kn];
+      const float* bpn = (g == KC / 8 - 1) ? bp + dil - (KC - 8) * row_len : bp + 8 * row_len;
+      if (gi + 1 < ngroups) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bpn[(2 * s) * row_len + nr * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av0 = wn_pick4(a_cur[0], s);
+        const float av1 = wn_pick4(a_cur[1], s);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, b_cur[s][nr], acc[0][nr], 0, 0, 0);
+          if (two) acc[1][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, b_cur[s][nr], acc[1][nr], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bp = bpn;
+      g = (g + 1) & (KC / 8 - 1);
+    }
+  }
+}
+
+template <int NR>
+__global__ void __launch_bounds__(512) wn_layer_fused_kernel(const WnArgs p) {
+  constexpr int NA = NR * 32;
+  constexpr int SU = 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const XT = lds;      // x tile [H][xrow]; later aliased by the acts tile [H][arow]
+  float* const AT = lds;
+
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int pi = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's row pair
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * NA;
+  const int H = p.H;
+
+  // ---- stage the x tile: all H channels, columns [t0 + xoff0, +xrow), zero outside [0, T)
+  {
+    const int R4 = p.xrow >> 2;
+    const int total = H * R4;
+    const int xs_start = t0 + p.xoff0;
+    const float* xb = p.x + (long long)b * p.x_bs;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (p.x_ld & 3) == 0 && (p.x_bs & 3) == 0;
+    int wc = tid / R4, wg = tid - wc * R4;
+    const int dc = nthr / R4, dg = nthr - dc * R4;
+    for (int base = tid; base < total; base += nthr * SU) {
+      float4 v[SU];
+      const int wc_s = wc, wg_s = wg;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int c = min(wc, H - 1);
+        int t = xs_start + 4 * wg;
+        const float* row = xb + (long long)c * p.x_ld;
+        if (vec) {
+          t = (t >= 0 && t < p.T) ? t : 0;
+          v[u] = *reinterpret_cast<const float4*>(row + t);
+        } else {
+          v[u].x = (t >= 0 && t < p.T) ? row[t] : 0.f;
+          v[u].y = (t + 1 >= 0 && t + 1 < p.T) ? row[t + 1] : 0.f;
+          v[u].z = (t + 2 >= 0 && t + 2 < p.T) ? row[t + 2] : 0.f;
+          v[u].w = (t + 3 >= 0 && t + 3 < p.T) ? row[t + 3] : 0.f;
+        }
+        wc += dc; wg += dg;
+        if (wg >= R4) { wg -= R4; ++wc; }
+      }
+      int wc2 = wc_s, wg2 = wg_s;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (base + u * nthr < total) {
+          const int t = xs_start + 4 * wg2;
+          float4 q = v[u];
+          q.x = (t >= 0 && t < p.T) ? q.x : 0.f;
+          q.y = (t + 1 >= 0 && t + 1 < p.T) ? q.y : 0.f;
+          q.z = (t + 2 >= 0 && t + 2 < p.T) ? q.z : 0.f;
+          q.w = (t + 3 >= 0 && t + 3 < p.T) ? q.w : 0.f;
+          *reinterpret_cast<float4*>(XT + wc2 * p.xrow + 4 * wg2) = q;
+        }
+        wc2 += dc; wg2 += dg;
+        if (wg2 >= R4) { wg2 -= R4; ++wc2; }
+      }
+    }
+  }
+
+  // ---- phase A: in_layer rows (tanh tile 2*pi, sigmoid tile 2*pi+1) on columns [t0, t0+NA)
+  f32x16 acc[2][NR];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[h][nr][i] = p.bias1[(2 * pi + h) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+  __syncthreads();
+  {
+    const float4* wp4 = reinterpret_cast<const float4*>(p.wp1);
+    const long long ab0 = (long long)(2 * pi) * p.ksg1 * 64 + lane;
+    wn_gemm<NR>(acc, wp4, ab0, ab0 + (long long)p.ksg1 * 64, true, p.ksg1, XT, p.xrow, l31 - p.pad - p.xoff0, p.ktaps, p.dil,
+                p.nchunks, hi);
+  }
+  __syncthreads();     // everybody is done reading the x tile -> its LDS is reused for acts
+  {
+    const float* gb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      const int m = nr * 32 + l31;
+      const int t = min(t0 + m, p.T - 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int chn = pi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float vA = acc[0][nr][r], vB = acc[1][nr][r];
+        if (gb) {
+          vA += gb[(long long)chn * p.gadd_ld + (long long)t * p.gadd_ts];
+          vB += gb[(long long)(H + chn) * p.gadd_ld + (long long)t * p.gadd_ts];
+        }
+        AT[chn * p.arow + m] = tanhf(vA) * wn_sigmoid(vB);
+      }
+    }
+  }
+  // ---- phase B: res_skip 1x1 on the acts tile; tile pi = x part, tile npairs + pi = skip part (last layer: tile pi only)
+  const bool two = !p.last;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        acc[h][nr][i] = (h == 0 || two) ? p.bias2[(h * p.npairs + pi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi] : 0.f;
+  __syncthreads();
+  {
+    const float4* wp4 = reinterpret_cast<const float4*>(p.wp2);
+    const long long ab0 = (long long)pi * p.ksg2 * 64 + lane;
+    const long long ab1 = two ? (long long)(p.npairs + pi) * p.ksg2 * 64 + lane : ab0;
+    wn_gemm<NR>(acc, wp4, ab0, ab1, two, p.ksg2, AT, p.arow, l31, 1, 1, p.nchunks, hi);
+  }
+  // ---- epilogue (modules.py:168-175)
+  const float* mb = p.mask + (long long)b * p.mask_bs;
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int t = t0 + nr * 32 + l31;
+    if (t >= p.T) continue;
+    const float mk = mb[t];
+    const int row0 = pi * 32 + 4 * hi;
+    float* ob = p.out + (long long)b * p.out_bs + (long long)row0 * p.out_ld + t;
+    if (two) {
+      const float* xr = p.x + (long long)b * p.x_bs + (long long)row0 * p.x_ld + t;
+      float* xw = p.xo + (long long)b * p.xo_bs + (long long)row0 * p.xo_ld + t;
+      float rv[16], ov[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = xr[(long long)((r & 3) + 8 * (r >> 2)) * p.x_ld];
+      if (!p.first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2);
+        xw[(long long)lr * p.xo_ld] = (rv[r] + acc[0][nr][r]) * mk;
+        ob[(long long)lr * p.out_ld] = p.first ? acc[1][nr][r] : ov[r] + acc[1][nr][r];
+      }
+    } else {
+      float ov[16];
+      if (!p.first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2);
+        const float v = p.first ? acc[0][nr][r] : ov[r] + acc[0][nr][r];
+        ob[(long long)lr * p.out_ld] = v * mk;
+      }
+    }
+  }
+}
+
+// Returns 1 when the fused layer does not apply (caller runs in_layer and res_skip as two convolutions).
+int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H, const float* x, long long x_bs, int x_ld,
+                          float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs, int out_ld, const float* mask,
+                          long long mask_bs, const float* gadd, long long gadd_bs, int gadd_ld, int gadd_ts, int first, int last,
+                          int B, int T, hipStream_t st) {
+  static const bool enabled = !(getenv("SVOC_FUSE_WN") && atoi(getenv("SVOC_FUSE_WN")) == 0);
+  if (!enabled) return 1;
+  if (H % 32 != 0 || H / 32 > 8 || !in_l.paired || in_l.Cin != H || in_l.Cout != 2 * H || rs_l.Cin != H) return 1;
+  if (rs_l.ktaps != 1 || (last ? rs_l.Cout != H : rs_l.Cout != 2 * H)) return 1;
+  const int npairs = H / 32;
+  WnArgs a;
+  a.x = x; a.x_bs = x_bs; a.x_ld = x_ld;
+  a.xo = xo; a.xo_bs = xo_bs; a.xo_ld = xo_ld;
+  a.out = out; a.out_bs = out_bs; a.out_ld = out_ld;
+  a.mask = mask; a.mask_bs = mask_bs;
+  a.gadd = gadd; a.gadd_bs = gadd_bs; a.gadd_ld = gadd_ld; a.gadd_ts = gadd_ts;
+  a.wp1 = in_l.wp.f(); a.bias1 = in_l.bias.f(); a.ksg1 = in_l.ksg_total; a.dil = in_l.dil; a.pad = in_l.pad;
+  a.wp2 = rs_l.wp.f(); a.bias2 = rs_l.bias.f(); a.ksg2 = rs_l.ksg_total;
+  a.H = H; a.ktaps = in_l.ktaps; a.nchunks = H / KC; a.npairs = npairs; a.T = T;
+  a.first = first; a.last = last;
+  // narrow tiles when there are few columns: every CU should get a workgroup
+  static const int ncu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  const int NR = ((long long)B * ((T + 63) / 64) >= 2LL * ncu) ? 2 : 1;
+  const int NA = NR * 32;
+  const int minoff = -in_l.pad, maxoff = (in_l.ktaps - 1) * in_l.dil - in_l.pad;
+  a.xoff0 = minoff & ~3;
+  a.xrow = round_up(NA + maxoff - a.xoff0, 4);
+  a.arow = NA + 1;
+  const size_t lds = (size_t)H * std::max(a.xrow, a.arow) * sizeof(float);
+  if (lds > 160 * 1024) return 1;
+  dim3 grid((T + NA - 1) / NA, 1, B);
+  const double flops = (in_l.flops_per_col + rs_l.flops_per_col) * (double)B * (double)T;
+  stats_add_conv(flops);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "fusedWN H%-4d k%-2d d%-2d N%-7d B%-3d NA%d%s", H, in_l.ktaps, in_l.dil, T, B, NA, last ? " last" : "");
+    prof_idx = prof_begin(st, d, flops);
+  }
+  if (NR == 2) {
+    auto kern = wn_layer_fused_kernel<2>;
+    static bool attr = false;
+    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(npairs * 64), lds, st, a);
+  } else {
+    auto kern = wn_layer_fused_kernel<1>;
+    static bool attr = false;
+    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(npairs * 64), lds, st, a);
+  }
+  prof_end(st, prof_idx);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+
+}  // namespace svoc

@@ -212,14 +212,8 @@ class SynthesizerTrn(_HipModule):
         self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 8, gin_channels=gin_channels)
 
     # enc_q is not part of infer: keep it out of the native table and of the change signature
-    def _infer_state(self):
+    def _state(self):
         return {k: v for k, v in self.state_dict(keep_vars=True).items() if not k.startswith("enc_q.")}
-
-    def _sig(self):
-        return tuple((p.data_ptr(), p._version) for p in self._infer_state().values())
-
-    def _table(self):
-        return N.TensorTable(self._infer_state())
 
     def _create(self, h, tab):
         c = N.svoc_synth_config()

@@ -73,6 +73,9 @@ class _WNConvTranspose1dParams(nn.Module):
         self.weight_v = nn.Parameter(v)
 
 
+_STRUCT_EPOCH = [0]
+
+
 def _fold_in_place(m):
     """remove_weight_norm for one container: replace (weight_g, weight_v) by the folded `weight` (HIP kernel)."""
     if not hasattr(m, "weight_v"):
@@ -86,6 +89,7 @@ def _fold_in_place(m):
     del m.weight_g, m.weight_v, m.bias
     m.weight = nn.Parameter(w)     # key order after removal in the reference: bias, weight
     m.bias = bias
+    _STRUCT_EPOCH[0] += 1          # every cached tensor list is rebuilt on next use
 
 
 class _HipModule(nn.Module):
@@ -93,18 +97,52 @@ class _HipModule(nn.Module):
 
     _destroy = None
 
+    def _state(self):
+        """{state_dict key: tensor} handed to the library (parameters only; subclasses may filter)."""
+        return dict(self.state_dict(keep_vars=True))
+
     def _sig(self):
-        return tuple((k, p.data_ptr(), p._version, str(p.device), p.dtype) for k, p in self.state_dict(keep_vars=True).items())
+        # cheap per-call change detection: the cached tensor list is rebuilt only when the module structure
+        # changes (_apply / remove_weight_norm / load_state_dict(assign=True) all go through here via versions)
+        st = self.__dict__.get("_nh_tensors")
+        if st is None or self.__dict__.get("_nh_epoch") != _STRUCT_EPOCH[0]:
+            st = list(self._state().values())
+            object.__setattr__(self, "_nh_tensors", st)
+            object.__setattr__(self, "_nh_epoch", _STRUCT_EPOCH[0])
+        return (_STRUCT_EPOCH[0], len(st), sum(t._version for t in st), st[0].data_ptr() if st else 0,
+                st[-1].data_ptr() if st else 0)
 
     def _table(self):
-        return N.TensorTable({k: v for k, v in self.state_dict(keep_vars=True).items()})
+        return N.TensorTable(self._state())
+
+    def _invalidate(self):
+        object.__setattr__(self, "_nh_tensors", None)
+        if self.__dict__.get("_nh") is not None:
+            self._nh.close()
+            object.__setattr__(self, "_nh", None)
+
+    def _apply(self, fn, *a, **k):          # .cuda() / .to() / .float(): tensors are replaced
+        r = super()._apply(fn, *a, **k)
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m._invalidate()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m._invalidate()
+        return r
 
     def _native(self):
         N.require_gpu(next(self.parameters()))
         sig = self._sig()
-        if getattr(self, "_nh", None) is None or self._nh_sig != sig:
-            if getattr(self, "_nh", None) is not None:
+        if self.__dict__.get("_nh") is None or self.__dict__.get("_nh_sig") != sig:
+            if self.__dict__.get("_nh") is not None:
                 self._nh.close()
+            object.__setattr__(self, "_nh_tensors", None)
+            sig = self._sig()
             h = N.Handle(self._destroy)
             tab = self._table()
             self._create(h, tab)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Latency of SynthesizerTrn.infer at small shapes (C1 = 1x200 and a few others)."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases
+from cases import sw
+from smart_vocoder_amd import models
+net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}, strict=False)
+net = net.cuda().eval()
+for (B, T) in ((1, 200), (1, 512), (4, 512), (16, 512), (32, 512), (8, 4096)):
+    mel = torch.from_numpy(sw.synthetic_mel(1, B, T)).cuda(); eps = torch.from_numpy(sw.synthetic_eps(1, B, T)).cuda()
+    ln = torch.full((B,), T, dtype=torch.int64).cuda()
+    for _ in range(3):
+        net.infer(mel, ln, noise_scale=0.667, eps=eps)
+    torch.cuda.synchronize()
+    n = 10 if B * T <= 16384 else 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        net.infer(mel, ln, noise_scale=0.667, eps=eps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"B={B:3d} T={T:5d}: {dt * 1e3:8.3f} ms  {B * T * 256 / dt / 1e6:8.2f} M samples/s  {B * T * 256 / dt / 22050:8.0f}x RT", flush=True)
