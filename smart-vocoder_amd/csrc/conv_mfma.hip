@@ -493,7 +493,10 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   int ncand = 0;
   if (needs_pair) { cand[ncand++] = CFG_B; cand[ncand++] = CFG_E; }
   else {
-    if (mt % 8 == 0) cand[ncand++] = CFG_A;
+    // the 256x128 tile (8 accumulator tiles per wave, occupancy 2, register spills) measured slower than two
+    // 128x128 row-blocks for every C=256 layer (profiles/r01_c_*), so it is opt-in only
+    static const bool use_a = getenv("SVOC_TILE_256") && atoi(getenv("SVOC_TILE_256")) != 0;
+    if (mt % 8 == 0 && use_a) cand[ncand++] = CFG_A;
     if (mt % 4 == 0) cand[ncand++] = CFG_B;
     if (mt % 2 == 0) cand[ncand++] = CFG_C;
     if (mt % 2 != 0) cand[ncand++] = CFG_D2;
