@@ -185,49 +185,55 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
       const int groups_per_sub = p.ktaps * (KC / 8);
       int gsub = 0;                       // groups done in the current 32-channel sub-chunk
       const float* bp = bp0;
-      float b_cur[4][NR], b_nxt[4][NR];
+      float b0[4][NR], b1[4][NR];        // ping-pong activation fragments (no register moves); a_nxt/a_cur likewise
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bp[(2 * s) * p.row_len + nr * 32];
+        for (int nr = 0; nr < NR; ++nr) b0[s][nr] = bp[(2 * s) * p.row_len + nr * 32];
       int g = 0;
-      for (int gi = 0; gi < ngroups; ++gi) {
+      // The next group's fragment requests are issued after the first k-step's MFMAs so that their issue overlaps
+      // MFMA execution instead of preceding it.  ngroups is a multiple of 4, so two groups per trip is exact.
+      auto run_group = [&](float4(&ac)[MR], float(&bc)[4][NR], float4(&an)[MR], float(&bn)[4][NR], bool last_group) {
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) a_cur[mr] = a_nxt[mr];
+        for (int mr = 0; mr < MR; ++mr) {
+          const float av = ac[mr].x;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int nr = 0; nr < NR; ++nr) b_cur[s][nr] = b_nxt[s][nr];
+          for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[0][nr], acc[mr][nr], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         ++ksg;
         const int kn = ksg < ksg_last ? ksg : ksg_last;
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) a_nxt[mr] = wp4[abase[mr] + (long long)kn * 64];
+        for (int mr = 0; mr < MR; ++mr) an[mr] = wp4[abase[mr] + (long long)kn * 64];
         // next group: +8 channels; after 32 channels next tap; after the last tap the next 32-channel sub-chunk
         ++gsub;
         const float* bpn = (g != KC / 8 - 1) ? bp + 8 * p.row_len
                            : (gsub != groups_per_sub ? bp + p.dil - (KC - 8) * p.row_len
                                                      : bp + 8 * p.row_len - (p.ktaps - 1) * p.dil);
         if (gsub == groups_per_sub) gsub = 0;
-        if (gi + 1 < ngroups) {
+        if (!last_group) {
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bpn[(2 * s) * p.row_len + nr * 32];
+            for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bpn[(2 * s) * p.row_len + nr * 32];
         }
+        bp = bpn;
+        g = (g + 1) & (KC / 8 - 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 1; s < 4; ++s) {
 #pragma unroll
           for (int mr = 0; mr < MR; ++mr) {
-            const float av = pick4(a_cur[mr], s);
+            const float av = pick4(ac[mr], s);
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
-              acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[s][nr], acc[mr][nr], 0, 0, 0);
+            for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[mr][nr], 0, 0, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        bp = bpn;
-        g = (g + 1) & (KC / 8 - 1);
+      };
+      for (int gi = 0; gi < ngroups; gi += 2) {
+        run_group(a_nxt, b0, a_cur, b1, false);
+        run_group(a_cur, b1, a_nxt, b0, gi + 2 >= ngroups);
       }
     }
   }

@@ -35,51 +35,54 @@ template <int NR, bool ACT>
 __device__ __forceinline__ void fused_gemm(f32x16 (&acc)[NR], const float4* __restrict__ wp4, long long abase, int ksg_total,
                                            const float* tile, int row_len, int col0, int ktaps, int dil, int nchunks,
                                            int hi, float slope) {
-  // a group here is only 4*NR MFMAs (512 cycles at NR=2), shorter than an L2 round trip: weights run two groups ahead
-  float4 a_cur, a_nxt = wp4[abase], a_nx2 = wp4[abase + (ksg_total > 1 ? 64 : 0)];
+  // ping-pong fragment registers; the next group's requests are issued after the first k-step's MFMAs
+  float4 a0 = wp4[abase], a1;
   int ksg = 0;
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* bp = tile + (ch * KC + hi) * row_len + col0;
-    float b_cur[4][NR], b_nxt[4][NR];
+    float b0[4][NR], b1[4][NR];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bp[(2 * s) * row_len + nr * 32];
+      for (int nr = 0; nr < NR; ++nr) {
+        const float v = bp[(2 * s) * row_len + nr * 32];
+        b0[s][nr] = ACT ? fmaxf(v, v * slope) : v;            // lrelu for slope in (0,1)
+      }
     const int ngroups = ktaps * (KC / 8);
     int g = 0;
-    for (int gi = 0; gi < ngroups; ++gi) {
-      a_cur = a_nxt;
-      a_nxt = a_nx2;
+    auto run_group = [&](float4& ac, float(&bc)[4][NR], float4& an, float(&bn)[4][NR], bool last_group) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) {
-          const float v = b_nxt[s][nr];
-          b_cur[s][nr] = ACT ? fmaxf(v, v * slope) : v;       // lrelu for slope in (0,1)
-        }
+      for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, bc[0][nr], acc[nr], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       ++ksg;
-      {
-        int kn = ksg + 1;
-        if (kn >= ksg_total) kn = ksg_total - 1;
-        a_nx2 = wp4[abase + (long long)kn * 64];
-      }
+      an = wp4[abase + (long long)(ksg < ksg_total ? ksg : 0) * 64];
       const float* bpn = (g == KC / 8 - 1) ? bp + dil - (KC - 8) * row_len : bp + 8 * row_len;
-      if (gi + 1 < ngroups) {
+      if (!last_group) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bpn[(2 * s) * row_len + nr * 32];
+          for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bpn[(2 * s) * row_len + nr * 32];
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float av = fz_pick4(a_cur, s);
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_cur[s][nr], acc[nr], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
       bp = bpn;
       g = (g + 1) & (KC / 8 - 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 1; s < 4; ++s) {
+        const float av = fz_pick4(ac, s);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[nr], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ACT && !last_group) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr) bn[s][nr] = fmaxf(bn[s][nr], bn[s][nr] * slope);
+      }
+    };
+    for (int gi = 0; gi < ngroups; gi += 2) {
+      run_group(a0, b0, a1, b1, false);
+      run_group(a1, b1, a0, b0, gi + 2 >= ngroups);
     }
   }
 }

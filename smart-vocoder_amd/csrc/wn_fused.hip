@@ -41,51 +41,56 @@ template <int NR>
 __device__ __forceinline__ void wn_gemm(f32x16 (&acc)[2][NR], const float4* __restrict__ wp4, long long abase0, long long abase1,
                                         bool two, int ksg_total, const float* tile, int row_len, int col0, int ktaps, int dil,
                                         int nchunks, int hi) {
-  float4 a_cur[2], a_nxt[2];
-  a_nxt[0] = wp4[abase0];
-  a_nxt[1] = wp4[abase1];
+  // ping-pong fragment registers; the next group's requests are issued after the first k-step's MFMAs
+  float4 a0[2], a1[2];
+  a0[0] = wp4[abase0];
+  a0[1] = wp4[abase1];
   int ksg = 0;
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* bp = tile + (ch * KC + hi) * row_len + col0;
-    float b_cur[4][NR], b_nxt[4][NR];
+    float b0[4][NR], b1[4][NR];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bp[(2 * s) * row_len + nr * 32];
+      for (int nr = 0; nr < NR; ++nr) b0[s][nr] = bp[(2 * s) * row_len + nr * 32];
     const int ngroups = ktaps * (KC / 8);
     int g = 0;
-    for (int gi = 0; gi < ngroups; ++gi) {
-      a_cur[0] = a_nxt[0];
-      a_cur[1] = a_nxt[1];
+    auto run_group = [&](float4(&ac)[2], float(&bc)[4][NR], float4(&an)[2], float(&bn)[4][NR], bool last_group) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) b_cur[s][nr] = b_nxt[s][nr];
+      for (int nr = 0; nr < NR; ++nr) {
+        acc[0][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0].x, bc[0][nr], acc[0][nr], 0, 0, 0);
+        if (two) acc[1][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[1].x, bc[0][nr], acc[1][nr], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       ++ksg;
       const long long kn = (long long)(ksg < ksg_total ? ksg : 0) * 64;
-      a_nxt[0] = wp4[abase0 + kn];
-      a_nxt[1] = wp4[abase1 + kn];
+      an[0] = wp4[abase0 + kn];
+      an[1] = wp4[abase1 + kn];
       const float* bpn = (g == KC / 8 - 1) ? bp + dil - (KC - 8) * row_len : bp + 8 * row_len;
-      if (gi + 1 < ngroups) {
+      if (!last_group) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int nr = 0; nr < NR; ++nr) b_nxt[s][nr] = bpn[(2 * s) * row_len + nr * 32];
+          for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bpn[(2 * s) * row_len + nr * 32];
       }
+      bp = bpn;
+      g = (g + 1) & (KC / 8 - 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float av0 = wn_pick4(a_cur[0], s);
-        const float av1 = wn_pick4(a_cur[1], s);
+      for (int s = 1; s < 4; ++s) {
+        const float av0 = wn_pick4(ac[0], s);
+        const float av1 = wn_pick4(ac[1], s);
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
-          acc[0][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, b_cur[s][nr], acc[0][nr], 0, 0, 0);
-          if (two) acc[1][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, b_cur[s][nr], acc[1][nr], 0, 0, 0);
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bc[s][nr], acc[0][nr], 0, 0, 0);
+          if (two) acc[1][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bc[s][nr], acc[1][nr], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      bp = bpn;
-      g = (g + 1) & (KC / 8 - 1);
+    };
+    for (int gi = 0; gi < ngroups; gi += 2) {
+      run_group(a0, b0, a1, b1, false);
+      run_group(a1, b1, a0, b0, gi + 2 >= ngroups);
     }
   }
 }
