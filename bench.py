@@ -192,7 +192,8 @@ def main():
     if rank == 0:
         samples_per_step = Bj * T * net.dec.hop
         value = samples_per_step * args.steps / dt
-        # dominant kernel family: conv_mfma_kernel<...> (every convolution of the path).  Algorithmic FLOPs of the
+        # dominant kernel family: the fp32-MFMA implicit-GEMM kernels (every convolution of the path; ResBlock
+        # iterations of the C=32/64 stages and WN layers run as fused kernels of the same family).  Algorithmic FLOPs of the
         # launches in the timed region (counted by the library, 2*MAC) over the device time of the region measured
         # with HIP events on the launch stream (includes the few % spent in the small non-GEMM kernels).
         conv_tflops = stats["conv_flops"] / (gpu_ms * 1e-3) / 1e12
@@ -208,7 +209,7 @@ def main():
             "samples_per_s_per_gpu": value / world,
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv, all instantiations)",
+                         "kernel": "fp32 MFMA implicit-GEMM family: conv_mfma_kernel, resblock_fused_kernel, wn_layer_fused_kernel",
                          "launches_per_step": stats["conv_launches"] / args.steps,
                          "flop_per_step": stats["conv_flops"] / args.steps,
                          "gpu_ms_per_step_rank0": gpu_ms / args.steps},
