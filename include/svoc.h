@@ -184,6 +184,20 @@ int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const 
                           int reverse, float* y, float* logdet, int B, int T);
 void svoc_convflow_destroy(svoc_convflow* h);
 
+/* ---- mel_processing.spectrogram_torch / spec_to_mel_torch / mel_spectrogram_torch (mel_processing.py:51-112) ------ */
+typedef struct svoc_melspec svoc_melspec;
+/* n_fft must be a multiple of hop_length and win_length == n_fft (the reference uses 1024/256/1024); fmax <= 0 means
+ * sampling_rate/2 (the config's mel_fmax: null).  The mel basis restates librosa 0.8.0 filters.mel (Slaney). */
+int svoc_melspec_create(svoc_melspec** out, int n_fft, int hop_length, int win_length, int n_mels, int sampling_rate,
+                        double fmin, double fmax);
+int svoc_melspec_frames(svoc_melspec* h, int64_t n_samples);      /* frames produced for a waveform of n_samples */
+/* y [B, n_samples] -> spec [B, n_fft/2+1, frames] = sqrt(re^2 + im^2 + 1e-6) (reflect pad (n_fft-hop)/2, center=False) */
+int svoc_melspec_spectrogram(svoc_melspec* h, void* stream, const float* y, int B, int n_samples, float* spec);
+/* spec [B, n_fft/2+1, F] -> mel [B, n_mels, F] = log(clamp(mel_basis @ spec, 1e-5)) */
+int svoc_melspec_mel(svoc_melspec* h, void* stream, const float* spec, int B, int n_frames, float* mel);
+int svoc_mel_filterbank(int sampling_rate, int n_fft, int n_mels, double fmin, double fmax, float* out_host);
+void svoc_melspec_destroy(svoc_melspec* h);
+
 /* ---- transforms.piecewise_rational_quadratic_transform (transforms.py:12-193), tails='linear' or none */
 /* inputs [n]; unnormalized widths/heights [n,num_bins]; derivatives [n,num_bins-1] (linear tails) or
  * [n,num_bins+1] (tails==0, domain [0,1]); outputs, logabsdet [n]. */

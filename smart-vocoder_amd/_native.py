@@ -79,6 +79,12 @@ SIGNATURES = {
     "svoc_convflow_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _F, *_TAB, C.c_char_p]),
     "svoc_convflow_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I]),
     "svoc_convflow_destroy": (None, [_P]),
+    "svoc_melspec_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, C.c_double, C.c_double]),
+    "svoc_melspec_frames": (_I, [_P, _L]),
+    "svoc_melspec_spectrogram": (_I, [_P, _P, _P, _I, _I, _P]),
+    "svoc_melspec_mel": (_I, [_P, _P, _P, _I, _I, _P]),
+    "svoc_mel_filterbank": (_I, [_I, _I, _I, C.c_double, C.c_double, _P]),
+    "svoc_melspec_destroy": (None, [_P]),
     "svoc_rq_spline": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _P]),
     "svoc_sequence_mask": (_I, [_P, _P, _P, _I, _I]),
     "svoc_fused_add_tanh_sigmoid_multiply": (_I, [_P, _P, _P, _P, _I, _I, _I]),

@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
           if (fl & F_ACC) v = *yp + v;
           if (fl & F_DIV) v = v / odiv;
           if (fl & F_OUTMASK) v *= mk;
+          if (fl & F_LOGCLAMP) v = logf(fmaxf(v, p.log_clamp));
           *yp = v;
         }
       }
@@ -398,6 +399,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
               vB += gaddb[(long long)(H + chn) * p.gadd_ld + (long long)col * p.gadd_ts];
             }
             o.y[yo] = tanhf(vA) * sigmoidf_(vB);
+          } else if (p.mode == EPI_MAG) {
+            o.y[yo] = sqrtf(vA * vA + vB * vB + p.mag_eps);
           } else if (p.mode == EPI_PROJ) {
             const float m = vA * mk, lg = vB * mk;
             const float e = p.eps ? p.eps[(long long)b * p.eps_bs + (long long)chn * p.eps_ld + col] : 0.0f;
@@ -545,7 +548,7 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   {   // experimental persistent wave-specialised kernel (conv_ws.hip), opt-in with SVOC_WS=1: at parity with the
       // kernel below for k >= 7 and slower for small k
     static const bool use_ws = getenv("SVOC_WS") && atoi(getenv("SVOC_WS")) != 0;
-    if (use_ws) {
+    if (use_ws && a.mode != EPI_MAG && !((a.out[0].flags | a.out[1].flags) & F_LOGCLAMP)) {
       const int r = launch_conv_ws(a, B, c.WM, c.WN, c.MR, c.NR, st);
       if (r <= 0) return r;
     }

@@ -242,6 +242,33 @@ int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, floa
   return SVOC_OK;
 }
 
+// Reflect-pad the waveform by `pad` on both sides (mel_processing.py:63) and lay it out as xt[b][c][t] =
+// padded[t*hop + c]: frames of n_fft = q*hop samples become a q-tap convolution over t with hop input channels.
+__global__ void frame_blocks_kernel(const float* __restrict__ y, int Lw, int pad, int hop, float* __restrict__ xt,
+                                    long long xt_bs, int xt_ld, int nblocks) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= nblocks) return;
+  const long long Lp = (long long)Lw + 2 * pad;
+  const long long i = (long long)t * hop + c;
+  float v = 0.f;
+  if (i < Lp) {
+    long long s = i - pad;
+    if (s < 0) s = -s;                       // reflect (no edge repeat)
+    if (s >= Lw) s = 2LL * (Lw - 1) - s;
+    s = s < 0 ? 0 : (s >= Lw ? Lw - 1 : s);
+    v = y[(long long)b * Lw + s];
+  }
+  xt[(long long)b * xt_bs + (long long)c * xt_ld + t] = v;
+}
+int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int hop, float* xt, long long xt_bs, int xt_ld, int nblocks) {
+  if (B <= 0 || nblocks <= 0) return SVOC_OK;
+  hipLaunchKernelGGL(frame_blocks_kernel, dim3((nblocks + 255) / 256, hop, B), dim3(256), 0, st, y, Lw, pad, hop, xt, xt_bs, xt_ld, nblocks);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
 __global__ void fill_kernel(float* p, size_t n, float v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

@@ -50,6 +50,7 @@ enum EpiFlags : unsigned {
   F_OUTMASK  = 1u << 3,   // val *= mask[col]
   F_CPL_REV  = 1u << 4,   // val = (res - val*mask) * mask              (mean-only coupling, reverse)
   F_CPL_FWD  = 1u << 5,   // val = val*mask + res*mask                   (mean-only coupling, forward)
+  F_LOGCLAMP = 1u << 6,   // val = log(max(val, log_clamp))               (mel_processing.py:19-25)
 };
 enum EpiMode : int {
   EPI_PLAIN = 0,          // per-element flags above, optional row split
@@ -57,6 +58,7 @@ enum EpiMode : int {
   EPI_GATE = 2,           // tile pairs: y = tanh(v0+g0) * sigmoid(v1+g1)
   EPI_PROJ = 3,           // tile pairs: m=v0*mask, logs=v1*mask, z_p = m + eps*exp(logs)*noise
   EPI_CPL_FULL_REV = 4,   // tile pairs: x1 = (x1 - v0*mask) * exp(-(v1*mask)) * mask
+  EPI_MAG = 6,            // tile pairs (re, im): y = sqrt(v0^2 + v1^2 + mag_eps)  (mel_processing.py:69)
   EPI_CPL_FULL_FWD = 5,   // tile pairs: x1 = v0*mask + x1*exp(v1*mask)*mask ; logdet += sum(v1*mask)
 };
 
@@ -92,6 +94,7 @@ struct ConvArgs {
   const float* eps; long long eps_bs; int eps_ld; float noise_scale;  // EPI_PROJ
   float* y2; float* y3;                              // EPI_PROJ: logs_p, z_p (same strides as out[0])
   float* logdet;                                     // EPI_CPL_FULL_FWD
+  float mag_eps; float log_clamp;                    // EPI_MAG / F_LOGCLAMP
 };
 
 // One convolution layer repacked for the MFMA kernel.
@@ -147,6 +150,7 @@ int k_copy2d(hipStream_t st, const float* src, long long s_bs, int s_ld, float* 
 int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
                 int C, int T);
 int k_fill(hipStream_t st, float* p, size_t n, float v);
+int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int hop, float* xt, long long xt_bs, int xt_ld, int nblocks);
 
 // stats / profiler
 bool prof_enabled();

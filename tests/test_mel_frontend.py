@@ -1,0 +1,79 @@
+"""Mel front-end: filterbank restatement on CPU, HIP path vs the mel oracle on the GPU.
+The reference's own mel_processing.py is not importable here (librosa absent), so this row is pinned only by the
+published librosa algorithm and torch.stft (see oracle/mel_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import mel_oracle as MO
+
+
+def test_filterbank_properties_cpu():
+    fb = MO.mel_filterbank(22050, 1024, 80, 0.0, None)
+    assert fb.shape == (80, 513) and fb.dtype == np.float32 and (fb >= 0).all()
+    # Slaney area normalisation: each triangle integrates to ~1 over frequency (bin width sr/n_fft)
+    area = fb.sum(axis=1) * (22050 / 1024)
+    assert np.allclose(area[5:], 1.0, atol=0.08), area
+    # centres increase monotonically; the scale is linear below 1 kHz and logarithmic above
+    centers = fb.argmax(axis=1)
+    assert (np.diff(centers) > 0).all()
+    assert abs(MO.hz_to_mel(1000.0) - 15.0) < 1e-12 and abs(MO.mel_to_hz(MO.hz_to_mel(4321.0)) - 4321.0) < 1e-9
+    # known anchor of the Slaney scale used by librosa: 6400 Hz is 27 log-steps above 1000 Hz
+    assert abs(MO.hz_to_mel(6400.0) - 42.0) < 1e-9
+
+
+def test_library_filterbank_matches_oracle():
+    import __graft_entry__ as g
+    g.build()
+    from smart_vocoder_amd import mel_processing as MP
+    for (sr, n_fft, nm, fmin, fmax) in ((22050, 1024, 80, 0.0, None), (16000, 512, 40, 50.0, 7600.0)):
+        a = MP.mel_filterbank(sr, n_fft, nm, fmin, fmax).numpy()
+        b = MO.mel_filterbank(sr, n_fft, nm, fmin, fmax)
+        assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max())
+
+
+def test_data_utils_names_import():
+    from smart_vocoder_amd import data_utils
+    with pytest.raises(NotImplementedError):
+        data_utils.AudioSpecLoader("x", None)
+
+
+def _audio(seed, B, n):
+    t = np.arange(n) / 22050.0
+    y = 0.3 * np.sin(2 * np.pi * 220.0 * t)[None] + 0.2 * np.sin(2 * np.pi * 3500.0 * t + 1.0)[None]
+    y = y + 0.05 * cases.sw.normal(seed, "audio", (B, n))
+    return np.clip(y, -1, 1).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n", [(1, 22050), (3, 8192 + 77), (2, 1024)])
+def test_spectrogram_and_mel_vs_oracle(B, n):
+    from smart_vocoder_amd import mel_processing as MP
+    y = torch.from_numpy(_audio(11, B, n))
+    spec = MP.spectrogram_torch(y.cuda(), 1024, 22050, 256, 1024, center=False).cpu()
+    ref = MO.spectrogram(y, 1024, 256, 1024)
+    assert spec.shape == ref.shape
+    err = (spec - ref).abs().max().item()
+    assert err <= 2e-4 * max(1.0, ref.abs().max().item()), err          # |X| up to ~100; fp32 1024-term sums
+    mel = MP.spec_to_mel_torch(spec.cuda(), 1024, 80, 22050, 0.0, None).cpu()
+    mref = MO.spec_to_mel(ref, 1024, 80, 22050, 0.0, None)
+    merr = (mel - mref).abs().max().item()
+    assert merr <= 2e-3, merr                                          # log domain
+    mel2 = MP.mel_spectrogram_torch(y.cuda(), 1024, 80, 22050, 256, 1024, 0.0, None).cpu()
+    assert torch.equal(mel2, mel)
+
+
+@pytest.mark.gpu
+def test_notebook_flow_wav_to_audio():
+    """inference.ipynb cell 4 end to end on the GPU: audio -> spectrogram_torch -> spec_to_mel_torch -> infer"""
+    from smart_vocoder_amd import mel_processing as MP, models
+    net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}, strict=False)
+    net = net.cuda().eval()
+    y = torch.from_numpy(_audio(12, 1, 22050)).cuda()
+    spec = MP.spectrogram_torch(y, 1024, 22050, 256, 1024, center=False)
+    mel = MP.spec_to_mel_torch(spec, 1024, 80, 22050, 0.0, None)
+    ln = torch.LongTensor([mel.size(2)]).cuda()
+    audio = net.infer(mel, ln, sid=None, noise_scale=.667, noise_scale_w=0.8, length_scale=1)[0][0, 0].data.cpu().float().numpy()
+    assert audio.shape == (mel.size(2) * 256,) and np.isfinite(audio).all() and np.abs(audio).max() <= 1.0
