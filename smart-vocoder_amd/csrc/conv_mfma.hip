@@ -443,7 +443,6 @@ struct TileCfg { int WM, WN, MR, NR; };
 constexpr TileCfg CFG_A{4, 1, 2, 4};   // 256 rows x 128 cols
 constexpr TileCfg CFG_B{2, 2, 2, 2};   // 128 x 128
 constexpr TileCfg CFG_C{2, 2, 1, 4};   //  64 x 256
-constexpr TileCfg CFG_D{1, 4, 1, 4};   //  32 x 512
 constexpr TileCfg CFG_D2{1, 4, 1, 2};  //  32 x 256
 constexpr TileCfg CFG_E{2, 2, 2, 1};   // 128 x  64  (short sequences, paired)
 constexpr TileCfg CFG_F{2, 2, 1, 1};   //  64 x  64  (short sequences)
@@ -557,7 +556,6 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   SVOC_LAUNCH(CFG_A);
   SVOC_LAUNCH(CFG_B);
   SVOC_LAUNCH(CFG_C);
-  SVOC_LAUNCH(CFG_D);
   SVOC_LAUNCH(CFG_D2);
   SVOC_LAUNCH(CFG_E);
   SVOC_LAUNCH(CFG_F);

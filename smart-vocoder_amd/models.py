@@ -259,6 +259,33 @@ class SynthesizerTrn(_HipModule):
                                          N.ptr(m_p), N.ptr(logs_p), B, T))
         return o, x_mask, (z, z_p, m_p, logs_p)
 
+    # receptive half-width of the whole path in mel frames: encoder WN 16*2 + flow 4*8*2 + decoder (conv_pre 3,
+    # and <= 60/8 + 60/64 + 60/128 + 60/256 + upsampler taps) -- 128 covers it with margin
+    RECEPTIVE_FRAMES = 128
+
+    def infer_chunked(self, x, x_lengths, chunk_frames=1024, noise_scale=1, eps=None, halo_frames=None):
+        """Long-form inference by time tiling: the mel is cut into chunks of `chunk_frames`, each is
+        run with `halo_frames` of real context on both sides, and only the interior samples are kept.  With a halo
+        of at least RECEPTIVE_FRAMES the result equals one-shot `infer` (every output sample sees the same inputs in
+        the same summation order), while the activation workspace stays bounded by the chunk size.
+        Returns the waveform [B, 1, T*hop] only."""
+        x = N.f32(x)
+        B, _, T = x.shape
+        halo = self.RECEPTIVE_FRAMES if halo_frames is None else int(halo_frames)
+        hop = self.dec.hop
+        if eps is None:
+            eps = torch.randn(B, self.inter_channels, T, dtype=torch.float32, device=x.device)
+        eps = N.f32(eps)
+        ln = x_lengths.to(device=x.device, dtype=torch.int64)
+        out = torch.empty(B, 1, T * hop, dtype=torch.float32, device=x.device)
+        for s in range(0, T, chunk_frames):
+            e = min(T, s + chunk_frames)
+            a, b = max(0, s - halo), min(T, e + halo)
+            o = self.infer(x[:, :, a:b].contiguous(), torch.clamp(ln - a, min=0, max=b - a), noise_scale=noise_scale,
+                           eps=eps[:, :, a:b].contiguous())[0]
+            out[:, :, s * hop:e * hop] = o[:, :, (s - a) * hop:(e - a) * hop]
+        return out
+
     def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
         # the reference's implementation dereferences a non-existent self.emb_g (models.py:343)
         raise AttributeError("'SynthesizerTrn' object has no attribute 'emb_g'")

@@ -296,3 +296,14 @@ def test_infer_long_form_tiling(M, net):
     err = (o.cpu() - o_ref).numpy()
     rms, ref = float(np.sqrt((err ** 2).mean())), float(o_ref.pow(2).mean().sqrt())
     assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)
+
+
+def test_infer_chunked_equals_one_shot(M, net):
+    """time tiling with a receptive-field halo reproduces one-shot inference (here: bit for bit)."""
+    Tn = 1500
+    mel = sw.synthetic_mel(777, 2, Tn); eps = sw.synthetic_eps(777, 2, Tn)
+    ln = np.array([Tn, 1100], dtype=np.int64)
+    full = net.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=0.667, eps=T(eps).cuda())[0]
+    tiled = net.infer_chunked(T(mel).cuda(), T(ln).cuda(), chunk_frames=400, noise_scale=0.667, eps=T(eps).cuda())
+    d = (full - tiled).abs().max().item()
+    assert d <= 1e-6, d
