@@ -214,6 +214,18 @@ def main():
                          "flop_per_step": stats["conv_flops"] / args.steps,
                          "gpu_ms_per_step_rank0": gpu_ms / args.steps},
         }
+        # HBM traffic of the same workload from PMC counters (collected offline with rocprofv3 --pmc in separate passes,
+        # tools/pmc_traffic.py; counters cannot be read from inside this process)
+        tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
+        if os.path.isfile(tpath) and B == 16 and T == 512:
+            try:
+                tj = json.load(open(tpath))
+                res["roofline"]["traffic"] = tj["gemm_family_bytes_per_launch"]
+                res["roofline"]["traffic_unit"] = "bytes per GEMM-family launch (mean)"
+                res["roofline"]["traffic_bytes_per_step"] = tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"]
+                res["roofline"]["traffic_source"] = "profiles/r01_c_pmc_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*)"
+            except Exception:   # noqa: BLE001
+                pass
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_sample_batch, T, 1001)
         print(json.dumps(res))
