@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvoc_hip.so")
+# SVOC_LIB selects another build of the same library (A/B comparisons of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("SVOC_LIB") or os.path.join(_HERE, "csrc", "libsvoc_hip.so")
 
 ABI_VERSION = 1
 _lib = None

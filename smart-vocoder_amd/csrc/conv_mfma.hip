@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
   const int stage_dc = NT / R4, stage_dg = NT - stage_dc * R4;
 
   long long tstamp[4] = {0, 0, 0, 0};
-  if (p.dbg) tstamp[0] = __builtin_readcyclecounter();
+  auto dbg_clock = [&]() -> long long { return p.dbg_wall ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter(); };
+  if (p.dbg) tstamp[0] = dbg_clock();
   const int sub_per_stage = p.kcs / KC;
   for (int ch = 0; ch < p.nchunks; ch += sub_per_stage) {
     __syncthreads();
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
       }
     }
     __syncthreads();
-    if (p.dbg && ch == 0) tstamp[1] = __builtin_readcyclecounter();
+    if (p.dbg && ch == 0) tstamp[1] = dbg_clock();
 
     if (wave_active) {
       // Group-level software pipeline (a group = 4 k-steps = 8 input channels of one tap): at the top of
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
     }
   }
 
-  if (p.dbg) tstamp[2] = __builtin_readcyclecounter();
+  if (p.dbg) tstamp[2] = dbg_clock();
   if (!wave_active) return;
 
   auto run_epilogue = [&]() {
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
   };
   run_epilogue();
   if (p.dbg && threadIdx.x == 0) {
-    tstamp[3] = __builtin_readcyclecounter();
+    tstamp[3] = dbg_clock();
     const long long lin = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
     long long* d = p.dbg + 4 * lin;
     d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
@@ -546,9 +547,9 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
 
   {   // experimental persistent wave-specialised kernel (conv_ws.hip), opt-in with SVOC_WS=1: at parity with the
       // kernel below for k >= 7 and slower for small k
-    static const bool use_ws = getenv("SVOC_WS") && atoi(getenv("SVOC_WS")) != 0;
-    if (use_ws && a.mode != EPI_MAG && !((a.out[0].flags | a.out[1].flags) & F_LOGCLAMP)) {
-      const int r = launch_conv_ws(a, B, c.WM, c.WN, c.MR, c.NR, st);
+    static const int ws_mode = getenv("SVOC_WS") ? atoi(getenv("SVOC_WS")) : 0;
+    if (ws_mode != 0 && a.mode != EPI_MAG && !((a.out[0].flags | a.out[1].flags) & F_LOGCLAMP)) {
+      const int r = ws_mode == 2 ? launch_conv_ws2(a, B, c.WM, c.WN, c.MR, c.NR, st) : launch_conv_ws(a, B, c.WM, c.WN, c.MR, c.NR, st);
       if (r <= 0) return r;
     }
   }

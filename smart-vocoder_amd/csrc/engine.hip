@@ -717,6 +717,7 @@ int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, co
   a.pre_slope = 0.1f;
   a.Ncols = L;
   a.dbg = (long long*)dbg.p;
+  a.dbg_wall = getenv("SVOC_DBG_WALL") && atoi(getenv("SVOC_DBG_WALL")) != 0;   // phases in 10 ns units
   set_out(a.out[0], y, (long long)C * L, L, C, residual ? (unsigned)F_RES : 0u);
   if (residual) set_res(a.out[0], residual, (long long)C * L, L);
   for (int it = 0; it < 2; ++it) SVOC_TRY(launch_conv(pc, a, B, st));
@@ -724,14 +725,17 @@ int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, co
   std::vector<long long> h(maxblocks * 4);
   SVOC_HIP(hipMemcpy(h.data(), dbg.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
   double s0 = 0, s1 = 0, s2 = 0; long long n = 0, tmin = 0, tmax = 0;
-  if (getenv("SVOC_DBG_DUMP")) {   // first 3 records of each half (consumer wave 0, producer wave 4 of the persistent kernel)
-    long long nrec = 0;
-    for (size_t i = 0; i < maxblocks; ++i) if (h[4 * i + 3] != 0) ++nrec;
-    for (size_t i = 0, shown = 0; i < maxblocks && shown < 6; ++i) {
-      const long long* d = &h[4 * i];
-      if (d[3] == 0) continue;
-      if (shown < 3 || i >= (size_t)nrec / 2) { fprintf(stderr, "dbg[%zu] %lld %lld %lld\n", i, d[1] - d[0], d[2] - d[1], d[3] - d[2]); ++shown; }
-    }
+  if (getenv("SVOC_DBG_DUMP")) {   // two records from each of SVOC_DBG_DUMP sections (roles of the persistent kernels)
+    const int nsec = std::max(1, atoi(getenv("SVOC_DBG_DUMP")));
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < maxblocks; ++i) if (h[4 * i + 3] != 0) idx.push_back(i);
+    for (int sct = 0; sct < nsec; ++sct)
+      for (size_t j = 0; j < 2; ++j) {
+        const size_t q = idx.size() * sct / nsec + j;
+        if (q >= idx.size()) continue;
+        const long long* d = &h[4 * idx[q]];
+        fprintf(stderr, "dbg[%zu] %lld %lld %lld\n", idx[q], d[1] - d[0], d[2] - d[1], d[3] - d[2]);
+      }
   }
   for (size_t i = 0; i < maxblocks; ++i) {
     const long long* d = &h[4 * i];

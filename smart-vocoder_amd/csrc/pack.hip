@@ -179,7 +179,9 @@ int pack_conv(PackedConv& pc, const PackSpec& sp, const float* w, const float* g
   pc.flops_per_col = 2.0 * sp.Cin * sp.Cout * sp.K;
 
   const long long total = (long long)pc.mtiles * pc.ksg_total * 256;
-  SVOC_TRY(pc.wp.ensure((size_t)total * sizeof(float)));
+  // one extra (zeroed) group: the kernels prefetch the weight stream one group past the last one they use
+  SVOC_TRY(pc.wp.ensure((size_t)(total + 256) * sizeof(float)));
+  SVOC_HIP(hipMemsetAsync(pc.wp.f() + total, 0, 256 * sizeof(float), st));
   SVOC_TRY(pc.bias.ensure((size_t)rowsP * sizeof(float)));
 
   TmpDev d_row_o, d_row_tap0, d_col_src, d_scale;

@@ -83,6 +83,7 @@ struct ConvArgs {
   int Ncols;                                         // output columns
   int ntn; int B;                                    // persistent kernel: time tiles per batch element, batch size
   long long* dbg;                                    // optional [nblocks][4] cycle stamps (diagnostics)
+  int dbg_wall;                                      // stamps from the 100 MHz wall clock instead of the shader clock
   // epilogue
   int mode;
   const float* mask; long long mask_bs;              // [B][>=Ncols] output-side mask
@@ -129,6 +130,7 @@ int fold_weight_norm(hipStream_t st, const float* v, const float* g, float* w, l
 int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st);
 
 int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);   // conv_ws.hip; 1 = not eligible
+int launch_conv_ws2(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);  // two consumer sets; 1 = not eligible
 
 // resblock_fused.hip: one ResBlock1 iteration (c1 -> lrelu -> c2 -> + x) in one kernel; returns 1 when not eligible
 int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const float* x, long long x_bs, int x_ld, float* y,

@@ -1,6 +1,7 @@
 """The alternate kernel paths are selected by environment variables that the library reads once per process, so each
 variant runs a slice of the parity suite in a subprocess:
   SVOC_WS=1                      experimental persistent wave-specialised convolution kernel (csrc/conv_ws.hip)
+  SVOC_WS=2                      ... with two consumer sets per workgroup
   SVOC_FUSE=0 SVOC_FUSE_WN=0     unfused fallbacks (two convolutions per ResBlock iteration / WN layer)
   SVOC_STREAMS=0                 single-stream MRF
   SVOC_TILE_256=1                256x128 tile for the C=256 stage
@@ -18,8 +19,8 @@ pytestmark = pytest.mark.gpu
 SLICE = "test_infer_vs_reference_golden or test_resblock1 or test_wn or test_generator or test_coupling"
 
 
-@pytest.mark.parametrize("env", [{"SVOC_WS": "1"}, {"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"}, {"SVOC_STREAMS": "0"},
-                                 {"SVOC_TILE_256": "1"}], ids=["ws", "unfused", "single_stream", "tile256"])
+@pytest.mark.parametrize("env", [{"SVOC_WS": "1"}, {"SVOC_WS": "2"}, {"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"}, {"SVOC_STREAMS": "0"},
+                                 {"SVOC_TILE_256": "1"}], ids=["ws", "ws2", "unfused", "single_stream", "tile256"])
 def test_variant(env):
     e = dict(os.environ)
     e.update(env)
