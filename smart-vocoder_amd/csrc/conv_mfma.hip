@@ -42,8 +42,9 @@ __device__ __forceinline__ float pick4(const float4& v, int s) {
   return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
 }
 
+// One output tile: workgroup (bx, by, bz) = (time tile, row block, batch element) of problem p.
 template <int WM, int WN, int MR, int NR>
-__global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const int by, const int bz, const long long dbg_lin) {
   constexpr int NT = WM * WN * 64;
   constexpr int BN = WN * NR * 32;
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -53,9 +54,9 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z;
-  const int n0 = blockIdx.x * BN;
-  const int mt0 = (blockIdx.y * WM + wm) * MR;
+  const int b = bz;
+  const int n0 = bx * BN;
+  const int mt0 = (by * WM + wm) * MR;
   const int ncol0 = n0 + wn * NR * 32;
   const bool wave_active = (mt0 < p.mtiles) && (ncol0 < p.Ncols);
 
@@ -431,10 +432,31 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
   run_epilogue();
   if (p.dbg && threadIdx.x == 0) {
     tstamp[3] = dbg_clock();
-    const long long lin = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
-    long long* d = p.dbg + 4 * lin;
+    long long* d = p.dbg + 4 * dbg_lin;
     d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3];
   }
+}
+
+template <int WM, int WN, int MR, int NR>
+__global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma_kernel(const ConvArgs p) {
+  conv_tile<WM, WN, MR, NR>(p, blockIdx.x, blockIdx.y, blockIdx.z,
+                            blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z));
+}
+
+// Several independent convolutions of one tile shape in ONE launch (the three MRF chains' step-i convolutions):
+// workgroups are numbered problem by problem, longest tiles first, so the short ones fill the tail of the long ones
+// and there is one tail per launch instead of one per convolution.
+template <int WM, int WN, int MR, int NR>
+__global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_group_kernel(const ConvGroup g) {
+  const int lin = blockIdx.x;
+  int pi = 0;
+  if (lin >= g.end[0]) pi = 1;
+  if (lin >= g.end[1]) pi = 2;
+  const int local = lin - (pi == 0 ? 0 : g.end[pi - 1]);
+  const ConvArgs& p = g.a[pi];
+  const int t = local / p.ntn;
+  const int bz = t / p.gy;
+  conv_tile<WM, WN, MR, NR>(p, local - t * p.ntn, t - bz * p.gy, bz, lin);
 }
 
 // ------------------------------------------------------------------ host side
@@ -468,8 +490,9 @@ int launch_cfg(const ConvArgs& a, int B, hipStream_t st) {
 
 }  // namespace
 
-int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
-  if (B <= 0 || a.Ncols <= 0) return SVOC_OK;
+namespace {
+// Completes `a` from the packed convolution and picks the tile configuration.
+int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
   a.wp = pc.wp.f();
   a.bias = pc.bias.f();
   a.Cin = pc.Cin;
@@ -512,7 +535,7 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
     if (mt % 2 == 0) cand[ncand++] = CFG_F;
     cand[ncand++] = CFG_G;
   }
-  TileCfg c = cand[0];
+  c = cand[0];
   long long best = -1;
   for (int i = 0; i < ncand; ++i) {
     const int bn = cand[i].WN * cand[i].NR * 32, bm = cand[i].WM * cand[i].MR;
@@ -533,6 +556,17 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
     const int nfit = std::max(1, budget / per32);
     a.kcs = KC * std::min(a.nchunks, nfit);
   }
+  a.ntn = (a.Ncols + BN - 1) / BN;
+  a.gy = (a.mtiles + c.WM * c.MR - 1) / (c.WM * c.MR);
+  a.B = B;
+  return SVOC_OK;
+}
+}  // namespace
+
+int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
+  if (B <= 0 || a.Ncols <= 0) return SVOC_OK;
+  TileCfg c{};
+  SVOC_TRY(prepare_conv(pc, a, B, c));
 
   const double flops = pc.flops_per_col * (double)B * (double)(pc.transposed ? a.Lin : a.Ncols);
   stats_add_conv(flops);
@@ -545,7 +579,7 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   }
   struct ProfEnd { hipStream_t st; int i; ~ProfEnd() { prof_end(st, i); } } prof_end_guard{st, prof_idx};
 
-  {   // experimental persistent wave-specialised kernel (conv_ws.hip), opt-in with SVOC_WS=1: at parity with the
+  {   // experimental persistent wave-specialised kernels (conv_ws.hip), opt-in with SVOC_WS=1 / 2: at parity with the
       // kernel below for k >= 7 and slower for small k
     static const int ws_mode = getenv("SVOC_WS") ? atoi(getenv("SVOC_WS")) : 0;
     if (ws_mode != 0 && a.mode != EPI_MAG && !((a.out[0].flags | a.out[1].flags) & F_LOGCLAMP)) {
@@ -563,6 +597,50 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   SVOC_LAUNCH(CFG_G);
 #undef SVOC_LAUNCH
   SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "no tile configuration");
+}
+
+// n <= 3 independent convolutions in one launch (all must select the 128x128 tile); returns 1 when the group is not
+// eligible, in which case the caller launches them one by one.  Problems should be ordered longest tile first.
+int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, int B, hipStream_t st) {
+  static const bool enabled = !(getenv("SVOC_GROUP") && atoi(getenv("SVOC_GROUP")) == 0);
+  if (!enabled || n < 2 || n > 3 || B <= 0) return 1;
+  ConvGroup g{};
+  size_t lds = 0;
+  double flops = 0;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.a[i] = as[i];
+    if (g.a[i].Ncols <= 0 || g.a[i].mode != EPI_PLAIN) return 1;
+    TileCfg c{};
+    SVOC_TRY(prepare_conv(*pcs[i], g.a[i], B, c));
+    if (!(c.WM == CFG_B.WM && c.WN == CFG_B.WN && c.MR == CFG_B.MR && c.NR == CFG_B.NR)) return 1;
+    lds = std::max(lds, (size_t)g.a[i].kcs * g.a[i].row_len * sizeof(float));
+    total += (long long)g.a[i].ntn * g.a[i].gy * B;
+    if (total > 0x7fffffffLL) return 1;
+    g.end[i] = (int)total;
+    flops += pcs[i]->flops_per_col * (double)B * (double)g.a[i].Ncols;
+  }
+  for (int i = n; i < 3; ++i) g.end[i] = 0x7fffffff;
+  if (n == 2) g.end[1] = 0x7fffffff;
+  if (lds > 160 * 1024) return 1;
+  for (int i = 0; i < n; ++i) stats_add_conv(pcs[i]->flops_per_col * (double)B * (double)g.a[i].Ncols);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "group Ci%-4d Co%-4d k%d/%d/%d N%-7d B%-3d", pcs[0]->Cin, pcs[0]->Cout, pcs[0]->ktaps, pcs[1]->ktaps,
+             n > 2 ? pcs[2]->ktaps : 0, g.a[0].Ncols, B);
+    prof_idx = prof_begin(st, d, flops);
+  }
+  auto kern = conv_group_kernel<CFG_B.WM, CFG_B.WN, CFG_B.MR, CFG_B.NR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, g);
+  prof_end(st, prof_idx);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
 }
 
 }  // namespace svoc

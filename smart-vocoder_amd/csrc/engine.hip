@@ -405,6 +405,87 @@ struct Generator {
   int n_bufs() const { return use_streams ? 3 + 2 * cfg.n_kernels : 4; }
   size_t workspace_bytes(int B, int T) const { return ((size_t)n_bufs() * stage_floats(T) * B + (size_t)cfg.upsample_initial_channel * B) * sizeof(float); }
 
+  // Grouped MRF (unfused ResBlock1 stages): the n_kernels chains advance in lock step, one launch per step carrying
+  // all chains' convolutions, longest tiles (largest kernel size) first.  The stream plan's buffers are reused:
+  // (A, Bf) per chain.  The last c2 of each chain accumulates into XS in chain order, so those run one by one.
+  bool mrf_grouped(int stage, int C) const {
+    static const bool on = !(getenv("SVOC_GROUP") && atoi(getenv("SVOC_GROUP")) == 0);
+    static const bool fuse = !(getenv("SVOC_FUSE") && atoi(getenv("SVOC_FUSE")) == 0);
+    const int nk = cfg.n_kernels;
+    if (!on || nk < 2 || nk > 3) return false;
+    if (fuse && (C == 32 || C == 64)) return false;          // resblock_fused_kernel handles these
+    const ResBlock& r0 = *rbs[stage * nk];
+    for (int j = 0; j < nk; ++j) {
+      const ResBlock& rb = *rbs[stage * nk + j];
+      if (rb.kind != 1 || rb.ND != r0.ND) return false;
+    }
+    return true;
+  }
+
+  int run_mrf_grouped(hipStream_t st, int stage, const float* X, float* XS, const std::vector<float*>& bufs, long long bs, int ld,
+                      int C, int B, int L) {
+    const int nk = cfg.n_kernels;
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + nk, [&](int a, int b) { return rbs[stage * nk + a]->K > rbs[stage * nk + b]->K; });
+    const float* cur[3] = {X, X, X};
+    const int ND = rbs[stage * nk]->ND;
+    for (int it = 0; it < ND; ++it) {
+      const bool last = it == ND - 1;
+      const PackedConv* pcs[3];
+      ConvArgs as[3];
+      float* scratch[3];
+      float* nxt[3];
+      for (int q = 0; q < nk; ++q) {
+        const int j = order[q];
+        float* A = bufs[3 + 2 * j];
+        float* Bf = bufs[4 + 2 * j];
+        scratch[q] = (cur[j] == A) ? Bf : A;
+        nxt[q] = (cur[j] == A || cur[j] == Bf) ? const_cast<float*>(cur[j]) : Bf;
+        ConvArgs a = mk_args();
+        set_in(a, cur[j], bs, ld, L);
+        a.pre_slope = 0.1f;
+        a.Ncols = L;
+        set_out(a.out[0], scratch[q], bs, ld, C);
+        as[q] = a;
+        pcs[q] = rbs[stage * nk + j]->c1[it].get();
+      }
+      int r = launch_conv_group(pcs, as, nk, B, st);
+      if (r < 0) return r;
+      if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
+      for (int q = 0; q < nk; ++q) {
+        const int j = order[q];
+        ConvArgs a = mk_args();
+        set_in(a, scratch[q], bs, ld, L);
+        a.pre_slope = 0.1f;
+        a.Ncols = L;
+        set_out(a.out[0], nxt[q], bs, ld, C, F_RES);
+        set_res(a.out[0], cur[j], bs, ld);
+        as[q] = a;
+        pcs[q] = rbs[stage * nk + j]->c2[it].get();
+      }
+      if (!last) {
+        r = launch_conv_group(pcs, as, nk, B, st);
+        if (r < 0) return r;
+        if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
+        for (int q = 0; q < nk; ++q) cur[order[q]] = nxt[q];
+      } else {
+        for (int j = 0; j < nk; ++j) {        // xs = sum_j ResBlock_j(x) / n, accumulated in chain order (models.py:149-155)
+          int q = 0;
+          while (order[q] != j) ++q;
+          ConvArgs a = as[q];
+          unsigned fl = F_RES;
+          if (j > 0) fl |= F_ACC;
+          if (j == nk - 1) fl |= F_DIV;
+          set_out(a.out[0], XS, bs, ld, C, fl);
+          a.out[0].div = (float)nk;
+          set_res(a.out[0], cur[j], bs, ld);
+          SVOC_TRY(launch_conv(*pcs[q], a, B, st));
+        }
+      }
+    }
+    return SVOC_OK;
+  }
+
   int forward(hipStream_t st, const float* x, int x_ld, long long x_bs, const float* in_mask, long long in_mask_bs,
               const float* g, float* out, int B, int T) {
     const size_t sf = stage_floats(T);
@@ -453,6 +534,13 @@ struct Generator {
         SVOC_TRY(launch_conv(*ups[i], a, B, st));
       }
       const long long bs = (long long)cho * ldo;
+      if (use_streams && mrf_grouped(i, cho)) {
+        // MRF with the chains' step-i convolutions grouped into single launches (conv_group_kernel)
+        SVOC_TRY(run_mrf_grouped(st, i, X, XS, bufs, bs, ldo, cho, B, Lo));
+        r ^= 1;
+        ch = cho; L = Lo; ld = ldo;
+        continue;
+      }
       if (use_streams) SVOC_HIP(hipEventRecord(ev_fork, st));
       for (int j = 0; j < cfg.n_kernels; ++j) {   // MRF: xs = sum_j ResBlock_j(x); x = xs / n (models.py:149-155)
         ResSink sink{XS, bs, ldo, 0u, 1.0f};

@@ -81,7 +81,8 @@ struct ConvArgs {
   int ksg_total;                                     // groups of 4 k-steps per m-tile
   int xoff0; int row_len;                            // LDS tile: starts at n0+xoff0 (multiple of 4), row_len floats
   int Ncols;                                         // output columns
-  int ntn; int B;                                    // persistent kernel: time tiles per batch element, batch size
+  int ntn; int B;                                    // time tiles per batch element, batch size (persistent and grouped kernels)
+  int gy;                                            // row blocks per time tile (grouped kernel)
   long long* dbg;                                    // optional [nblocks][4] cycle stamps (diagnostics)
   int dbg_wall;                                      // stamps from the 100 MHz wall clock instead of the shader clock
   // epilogue
@@ -129,6 +130,8 @@ int fold_weight_norm(hipStream_t st, const float* v, const float* g, float* w, l
 // Fills geometry fields (wp, bias, taps, tiles, LDS tile) of `a` from `pc`; caller sets x/epilogue fields first.
 int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st);
 
+struct ConvGroup { ConvArgs a[3]; int end[3]; };     // conv_group_kernel: end[i] = first workgroup id after problem i
+int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, int B, hipStream_t st);   // 1 = not eligible
 int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);   // conv_ws.hip; 1 = not eligible
 int launch_conv_ws2(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);  // two consumer sets; 1 = not eligible
 

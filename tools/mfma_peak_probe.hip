@@ -213,6 +213,64 @@ __global__ void __launch_bounds__(256) mfma_mix(float* out, const float* rnd, in
   if (s == 12345.678f) out[0] = s;
 }
 
+// Same instruction counts, but spread: one VALU / ds_read / SALU is placed after each of the first N MFMAs instead of
+// in one block ahead of them.
+template <int NV, int NL, int NS>
+__global__ void __launch_bounds__(256) mfma_interleaved(float* out, const float* rnd, int iters) {
+  __shared__ float sm[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = rnd[i];
+  __syncthreads();
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  const float a = 0.25f + threadIdx.x * 1e-6f, b = 0.5f;
+  unsigned laddr = (threadIdx.x & 63) * 4;
+  int x = threadIdx.x, sx = iters;
+  float r0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < NV) asm volatile("v_add_u32 %0, %0, 1" : "+v"(x));
+      if (m + 16 < NV) asm volatile("v_add_u32 %0, %0, 1" : "+v"(x));
+      if (m < NL) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r0) : "v"(laddr), "n"(m * 256));
+      if (m < NS) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NL > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float s = (float)x + (float)sx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += acc[i][j];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <int NV, int NL, int NS>
+void run_interleaved(int blocks, int iters) {
+  float *out, *rnd;
+  (void)hipMalloc(&out, 4);
+  (void)hipMalloc(&rnd, 65536 * 4);
+  (void)hipMemset(rnd, 0, 65536 * 4);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  mfma_interleaved<NV, NL, NS><<<blocks, 256>>>(out, rnd, iters / 10);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  mfma_interleaved<NV, NL, NS><<<blocks, 256>>>(out, rnd, iters);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4 * iters * 16.0 * (2.0 * 32 * 32 * 2);
+  printf("interleaved per 16 MFMAs: %2d VALU %2d ds_read %2d SALU (%d waves/SIMD): %7.1f TFLOP/s\n", NV, NL, NS, blocks / 256, flops / ms * 1e-9);
+  (void)hipFree(out); (void)hipFree(rnd);
+}
+
 template <int NV, int NL, int NG, int NS>
 void run_mix(int blocks, int iters) {
   float *out, *rnd; long long* clk;
@@ -293,5 +351,15 @@ int main() {
   run_mix<0, 0, 4, 0>(cus * 3, 50000);
   run_mix<0, 0, 0, 16>(cus * 3, 50000);
   run_mix<8, 8, 2, 8>(cus * 3, 50000);
+  run_interleaved<8, 0, 0>(cus * 3, 50000);
+  run_interleaved<16, 0, 0>(cus * 3, 50000);
+  run_interleaved<32, 0, 0>(cus * 3, 50000);
+  run_interleaved<0, 8, 0>(cus * 3, 50000);
+  run_interleaved<0, 0, 16>(cus * 3, 50000);
+  run_interleaved<8, 8, 8>(cus * 3, 50000);
+  run_interleaved<16, 8, 16>(cus * 3, 50000);
+  run_interleaved<16, 8, 16>(cus * 1, 50000);
+  run_mix<16, 8, 0, 16>(cus * 3, 50000);
+  run_mix<16, 8, 0, 16>(cus * 1, 50000);
   return 0;
 }
