@@ -40,13 +40,14 @@ __device__ __forceinline__ float wn_sigmoid(float x) { return 1.0f / (1.0f + exp
 template <int NR>
 __device__ __forceinline__ void wn_gemm(f32x16 (&acc)[2][NR], const float4* __restrict__ wp4, long long abase0, long long abase1,
                                         bool two, int ksg_total, const float* tile, int row_len, int col0, int ktaps, int dil,
-                                        int nchunks, int hi) {
+                                        int nchunks, int hi, int ch_begin = 0) {
+  // channel chunks [ch_begin, nchunks) of the K dimension (the K-split kernel gives each wave half of them);
   // ping-pong fragment registers; the next group's requests are issued after the first k-step's MFMAs
   float4 a0[2], a1[2];
-  a0[0] = wp4[abase0];
-  a0[1] = wp4[abase1];
-  int ksg = 0;
-  for (int ch = 0; ch < nchunks; ++ch) {
+  int ksg = ch_begin * ktaps * (KC / 8);
+  a0[0] = wp4[abase0 + (long long)ksg * 64];
+  a0[1] = wp4[abase1 + (long long)ksg * 64];
+  for (int ch = ch_begin; ch < nchunks; ++ch) {
     const float* bp = tile + (ch * KC + hi) * row_len + col0;
     float b0[4][NR], b1[4][NR];
 #pragma unroll
@@ -250,6 +251,186 @@ __global__ void __launch_bounds__(512) wn_layer_fused_kernel(const WnArgs p) {
   }
 }
 
+// K-split variant for short inputs (one 32-column workgroup per CU at the headline config).  With one wave per row
+// pair a workgroup has H/32 = 6 waves on 4 SIMDs (2,2,1,1: the matrix pipes are 75 % used at best).  Here 2*npairs
+// waves run: wave (pi, kh) multiplies row pair pi over half kh of the input channels; partial accumulators are
+// exchanged through LDS so that each wave finishes HALF of the pair's outputs (gate: 8 of the 16 accumulator
+// registers; res_skip: kh=0 the residual tile, kh=1 the skip tile).  12 waves = 3 per SIMD, every phase balanced.
+__global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) {
+  constexpr int NR = 1;
+  constexpr int NA = 32;
+  constexpr int SU = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const XT = lds;      // x tile [H][xrow]; later aliased by the acts tile [H][arow]
+  float* const AT = lds;
+  const int H = p.H;
+  float* const RED = lds + H * max(p.xrow, p.arow);   // exchange area: [2*npairs waves][16][64]
+
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave >= p.npairs ? 1 : 0;                 // K half
+  const int pi = wave - kh * p.npairs;                     // row pair
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * NA;
+  const int chh = p.nchunks >> 1;                          // chunks per half (nchunks is even)
+  const int ch_lo = kh * chh, ch_hi = ch_lo + chh;
+  float* const red_mine = RED + (wave * 16) * 64 + lane;
+  float* const red_peer = RED + ((kh ? pi : pi + p.npairs) * 16) * 64 + lane;
+
+  // ---- stage the x tile: all H channels, columns [t0 + xoff0, +xrow), zero outside [0, T)
+  {
+    const int R4 = p.xrow >> 2;
+    const int total = H * R4;
+    const int xs_start = t0 + p.xoff0;
+    const float* xb = p.x + (long long)b * p.x_bs;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (p.x_ld & 3) == 0 && (p.x_bs & 3) == 0;
+    int wc = tid / R4, wg = tid - wc * R4;
+    const int dc = nthr / R4, dg = nthr - dc * R4;
+    for (int base = tid; base < total; base += nthr * SU) {
+      float4 v[SU];
+      const int wc_s = wc, wg_s = wg;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int c = min(wc, H - 1);
+        int t = xs_start + 4 * wg;
+        const float* row = xb + (long long)c * p.x_ld;
+        if (vec) {
+          t = (t >= 0 && t < p.T) ? t : 0;
+          v[u] = *reinterpret_cast<const float4*>(row + t);
+        } else {
+          v[u].x = (t >= 0 && t < p.T) ? row[t] : 0.f;
+          v[u].y = (t + 1 >= 0 && t + 1 < p.T) ? row[t + 1] : 0.f;
+          v[u].z = (t + 2 >= 0 && t + 2 < p.T) ? row[t + 2] : 0.f;
+          v[u].w = (t + 3 >= 0 && t + 3 < p.T) ? row[t + 3] : 0.f;
+        }
+        wc += dc; wg += dg;
+        if (wg >= R4) { wg -= R4; ++wc; }
+      }
+      int wc2 = wc_s, wg2 = wg_s;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (base + u * nthr < total) {
+          const int t = xs_start + 4 * wg2;
+          float4 q = v[u];
+          q.x = (t >= 0 && t < p.T) ? q.x : 0.f;
+          q.y = (t + 1 >= 0 && t + 1 < p.T) ? q.y : 0.f;
+          q.z = (t + 2 >= 0 && t + 2 < p.T) ? q.z : 0.f;
+          q.w = (t + 3 >= 0 && t + 3 < p.T) ? q.w : 0.f;
+          *reinterpret_cast<float4*>(XT + wc2 * p.xrow + 4 * wg2) = q;
+        }
+        wc2 += dc; wg2 += dg;
+        if (wg2 >= R4) { wg2 -= R4; ++wc2; }
+      }
+    }
+  }
+
+  // ---- phase A: in_layer rows (tanh tile 2*pi, sigmoid tile 2*pi+1), this wave's half of the input channels
+  f32x16 acc[2][NR];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      acc[h][0][i] = kh ? 0.f : p.bias1[(2 * pi + h) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+  __syncthreads();
+  {
+    const float4* wp4 = reinterpret_cast<const float4*>(p.wp1);
+    const long long ab0 = (long long)(2 * pi) * p.ksg1 * 64 + lane;
+    wn_gemm<NR>(acc, wp4, ab0, ab0 + (long long)p.ksg1 * 64, true, p.ksg1, XT, p.xrow, l31 - p.pad - p.xoff0, p.ktaps, p.dil,
+                ch_hi, hi, ch_lo);
+  }
+  // exchange: this wave finishes registers [8*kh, 8*kh+8) of both tiles and hands the other 8 to its peer
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red_mine[(h * 8 + q) * 64] = kh ? acc[h][0][q] : acc[h][0][8 + q];
+  __syncthreads();     // partials published; everybody is done reading the x tile -> its LDS is reused for acts
+  {
+    const float* gb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
+    const int m = l31;
+    const int t = min(t0 + m, p.T - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = kh * 8 + q;
+      const int chn = pi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float vA = (kh ? acc[0][0][8 + q] : acc[0][0][q]) + red_peer[q * 64];
+      float vB = (kh ? acc[1][0][8 + q] : acc[1][0][q]) + red_peer[(8 + q) * 64];
+      if (gb) {
+        vA += gb[(long long)chn * p.gadd_ld + (long long)t * p.gadd_ts];
+        vB += gb[(long long)(H + chn) * p.gadd_ld + (long long)t * p.gadd_ts];
+      }
+      AT[chn * p.arow + m] = tanhf(vA) * wn_sigmoid(vB);
+    }
+  }
+  // ---- phase B: res_skip 1x1 on the acts tile; tile pi = x part, tile npairs + pi = skip part (last layer: tile pi only)
+  const bool two = !p.last;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      acc[h][0][i] = (!kh && (h == 0 || two)) ? p.bias2[(h * p.npairs + pi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi] : 0.f;
+  __syncthreads();     // acts tile complete, exchange area free again
+  {
+    const float4* wp4 = reinterpret_cast<const float4*>(p.wp2);
+    const long long ab0 = (long long)pi * p.ksg2 * 64 + lane;
+    const long long ab1 = two ? (long long)(p.npairs + pi) * p.ksg2 * 64 + lane : ab0;
+    wn_gemm<NR>(acc, wp4, ab0, ab1, two, p.ksg2, AT, p.arow, l31, 1, 1, ch_hi, hi, ch_lo);
+  }
+  // exchange: kh=0 finishes tile 0 (residual part; on the last layer the only tile), kh=1 finishes tile 1 (skip part)
+  if (two) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red_mine[q * 64] = kh ? acc[0][0][q] : acc[1][0][q];
+  } else if (kh) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red_mine[q * 64] = acc[0][0][q];
+  }
+  __syncthreads();
+  float fin[16];
+  if (two || !kh) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) fin[q] = (kh ? acc[1][0][q] : acc[0][0][q]) + red_peer[q * 64];
+  }
+  // ---- epilogue (modules.py:168-175)
+  const int t = t0 + l31;
+  if (t >= p.T) return;
+  const float* mb = p.mask + (long long)b * p.mask_bs;
+  const float mk = mb[t];
+  const int row0 = pi * 32 + 4 * hi;
+  float* ob = p.out + (long long)b * p.out_bs + (long long)row0 * p.out_ld + t;
+  if (two) {
+    if (!kh) {         // x = (x + rs[:H]) * mask
+      const float* xr = p.x + (long long)b * p.x_bs + (long long)row0 * p.x_ld + t;
+      float* xw = p.xo + (long long)b * p.xo_bs + (long long)row0 * p.xo_ld + t;
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = xr[(long long)((r & 3) + 8 * (r >> 2)) * p.x_ld];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xw[(long long)((r & 3) + 8 * (r >> 2)) * p.xo_ld] = (rv[r] + fin[r]) * mk;
+    } else {           // out += rs[H:]
+      float ov[16];
+      if (!p.first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = p.first ? fin[r] : ov[r] + fin[r];
+    }
+  } else if (!kh) {    // last layer: out = (out + rs) * mask
+    float ov[16];
+    if (!p.first) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = p.first ? fin[r] : ov[r] + fin[r];
+      ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = v * mk;
+    }
+  }
+}
+
 // Returns 1 when the fused layer does not apply (caller runs in_layer and res_skip as two convolutions).
 int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H, const float* x, long long x_bs, int x_ld,
                           float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs, int out_ld, const float* mask,
@@ -278,7 +459,11 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   a.xoff0 = minoff & ~3;
   a.xrow = round_up(NA + maxoff - a.xoff0, 4);
   a.arow = NA + 1;
-  const size_t lds = (size_t)H * std::max(a.xrow, a.arow) * sizeof(float);
+  size_t lds = (size_t)H * std::max(a.xrow, a.arow) * sizeof(float);
+  // short inputs: 2*npairs waves per workgroup, K split in two halves (wn_layer_fused_ks_kernel)
+  static const bool ksplit_on = !(getenv("SVOC_WN_KSPLIT") && atoi(getenv("SVOC_WN_KSPLIT")) == 0);
+  const bool ksplit = ksplit_on && NR == 1 && (a.nchunks % 2) == 0 && 2 * npairs * 64 <= 768;
+  if (ksplit) lds += (size_t)2 * npairs * 16 * 64 * sizeof(float);
   if (lds > 160 * 1024) return 1;
   dim3 grid((T + NA - 1) / NA, 1, B);
   const double flops = (in_l.flops_per_col + rs_l.flops_per_col) * (double)B * (double)T;
@@ -286,10 +471,15 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "fusedWN H%-4d k%-2d d%-2d N%-7d B%-3d NA%d%s", H, in_l.ktaps, in_l.dil, T, B, NA, last ? " last" : "");
+    snprintf(d, sizeof(d), "fusedWN H%-4d k%-2d d%-2d N%-7d B%-3d NA%d%s%s", H, in_l.ktaps, in_l.dil, T, B, NA, ksplit ? " ksplit" : "", last ? " last" : "");
     prof_idx = prof_begin(st, d, flops);
   }
-  if (NR == 2) {
+  if (ksplit) {
+    auto kern = wn_layer_fused_ks_kernel;
+    static bool attr = false;
+    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(2 * npairs * 64), lds, st, a);
+  } else if (NR == 2) {
     auto kern = wn_layer_fused_kernel<2>;
     static bool attr = false;
     if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
