@@ -209,21 +209,23 @@ def main():
             "samples_per_s_per_gpu": value / world,
             "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "fp32 MFMA implicit-GEMM family: conv_mfma_kernel, resblock_fused_kernel, wn_layer_fused_kernel",
+                         "kernel": "fp32 MFMA implicit-GEMM family: conv_mfma_kernel, conv_group_kernel, resblock_fused_kernel, wn_layer_fused(_ks)_kernel",
                          "launches_per_step": stats["conv_launches"] / args.steps,
                          "flop_per_step": stats["conv_flops"] / args.steps,
                          "gpu_ms_per_step_rank0": gpu_ms / args.steps},
         }
         # HBM traffic of the same workload from PMC counters (collected offline with rocprofv3 --pmc in separate passes,
         # tools/pmc_traffic.py; counters cannot be read from inside this process)
-        tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
-        if os.path.isfile(tpath) and B == 16 and T == 512:
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+        if tfiles and B == 16 and T == 512:
             try:
-                tj = json.load(open(tpath))
-                res["roofline"]["traffic"] = tj["gemm_family_bytes_per_launch"]
-                res["roofline"]["traffic_unit"] = "bytes per GEMM-family launch (mean)"
-                res["roofline"]["traffic_bytes_per_step"] = tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"]
-                res["roofline"]["traffic_source"] = "profiles/r01_c_pmc_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*)"
+                tj = json.load(open(tfiles[-1]))
+                step_bytes = tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"]
+                res["roofline"]["traffic"] = step_bytes / max(1.0, res["roofline"]["launches_per_step"])
+                res["roofline"]["traffic_unit"] = "HBM bytes per convolution (mean over the launches_per_step convolutions of a step)"
+                res["roofline"]["traffic_bytes_per_step"] = step_bytes
+                res["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*)"
             except Exception:   # noqa: BLE001
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box into gpurun_out/evidence/ (copy what should be judged to profiles/).
+#   gpurun --timeout 2400 -- 'bash tools/collect_evidence.sh <tag>'
+TAG=${1:-r01_x}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/evidence
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+( cd $R && timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5 ) > $O/${TAG}_gpu_tests.txt
+( cd $R && python bench.py ) > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+STEPS=5; WARM=2
+rocprofv3 --kernel-trace --stats -d /tmp/kt --output-format csv -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
+python $R/tools/prof_summary.py /tmp/kt > $O/${TAG}_bench_kernel_trace_summary.txt
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/${TAG}_rocprofv3_kernel_stats.csv
+python $R/tools/timeline.py /tmp/kt 400 > $O/${TAG}_kernel_timeline_one_step.txt
+NK=$(head -1 $O/${TAG}_kernel_timeline_one_step.txt | sed 's/# \([0-9]*\) kernels.*/\1/')
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/pr --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d /tmp/pw --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/pmc_traffic.py /tmp/pr /tmp/pw $NK 2 > $O/${TAG}_pmc_hbm_traffic.json
+( cd $R && python tools/profile_infer.py 16 512 3 ) > $O/${TAG}_per_layer_event_profile.txt 2>&1
+( cd $R && python tools/latency_probe.py ) > $O/${TAG}_latency_by_shape.txt 2>&1
+( cd $R && tools/mfma_peak_probe ) > $O/${TAG}_mfma_peak_probe.txt 2>&1
+( cd $R && SVOC_STREAMS=0 python tools/clock_trace.py 16 512 3 ) > $O/${TAG}_shader_clock_trace.txt 2>&1
+ls -la $O
