@@ -165,6 +165,19 @@ int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T);
 int svoc_synth_hop(svoc_synth* h);         /* prod(upsample_rates) */
 void svoc_synth_destroy(svoc_synth* h);
 
+/* ---- models.PosteriorEncoder (models.py:83-112): not on the infer path; enc_q of training / voice conversion ---- */
+typedef struct svoc_posterior svoc_posterior;
+/* tensors: pre.{weight,bias}, enc.<WN tensors>, proj.{weight,bias} */
+int svoc_posterior_create(svoc_posterior** out, int in_channels, int out_channels, int hidden_channels, int kernel_size,
+                          int dilation_rate, int n_layers, int gin_channels, const svoc_tensor* tensors, int n_tensors,
+                          const char* prefix);
+/* forward(x, x_lengths, g) (models.py:105-112): x [B,in,T], lengths [B] int64, g NULL or [B,gin,Tg], eps [B,out,T] = the
+ * reference's torch.randn_like(m) draw; writes z = (m + eps*exp(logs))*mask, m, logs [B,out,T] and x_mask [B,1,T] (may be NULL) */
+int svoc_posterior_forward(svoc_posterior* h, void* stream, const float* x, const int64_t* lengths, const float* g, int g_T,
+                           const float* eps, float* z, float* m, float* logs, float* x_mask, int B, int T);
+void svoc_posterior_destroy(svoc_posterior* h);
+
+
 /* ---- modules.DDSConv (modules.py:70-108) ---------------------------------- */
 typedef struct svoc_dds svoc_dds;
 /* tensors: convs_sep.{i}.{weight,bias}, convs_1x1.{i}.{weight,bias}, norms_1.{i}.{gamma,beta}, norms_2.{i}.* */

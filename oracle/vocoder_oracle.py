@@ -104,6 +104,18 @@ def mel_encoder(sd, mel, lengths, prefix="enc_p."):
     return x, stats[:, :C], stats[:, C:], mask
 
 
+def posterior_encoder(sd, prefix, x, lengths, g, eps, *, hidden, kernel_size, dilation_rate, n_layers):
+    """reference models.py:105-112 (PosteriorEncoder.forward) with the randn_like draw replaced by eps."""
+    mask = sequence_mask(lengths, x.shape[2], x.dtype)
+    h = _conv(sd, prefix + "pre", x) * mask
+    h = wn(sd, prefix + "enc.", h, mask, g, hidden=hidden, kernel_size=kernel_size, dilation_rate=dilation_rate, n_layers=n_layers)
+    stats = _conv(sd, prefix + "proj", h) * mask
+    C = stats.shape[1] // 2
+    m, logs = stats[:, :C], stats[:, C:]
+    z = (m + eps * torch.exp(logs)) * mask
+    return z, m, logs, mask
+
+
 def coupling(sd, prefix, x, mask, g=None, *, reverse, hidden=192, kernel_size=5, dilation_rate=1, n_layers=8,
              mean_only=True):
     half = x.shape[1] // 2

@@ -74,6 +74,9 @@ SIGNATURES = {
     "svoc_synth_workspace_bytes": (_L, [_P, _I, _I]),
     "svoc_synth_hop": (_I, [_P]),
     "svoc_synth_destroy": (None, [_P]),
+    "svoc_posterior_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _I, _I, *_TAB, C.c_char_p]),
+    "svoc_posterior_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
+    "svoc_posterior_destroy": (None, [_P]),
     "svoc_dds_create": (_I, [C.POINTER(_P), _I, _I, _I, *_TAB, C.c_char_p]),
     "svoc_dds_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I]),
     "svoc_dds_destroy": (None, [_P]),

@@ -408,7 +408,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
             const float e = p.eps ? p.eps[(long long)b * p.eps_bs + (long long)chn * p.eps_ld + col] : 0.0f;
             if (o.y) o.y[yo] = m;
             if (p.y2) p.y2[yo] = lg;
-            if (p.y3) p.y3[yo] = m + e * expf(lg) * p.noise_scale;
+            if (p.y3) p.y3[yo] = (m + e * expf(lg) * p.noise_scale) * ((o.flags & F_OUTMASK) ? mk : 1.0f);   // F_OUTMASK: PosteriorEncoder's z
           } else {
             const float m = vA * mk, lg = vB * mk;
             const float x1 = o.res[(long long)b * o.res_bs + (long long)chn * o.res_ld + col];

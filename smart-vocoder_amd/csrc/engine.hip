@@ -563,6 +563,60 @@ struct Generator {
   }
 };
 
+// =================================================================== PosteriorEncoder (models.py:83-112)
+// Not on the infer path (training / voice conversion); built from the same kernels: pre 1x1 -> mask -> WN -> proj 1x1
+// with the (m, logs, z = (m + eps*exp(logs))*mask) epilogue.
+struct Posterior {
+  int Cin = 0, Cout = 0, H = 0;
+  PackedConv pre, proj;
+  WNStack enc;
+  DevBuf ws;
+
+  int create(int in_channels, int out_channels, int hidden, int k, int dr, int nl, int gin, const TensorTable& tab,
+             const std::string& prefix, hipStream_t st) {
+    if (in_channels <= 0 || out_channels <= 0 || hidden <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "posterior encoder: bad configuration");
+    Cin = in_channels; Cout = out_channels; H = hidden;
+    PackSpec ps{}; ps.Cin = Cin; ps.Cout = H; ps.K = 1;
+    SVOC_TRY(pack_conv_named(pre, ps, tab, prefix + "pre", st));
+    SVOC_TRY(enc.create(H, k, dr, nl, gin, tab, prefix + "enc.", st));
+    PackSpec pj{}; pj.Cin = H; pj.Cout = 2 * Cout; pj.K = 1; pj.paired = true;
+    SVOC_TRY(pack_conv_named(proj, pj, tab, prefix + "proj", st));
+    return SVOC_OK;
+  }
+
+  int forward(hipStream_t st, const float* x, const int64_t* lengths, const float* g, int g_T, const float* eps, float* z, float* m,
+              float* logs, float* x_mask, int B, int T) {
+    const int Tp = pad4(T);
+    const long long hper = (long long)H * Tp;
+    SVOC_TRY(ws.ensure((size_t)((2 * hper + Tp) * B) * sizeof(float)));
+    float* xe = ws.f();
+    float* eo = xe + hper * B;
+    float* mask = eo + hper * B;
+    SVOC_TRY(k_sequence_mask(st, lengths, mask, B, Tp));
+    {   // x = pre(x) * x_mask (models.py:107)
+      ConvArgs a = mk_args();
+      set_in(a, x, (long long)Cin * T, T, T);
+      a.Ncols = T; a.mask = mask; a.mask_bs = Tp;
+      set_out(a.out[0], xe, hper, Tp, H, F_OUTMASK);
+      SVOC_TRY(launch_conv(pre, a, B, st));
+    }
+    SVOC_TRY(enc.forward(st, xe, hper, Tp, mask, Tp, g, g_T, eo, hper, Tp, B, T));
+    {   // stats = proj(x) * x_mask; z = (m + eps * exp(logs)) * x_mask (models.py:109-111)
+      ConvArgs a = mk_args();
+      set_in(a, eo, hper, Tp, T);
+      a.Ncols = T; a.mask = mask; a.mask_bs = Tp;
+      a.mode = EPI_PROJ;
+      const long long ubs = (long long)Cout * T;
+      set_out(a.out[0], m, ubs, T, Cout, F_OUTMASK);
+      a.y2 = logs; a.y3 = z;
+      a.eps = eps; a.eps_bs = ubs; a.eps_ld = T; a.noise_scale = 1.0f;
+      SVOC_TRY(launch_conv(proj, a, B, st));
+    }
+    if (x_mask) SVOC_TRY(k_copy2d(st, mask, Tp, Tp, x_mask, T, T, B, 1, T, nullptr, 0));
+    return SVOC_OK;
+  }
+};
+
 // =================================================================== SynthesizerTrn.infer (models.py:331-339)
 struct Synth {
   svoc_synth_config cfg{};
@@ -649,6 +703,7 @@ struct svoc_coupling { Coupling m; };
 struct svoc_flow { Flow m; };
 struct svoc_generator { Generator m; };
 struct svoc_synth { Synth m; };
+struct svoc_posterior { Posterior m; };
 
 #define SVOC_GUARD_BEGIN try {
 #define SVOC_GUARD_END } catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
@@ -786,6 +841,28 @@ int svoc_synth_infer(svoc_synth* h, void* stream, const float* mel, const int64_
 int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T) { return h ? h->m.workspace_bytes(B, T) : 0; }
 int svoc_synth_hop(svoc_synth* h) { return h ? h->m.dec.hop : 0; }
 void svoc_synth_destroy(svoc_synth* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_posterior_create(svoc_posterior** out, int in_channels, int out_channels, int hidden_channels, int kernel_size,
+                          int dilation_rate, int n_layers, int gin_channels, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
+  if (!out || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_posterior_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_posterior> h(new svoc_posterior());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, tab,
+                       prefix ? prefix : "", nullptr));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_posterior_forward(svoc_posterior* h, void* stream, const float* x, const int64_t* lengths, const float* g, int g_T,
+                           const float* eps, float* z, float* m, float* logs, float* x_mask, int B, int T) {
+  if (!h || !x || !lengths || !eps || !z || !m || !logs || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_posterior_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  return h->m.forward(as_stream(stream), x, lengths, g, g_T, eps, z, m, logs, x_mask, B, T);
+  SVOC_GUARD_END
+}
+void svoc_posterior_destroy(svoc_posterior* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
 
 // ---- diagnostics: phase timing of one convolution launch (cycle stamps per workgroup)
 int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, const float* bias, const float* residual, float* y,

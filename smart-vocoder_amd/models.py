@@ -80,8 +80,12 @@ class ResidualCouplingBlock(_HipModule):
         return y
 
 
-class PosteriorEncoder(nn.Module):
-    """reference models.py:83-112 — training-only; kept so that ``enc_q.*`` stays in the state_dict."""
+class PosteriorEncoder(_HipModule):
+    """reference models.py:83-112 (enc_q of training / voice conversion; not part of ``infer``).
+
+    ``forward`` accepts one extra keyword, ``eps=``, to inject the N(0,1) draw the reference takes with
+    ``torch.randn_like(m)`` (models.py:111)."""
+    _destroy = "svoc_posterior_destroy"
 
     def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0):
         super().__init__()
@@ -96,8 +100,27 @@ class PosteriorEncoder(nn.Module):
         self.enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
         self.proj = _Conv1dParams(hidden_channels, out_channels * 2, 1)
 
-    def forward(self, x, x_lengths, g=None):
-        raise NotImplementedError("PosteriorEncoder is training-only and outside the inference path")
+    def _create(self, h, tab):
+        N.check(N.lib().svoc_posterior_create(h.out(), self.in_channels, self.out_channels, self.hidden_channels, self.kernel_size,
+                                              self.dilation_rate, self.n_layers, self.gin_channels, tab.arr, tab.n, b""))
+
+    def forward(self, x, x_lengths, g=None, eps=None):
+        x = N.f32(x)
+        B, Cc, T = x.shape
+        if Cc != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {Cc}")
+        lengths = x_lengths.to(device=x.device, dtype=torch.int64).contiguous()
+        g, gT = modules._g_args(g, T)
+        if eps is None:
+            eps = torch.randn(B, self.out_channels, T, device=x.device, dtype=torch.float32)
+        eps = N.f32(eps)
+        if tuple(eps.shape) != (B, self.out_channels, T):
+            raise ValueError(f"eps must be [{B}, {self.out_channels}, {T}], got {tuple(eps.shape)}")
+        z, m, logs = (torch.empty(B, self.out_channels, T, device=x.device, dtype=torch.float32) for _ in range(3))
+        x_mask = torch.empty(B, 1, T, device=x.device, dtype=torch.float32)
+        N.check(N.lib().svoc_posterior_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(lengths), N.ptr(g), gT,
+                                               N.ptr(eps), N.ptr(z), N.ptr(m), N.ptr(logs), N.ptr(x_mask), B, T))
+        return z, m, logs, x_mask
 
 
 def _gen_config(initial_channel, resblock, rks, rds, ur, uic, uks, gin):
@@ -286,6 +309,16 @@ class SynthesizerTrn(_HipModule):
             out[:, :, s * hop:e * hop] = o[:, :, (s - a) * hop:(e - a) * hop]
         return out
 
-    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
-        # the reference's implementation dereferences a non-existent self.emb_g (models.py:343)
-        raise AttributeError("'SynthesizerTrn' object has no attribute 'emb_g'")
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, eps=None):
+        """reference models.py:341-349.  The reference never creates ``emb_g`` (models.py:305-314), so as there this
+        raises AttributeError unless the caller attaches one (``net.emb_g = nn.Embedding(n_speakers, gin_channels)``)."""
+        assert self.n_speakers > 0, "n_speakers have to be larger than 0."
+        if not hasattr(self, "emb_g"):
+            raise AttributeError("'SynthesizerTrn' object has no attribute 'emb_g'")
+        g_src = self.emb_g(sid_src).unsqueeze(-1)
+        g_tgt = self.emb_g(sid_tgt).unsqueeze(-1)
+        z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g_src, eps=eps)
+        z_p = self.flow(z, y_mask, g=g_src)
+        z_hat = self.flow(z_p, y_mask, g=g_tgt, reverse=True)
+        o_hat = self.dec(z_hat * y_mask, g=g_tgt)
+        return o_hat, y_mask, (z, z_p, z_hat)

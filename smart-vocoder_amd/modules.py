@@ -76,15 +76,21 @@ class _WNConvTranspose1dParams(nn.Module):
 _STRUCT_EPOCH = [0]
 
 
+def _fold_tensor(weight_v, weight_g):
+    """w = g * v / ||v|| over all dims but 0 (torch.nn.utils.weight_norm, dim=0), on the device (HIP kernel)."""
+    v = N.f32(weight_v.detach())
+    g = N.f32(weight_g.detach())
+    w = torch.empty_like(v)
+    N.check(N.lib().svoc_fold_weight_norm(N.stream_ptr(v.device), N.ptr(v), N.ptr(g), N.ptr(w), v.shape[0],
+                                          v[0].numel()))
+    return w
+
+
 def _fold_in_place(m):
     """remove_weight_norm for one container: replace (weight_g, weight_v) by the folded `weight` (HIP kernel)."""
     if not hasattr(m, "weight_v"):
         return
-    v = N.f32(m.weight_v.detach())
-    g = N.f32(m.weight_g.detach())
-    w = torch.empty_like(v)
-    N.check(N.lib().svoc_fold_weight_norm(N.stream_ptr(v.device), N.ptr(v), N.ptr(g), N.ptr(w), v.shape[0],
-                                          v[0].numel()))
+    w = _fold_tensor(m.weight_v, m.weight_g)
     bias = m.bias
     del m.weight_g, m.weight_v, m.bias
     m.weight = nn.Parameter(w)     # key order after removal in the reference: bias, weight

@@ -96,6 +96,63 @@ def save_checkpoint(model, optimizer, learning_rate, iteration, checkpoint_path)
                 "learning_rate": learning_rate}, checkpoint_path)
 
 
+def remove_all_weight_norm(model):
+    """Fold every (weight_g, weight_v) pair of `model` into a plain `weight` on the device: the whole-model version of
+    Generator.remove_weight_norm / WN.remove_weight_norm / ResBlock*.remove_weight_norm (reference models.py:162-167,
+    modules.py:178-184, 225-229, 254-256).  The model must live on the GPU (the fold is a HIP kernel)."""
+    try:
+        from .modules import _fold_in_place
+    except ImportError:      # imported as a top-level module (drop-in mode, INTEGRATION.md section 1)
+        from modules import _fold_in_place
+    n = 0
+    for m in model.modules():
+        if "weight_v" in m._parameters and "weight_g" in m._parameters:
+            _fold_in_place(m)
+            n += 1
+    return n
+
+
+def folded_state_dict(model):
+    """state_dict of `model` as it would be after remove_all_weight_norm, computed without touching the model."""
+    try:
+        from .modules import _fold_tensor
+    except ImportError:
+        from modules import _fold_tensor
+    out, folded = {}, set()
+    for name, m in model.named_modules():
+        if "weight_v" in m._parameters and "weight_g" in m._parameters:
+            p = name + "." if name else ""
+            out[p + "weight"] = _fold_tensor(m.weight_v, m.weight_g)
+            folded.update((p + "weight_v", p + "weight_g"))
+    for k, v in model.state_dict().items():
+        if k not in folded:
+            out[k] = v
+    return out
+
+
+def export_folded(model, path, iteration=0):
+    """Folded-weight cache file: what the reference obtains by remove_weight_norm() + torch.save.
+    The source model is left untouched."""
+    target = model.module if hasattr(model, "module") else model
+    torch.save({"model_folded": {k: v.detach().cpu() for k, v in folded_state_dict(target).items()}, "iteration": iteration,
+                "format": "svoc-folded-1"}, path)
+    return path
+
+
+def load_folded(path, model):
+    """Load a file written by export_folded into `model` (on the GPU): the model's weight-norm pairs are folded first so
+    that the key sets agree; keys missing from the file keep the model's value, as in load_checkpoint."""
+    d = torch.load(path, map_location="cpu")
+    if d.get("format") != "svoc-folded-1":
+        raise ValueError(f"{path} is not a folded-weight file")
+    target = model.module if hasattr(model, "module") else model
+    remove_all_weight_norm(target)
+    saved = d["model_folded"]
+    new_sd = {k: (saved[k] if k in saved else v) for k, v in target.state_dict().items()}
+    target.load_state_dict(new_sd)
+    return model, d.get("iteration", 0)
+
+
 def latest_checkpoint_path(dir_path, regex="G_*.pth"):
     """reference utils.py:70-75: newest by the digits in the file name"""
     f_list = glob.glob(os.path.join(dir_path, regex))

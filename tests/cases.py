@@ -72,6 +72,10 @@ WN_CASES = {
     "wn_h192_k5_n3_g": dict(H=192, k=5, dr=1, n=3, gin=256, B=2, T=50, lengths=[50, 33], seed=5002),
     "wn_h64_k3_dr2_n4_g": dict(H=64, k=3, dr=2, n=4, gin=32, B=2, T=61, lengths=[61, 40], seed=5003),
 }
+POSTERIOR_CASES = {   # PosteriorEncoder(in, out, hidden, k, dr, n, gin) (models.py:83-112)
+    "posterior_small_g": dict(Cin=33, Cout=16, H=32, k=5, dr=1, n=3, gin=8, B=2, T=37, lengths=[37, 20], seed=5601),
+    "posterior_513_192": dict(Cin=513, Cout=192, H=192, k=5, dr=1, n=2, gin=0, B=2, T=24, lengths=[24, 9], seed=5602),
+}
 COUPLING_CASES = {
     "rcl_mean_rev": dict(C=192, H=192, k=5, dr=1, n=2, gin=0, mean_only=True, reverse=True, B=2, T=40,
                          lengths=[40, 23], seed=6001),
@@ -167,6 +171,14 @@ def resblock2_shapes(C, k, prefix=""):
 
 def ups_shapes(Ci, Co, k, prefix=""):
     return {prefix + "bias": (Co,), prefix + "weight_g": (Ci, 1, 1), prefix + "weight_v": (Ci, Co, k)}
+
+
+def posterior_shapes(Cin, Cout, H, k, n, gin, prefix=""):
+    d = {}
+    _conv(d, prefix + "pre", H, Cin, 1)
+    d.update(wn_shapes(H, k, n, gin, prefix + "enc."))
+    _conv(d, prefix + "proj", 2 * Cout, H, 1)
+    return d
 
 
 def coupling_shapes(C, H, k, n, gin, mean_only, prefix=""):

@@ -41,7 +41,12 @@ def load_synth(module, seed, gain=None):
     return module.eval()
 
 
+ONLY = sys.argv[1:]      # optional name filters: only fixtures whose name contains one of them are (re)written
+
+
 def save(name, **arrs):
+    if ONLY and not any(f in name for f in ONLY):
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KB  " + " ".join(f"{k}{tuple(np.shape(v))}" for k, v in arrs.items()))
@@ -100,6 +105,18 @@ for name, c in cases.WN_CASES.items():
     mask = T(cases.lengths_mask(c["lengths"], c["T"]))
     g = T(cases.rnd(c["seed"], "g", (c["B"], c["gin"], 1), 1.0)) if c["gin"] else None
     save(name, y=m(T(x) * mask, mask, g=g).numpy())
+
+for name, c in cases.POSTERIOR_CASES.items():
+    m = load_synth(ref_models.PosteriorEncoder(c["Cin"], c["Cout"], c["H"], c["k"], c["dr"], c["n"], gin_channels=c["gin"]), c["seed"])
+    x = cases.rnd(c["seed"], "x", (c["B"], c["Cin"], c["T"]), 1.0)
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["gin"], 1), 1.0)) if c["gin"] else None
+    lengths = torch.tensor(c["lengths"], dtype=torch.int64)
+    torch.manual_seed(c["seed"])
+    z, mq, logs, mask = m(T(x), lengths, g=g)
+    torch.manual_seed(c["seed"])
+    eps = torch.randn_like(mq)          # the draw forward() just took (its only RNG call, models.py:111)
+    assert torch.equal(z, (mq + eps * torch.exp(logs)) * mask)
+    save(name, z=z.numpy(), m=mq.numpy(), logs=logs.numpy(), mask=mask.numpy(), eps=eps.numpy())
 
 for name, c in cases.COUPLING_CASES.items():
     m = ref_modules.ResidualCouplingLayer(c["C"], c["H"], c["k"], c["dr"], c["n"], gin_channels=c["gin"],

@@ -137,6 +137,28 @@ def test_wn(M, name):
     check(name, y, cases.golden(name)["y"])
 
 
+@pytest.mark.parametrize("name", list(cases.POSTERIOR_CASES))
+def test_posterior_encoder(M, name):
+    c = cases.POSTERIOR_CASES[name]
+    sd = sw.fill_state_dict(cases.posterior_shapes(c["Cin"], c["Cout"], c["H"], c["k"], c["n"], c["gin"]), c["seed"])
+    m = load(M.models.PosteriorEncoder(c["Cin"], c["Cout"], c["H"], c["k"], c["dr"], c["n"], gin_channels=c["gin"]), sd)
+    gold = cases.golden(name)
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["Cin"], c["T"]), 1.0))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["gin"], 1), 1.0)) if c["gin"] else None
+    z, mq, logs, mask = m(x.cuda(), torch.tensor(c["lengths"]).cuda(), g=g.cuda() if g is not None else None, eps=T(gold["eps"]).cuda())
+    check(name + ".m", mq, gold["m"])
+    check(name + ".logs", logs, gold["logs"])
+    check(name + ".z", z, gold["z"], atol=5e-5)
+    assert np.array_equal(mask.cpu().numpy(), gold["mask"])
+
+
+def test_voice_conversion_needs_emb_g_like_the_reference(M):
+    # reference models.py:341-349 dereferences self.emb_g, which models.py:305-314 never creates
+    net = M.models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+    with pytest.raises(AttributeError):
+        net.voice_conversion(torch.zeros(1, 513, 8), torch.tensor([8]), torch.tensor([0]), torch.tensor([1]))
+
+
 @pytest.mark.parametrize("name", list(cases.COUPLING_CASES))
 def test_coupling(M, name):
     c = cases.COUPLING_CASES[name]
@@ -274,6 +296,49 @@ def test_infer_vs_reference_golden(M, net, name):
     rms, ref = float(np.sqrt((err ** 2).mean())), float(np.sqrt((g["o"] ** 2).mean()))
     print(f"{name}: waveform rms err {rms:.3e} (ref rms {ref:.3f}, rel {rms / ref:.2e}), max {np.abs(err).max():.3e}")
     assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)
+
+
+def test_voice_conversion_with_attached_emb_g(M):
+    """models.py:341-349 once an emb_g exists: enc_q -> flow(g_src) -> flow^-1(g_tgt) -> dec(g_tgt), against the oracle."""
+    sd = cases.full_model_weights(skip_enc_q=False)
+    n = M.models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+    n.load_state_dict({k: T(v) for k, v in sd.items()})
+    n.emb_g = torch.nn.Embedding(109, 256)
+    n.emb_g.weight.data.copy_(T(cases.rnd(31, "emb_g", (109, 256), 1.0)))
+    n = n.cuda().eval()
+    Bn, Tn = 2, 24
+    y = T(np.abs(cases.rnd(32, "spec", (Bn, 513, Tn), 1.0)))
+    ln = torch.tensor([24, 15])
+    eps = T(cases.rnd(33, "eps", (Bn, 192, Tn), 1.0))
+    src, tgt = torch.tensor([3, 77]), torch.tensor([50, 4])
+    o, mask, (z, z_p, z_hat) = n.voice_conversion(y.cuda(), ln.cuda(), src.cuda(), tgt.cuda(), eps=eps.cuda())
+    sdt = sdT(sd)
+    with torch.no_grad():
+        emb = T(cases.rnd(31, "emb_g", (109, 256), 1.0))
+        g_src, g_tgt = emb[src].unsqueeze(-1), emb[tgt].unsqueeze(-1)
+        rz, _, _, rmask = O.posterior_encoder(sdt, "enc_q.", y, ln, g_src, eps, hidden=192, kernel_size=5, dilation_rate=1, n_layers=16)
+        rzp = O.flow(sdt, rz, rmask, g_src, reverse=False)
+        rzh = O.flow(sdt, rzp, rmask, g_tgt, reverse=True)
+        ro = O.generator(sdt, rzh * rmask, g_tgt)
+    check("vc z", z, rz.numpy(), 5e-5, 1e-4); check("vc z_p", z_p, rzp.numpy(), 1e-4, 1e-4); check("vc z_hat", z_hat, rzh.numpy(), 2e-4, 2e-4)
+    err = (o.cpu() - ro).numpy()
+    rms, ref = float(np.sqrt((err ** 2).mean())), float(ro.pow(2).mean().sqrt())
+    assert rms <= 1e-3 and rms / ref <= 1e-3, (rms, rms / ref)
+
+
+def test_folded_weight_file_round_trip(M, net, tmp_path):
+    """export_folded -> load_folded into a fresh model gives the same waveform as the weight-normed model."""
+    from smart_vocoder_amd import utils
+    mel, ln, eps = cases.infer_inputs("ragged")
+    o_ref = net.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=0.667, eps=T(eps).cuda())[0]
+    nkeys = len(net.state_dict())
+    path = utils.export_folded(net, str(tmp_path / "G_folded.pth"), iteration=7)
+    assert len(net.state_dict()) == nkeys and any(k.endswith("weight_g") for k in net.state_dict())      # source untouched
+    fresh = M.models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL).cuda().eval()
+    _, it = utils.load_folded(path, fresh)
+    assert it == 7 and not any(k.endswith("weight_g") or k.endswith("weight_v") for k in fresh.state_dict())
+    o = fresh.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=0.667, eps=T(eps).cuda())[0]
+    assert (o - o_ref).abs().max().item() <= 1e-6
 
 
 def test_infer_batch_independence(M, net):

@@ -91,6 +91,21 @@ def test_wn(name):
     close(y, cases.golden(name)["y"], 4e-6)
 
 
+@pytest.mark.parametrize("name", list(cases.POSTERIOR_CASES))
+def test_posterior_encoder(name):
+    c = cases.POSTERIOR_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.posterior_shapes(c["Cin"], c["Cout"], c["H"], c["k"], c["n"], c["gin"]), c["seed"]))
+    gold = cases.golden(name)
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["Cin"], c["T"]), 1.0))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["gin"], 1), 1.0)) if c["gin"] else None
+    z, m, logs, mask = O.posterior_encoder(sd, "", x, torch.tensor(c["lengths"]), g, T(gold["eps"]), hidden=c["H"],
+                                           kernel_size=c["k"], dilation_rate=c["dr"], n_layers=c["n"])
+    close(m, gold["m"], 4e-6)
+    close(logs, gold["logs"], 4e-6)
+    close(z, gold["z"], 1e-5)
+    assert np.array_equal(mask.numpy(), gold["mask"])
+
+
 @pytest.mark.parametrize("name", list(cases.COUPLING_CASES))
 def test_coupling(name):
     c = cases.COUPLING_CASES[name]
