@@ -2,10 +2,10 @@
 //     y = c2( lrelu( c1( lrelu(x) ) ) ) + x          c1: k taps, dilation d;  c2: k taps, dilation 1
 // for the narrow decoder stages (C = 32, 64), where conv-by-conv execution is bound by HBM traffic (each conv
 // writes its full 268 MB output; the write path tops out at ~2.7 TB/s, profiles/r01_membw_probe.txt).  Here the
-// intermediate activation never leaves the CU: the raw x tile (all C channels, time tile + both halos) is staged
-// into LDS once, phase A computes c1 on N_A = WN*NR*32 columns and writes lrelu(.) (zeroed outside [0,L): c2's own
+// intermediate activation never leaves the CU: the x tile (all C channels, time tile + both halos) is staged into LDS
+// once, already leaky-relu'd (x is recovered from it for the residual: negative samples times 1/slope), phase A computes c1 on N_A = WN*NR*32 columns and writes lrelu(.) (zeroed outside [0,L): c2's own
 // zero padding) into a second LDS tile, phase B runs c2 on it for the N2 = N_A-(k-1) interior columns, and the
-// residual is read back from the staged raw tile.  HBM traffic per iteration: read x once + write y once
+// residual is read back from the staged tile.  HBM traffic per iteration: read x once + write y once
 // (was: 2 writes + 3 reads).  Same MFMA instruction, packed-weight streams and numerics as conv_mfma.hip.
 #include "svoc_internal.h"
 
@@ -91,7 +91,7 @@ template <int WM, int WN, int NR>
 __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs p) {
   constexpr int SU = 13;                                   // one batch of staging loads per thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const XT = lds;                                   // raw x tile  [C][xrow]
+  float* const XT = lds;                                   // lrelu(x) tile  [C][xrow]
   float* const YT = lds;                                   // lrelu(c1(.)) tile [C][yrow], ALIASES the x tile (see below)
 
   const int tid = threadIdx.x;
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
   const int t0 = blockIdx.x * p.n2;                        // first output sample of this tile
   const int h2 = p.pad2;
 
-  // ---- stage the raw x tile: all C channels, columns [t0 + xoff0, +xrow); zero outside [0, L)
+  // ---- stage the x tile: all C channels, columns [t0 + xoff0, +xrow); zero outside [0, L)
   {
     const int R4 = p.xrow >> 2;
     const int total = p.C * R4;
@@ -133,6 +133,12 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
           q.y = (t + 1 >= 0 && t + 1 < p.L) ? q.y : 0.f;
           q.z = (t + 2 >= 0 && t + 2 < p.L) ? q.z : 0.f;
           q.w = (t + 3 >= 0 && t + 3 < p.L) ? q.w : 0.f;
+          // the tile holds lrelu(x): c1 re-reads every element once per tap, activating at staging costs k times less
+          // vector ALU work beside the MFMAs; the residual recovers x from it (see below)
+          q.x = fmaxf(q.x, q.x * p.slope);
+          q.y = fmaxf(q.y, q.y * p.slope);
+          q.z = fmaxf(q.z, q.z * p.slope);
+          q.w = fmaxf(q.w, q.w * p.slope);
           *reinterpret_cast<float4*>(XT + wc2 * p.xrow + 4 * wg2) = q;
         }
         wc2 += dc; wg2 += dg;
@@ -150,13 +156,14 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
   __syncthreads();
   {
     const int col0 = wn * NR * 32 + l31 - h2 - p.pad1 - p.xoff0;
-    fused_gemm<NR, true>(acc, reinterpret_cast<const float4*>(p.wp1), (long long)mt * p.ksg1 * 64 + lane, p.ksg1, XT, p.xrow, col0,
+    fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp1), (long long)mt * p.ksg1 * 64 + lane, p.ksg1, XT, p.xrow, col0,
                          p.ktaps, p.dil1, p.nchunks, hi, p.slope);
   }
   // The x tile is now only needed for the residual: every wave pulls its own residual values into registers, then
   // (after a barrier) the same LDS region is overwritten with lrelu(c1(.)) as c2's B operand.  Halving the LDS
   // footprint doubles the number of resident workgroups.
   const int ncol0 = wn * NR * 32;
+  const float inv_slope = 1.0f / p.slope;
   float resv[NR][16];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
@@ -164,7 +171,12 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
     const int cidx = min(n - p.xoff0, p.xrow - 1);
     const float* rbase = XT + (mt * 32 + 4 * hi) * p.xrow + cidx;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) resv[nr][r] = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
+    for (int r = 0; r < 16; ++r) {
+      // x from lrelu(x): negative values were scaled by the slope (0.1: 1/slope = 10 exactly in fp32; the round trip
+      // x*0.1*10 differs from x by at most one ulp, 6e-8 relative, on negative samples only)
+      const float v = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
+      resv[nr][r] = v < 0.f ? v * inv_slope : v;
+    }
   }
   __syncthreads();
   // lrelu, zero outside [0, L) (c2 zero-pads ITS input)
@@ -190,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
   if (ncol0 >= p.n2 || t0 + ncol0 >= p.L) return;
   fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp2), (long long)mt * p.ksg2 * 64 + lane, p.ksg2, YT, p.yrow,
                         ncol0 + l31, p.ktaps, 1, p.nchunks, hi, 1.0f);
-  // ---- epilogue: + residual (raw x from LDS), sink flags, store
+  // ---- epilogue: + residual (x recovered from the LDS tile above), sink flags, store
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
     const int n = ncol0 + nr * 32 + l31;
