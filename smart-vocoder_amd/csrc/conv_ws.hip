@@ -4,13 +4,14 @@
 // Why: with identical workgroups the chip runs read -> MFMA -> write bulk-synchronously, and a
 // wave that both streams activations and consumes weight fragments serialises them on its single in-order
 // vmcnt queue.  Here one 8-wave workgroup per CU walks a list of output tiles and splits the roles:
-//   waves 0-3  consumers : LDS fragments -> v_mfma_f32_32x32x2_f32 -> fused epilogue stores (fire and forget);
-//                          bias lives in registers, the residual of the ResBlock fast path is prefetched during
-//                          the last channel chunk; no other vector-memory loads, so nothing queues behind stores
-//   waves 4-5  weight producers    : per (chunk, tap) sub-stage copy BM x 32 packed weights L2 -> LDS
-//   waves 6-7  activation producers: per 32-channel chunk copy the [32][BN+halo] tile HBM -> LDS
-//                                    (leaky-relu / mask / zero padding applied on the way), requested one chunk ahead
-// One s_barrier per sub-stage hands double-buffered LDS tiles from producers to consumers.
+//   waves 0-3  consumers : activation fragments from LDS, weight fragments straight from L2 (packed order, one
+//                          group ahead, ping-pong registers) -> v_mfma_f32_32x32x2_f32 -> fused epilogue stores
+//   waves 4-7  activation producers: wave 4+w owns the 32-channel chunks cc == w (mod 4): requests the
+//                          [32][BN+halo] tile three chunks ahead (branch-free clamped loads), holds it in registers
+//                          across two barriers and publishes it (leaky-relu / mask / zero padding applied on the way)
+//                          one chunk before it is consumed; 4-slot LDS ring
+// One raw s_barrier per chunk hands LDS tiles from producers to consumers.  conv_ws2_kernel (below) adds a second
+// consumer set.  Both are opt-in experiments (SVOC_WS=1 / 2): correct, at parity with conv_mfma.hip at best.
 #include "svoc_internal.h"
 
 #include <algorithm>

@@ -3,8 +3,9 @@
 // for the narrow decoder stages (C = 32, 64), where conv-by-conv execution is bound by HBM traffic (each conv
 // writes its full 268 MB output; the write path tops out at ~2.7 TB/s, profiles/r01_membw_probe.txt).  Here the
 // intermediate activation never leaves the CU: the x tile (all C channels, time tile + both halos) is staged into LDS
-// once, already leaky-relu'd (x is recovered from it for the residual: negative samples times 1/slope), phase A computes c1 on N_A = WN*NR*32 columns and writes lrelu(.) (zeroed outside [0,L): c2's own
-// zero padding) into a second LDS tile, phase B runs c2 on it for the N2 = N_A-(k-1) interior columns, and the
+// once, already leaky-relu'd (x is recovered from it for the residual: negative samples times 1/slope), phase A
+// computes c1 on N_A = WN*NR*32 columns and writes lrelu(.) (zeroed outside [0,L): c2's own zero padding) into a
+// second LDS tile, phase B runs c2 on it for the N2 = N_A-(k-1) interior columns, and the
 // residual is read back from the staged tile.  HBM traffic per iteration: read x once + write y once
 // (was: 2 writes + 3 reads).  Same MFMA instruction, packed-weight streams and numerics as conv_mfma.hip.
 #include "svoc_internal.h"

@@ -295,6 +295,79 @@ void run_mix(int blocks, int iters) {
   (void)hipFree(out); (void)hipFree(rnd); (void)hipFree(clk);
 }
 
+// Do the matrix pipe and the vector ALU of one SIMD run side by side?  Workgroups of 8 waves: waves 0-3 (one per SIMD)
+// issue only MFMAs, waves 4-7 (their SIMD partners) only v_fma_f32 / v_pk_fma_f32 on independent accumulators.
+// mode 0: MFMA waves only work, 1: VALU waves only, 2: both.  Rates are reported per kind.
+template <bool PACKED>
+__global__ void __launch_bounds__(512) mfma_valu_coexec(float* out, int iters, int mode, float a0) {
+  const int wave = threadIdx.x >> 6;
+  float s = 0.f;
+  if (wave < 4) {
+    if (mode == 1) return;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const float a = a0 + threadIdx.x * 1e-6f, b = 0.5f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int m = 0; m < 16; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m & 3], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += acc[i][j];
+  } else {
+    if (mode == 0) return;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    // per iteration 256 v_fma_f32 (or 128 v_pk_fma_f32) on 16 independent accumulators (pairs)
+    f2 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (f2){0.f, 0.f};
+    const f2 x = (f2){a0 + threadIdx.x * 1e-6f, a0 * 0.5f};
+    const f2 w = (f2){0.999f, 1.001f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (PACKED) {
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(w));
+          } else {
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].x) : "v"(x.x), "v"(w.x));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].y) : "v"(x.y), "v"(w.y));
+          }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i].x + acc[i].y;
+  }
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <bool PACKED>
+void run_coexec(int cus, int iters) {
+  float* out;
+  (void)hipMalloc(&out, 4);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int mode = 0; mode < 3; ++mode) {
+    mfma_valu_coexec<PACKED><<<cus, 512>>>(out, iters / 10, mode, 1e-3f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    mfma_valu_coexec<PACKED><<<cus, 512>>>(out, iters, mode, 1e-3f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double mf = (mode != 1) ? (double)cus * 4 * iters * 16.0 * (2.0 * 32 * 32 * 2) / ms * 1e-9 : 0.0;
+    const double vf = (mode != 0) ? (double)cus * 4 * iters * 256.0 * 64 * 2.0 / ms * 1e-9 : 0.0;
+    printf("coexec (%s, 1 MFMA wave + 1 VALU wave per SIMD) mode %s: %8.3f ms  MFMA %6.1f TFLOP/s  VALU %6.1f TFLOP/s\n",
+           PACKED ? "v_pk_fma_f32" : "v_fma_f32", mode == 0 ? "MFMA only" : mode == 1 ? "VALU only" : "both     ", ms, mf, vf);
+  }
+  (void)hipFree(out);
+}
+
 template <int NACC>
 void run(int blocks, int threads, int iters, const char* what) {
   float* out;
@@ -361,5 +434,7 @@ int main() {
   run_interleaved<16, 8, 16>(cus * 1, 50000);
   run_mix<16, 8, 0, 16>(cus * 3, 50000);
   run_mix<16, 8, 0, 16>(cus * 1, 50000);
+  run_coexec<false>(cus, 20000);
+  run_coexec<true>(cus, 20000);
   return 0;
 }
