@@ -68,6 +68,8 @@ int svoc_profile_enable(int on);
 int svoc_profile_report(char* buf, int buflen);
 /* Diagnostics: run lrelu->Conv1d(C->C,k,d)[+residual] twice with per-workgroup cycle stamps; out4 = mean cycles of
  * {staging of the first stage, MFMA (+later stages), epilogue} and the span of the last launch. */
+/* diagnostics: [workgroup][8] int64 device buffer for resblock_fused_kernel's phase cycle stamps (NULL = off) */
+int svoc_debug_set_stamp_buffer(void* buf);
 int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, const float* bias, const float* residual, float* y,
                            int B, int C, int L, int kernel_size, int dilation, double* out4);
 

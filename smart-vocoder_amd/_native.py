@@ -53,6 +53,7 @@ SIGNATURES = {
     "svoc_stats_get": (_I, [C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(_L)]),
     "svoc_profile_enable": (_I, [_I]),
     "svoc_profile_report": (_I, [C.c_char_p, _I]),
+    "svoc_debug_set_stamp_buffer": (_I, [_P]),
     "svoc_debug_conv_timing": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "svoc_wn_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, *_TAB, C.c_char_p]),
     "svoc_wn_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I]),

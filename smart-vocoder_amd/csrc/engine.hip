@@ -864,6 +864,10 @@ int svoc_posterior_forward(svoc_posterior* h, void* stream, const float* x, cons
 }
 void svoc_posterior_destroy(svoc_posterior* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
 
+// ---- diagnostics: device buffer ([workgroup][8] int64, zeroed by the caller) that resblock_fused_kernel fills with its
+// phase cycle stamps; NULL switches the stamps off
+int svoc_debug_set_stamp_buffer(void* buf) { set_debug_stamp_buffer(static_cast<long long*>(buf)); return SVOC_OK; }
+
 // ---- diagnostics: phase timing of one convolution launch (cycle stamps per workgroup)
 int svoc_debug_conv_timing(void* stream, const float* x, const float* weight, const float* bias, const float* residual, float* y,
                            int B, int C, int L, int kernel_size, int dilation, double* out4) {

@@ -9,6 +9,12 @@
 
 namespace svoc {
 
+// diagnostics: kernels that support phase stamps write them here when set (svoc_debug_set_stamp_buffer)
+static long long* g_stamp_buffer = nullptr;
+long long* debug_stamp_buffer() { return g_stamp_buffer; }
+void set_debug_stamp_buffer(long long* p) { g_stamp_buffer = p; }
+
+
 // ------------------------------------------------------------------ errors / stats
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {

@@ -26,6 +26,7 @@ struct FusedArgs {
   float* y; long long y_bs; int y_ld; unsigned flags; float div;
   int n2; int xoff0; int xrow; int yrow;
   float slope;
+  long long* dbg;            // optional [nblocks][8] cycle stamps (svoc_debug_set_stamp_buffer)
 };
 
 __device__ __forceinline__ float fz_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
@@ -103,6 +104,8 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
   const int b = blockIdx.z;
   const int t0 = blockIdx.x * p.n2;                        // first output sample of this tile
   const int h2 = p.pad2;
+  long long ts[6] = {0, 0, 0, 0, 0, 0};
+  if (p.dbg) ts[0] = __builtin_readcyclecounter();
 
   // ---- stage the x tile: all C channels, columns [t0 + xoff0, +xrow); zero outside [0, L)
   {
@@ -155,6 +158,7 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias1[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
   __syncthreads();
+  if (p.dbg) ts[1] = __builtin_readcyclecounter();
   {
     const int col0 = wn * NR * 32 + l31 - h2 - p.pad1 - p.xoff0;
     fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp1), (long long)mt * p.ksg1 * 64 + lane, p.ksg1, XT, p.xrow, col0,
@@ -163,6 +167,7 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
   // The x tile is now only needed for the residual: every wave pulls its own residual values into registers, then
   // (after a barrier) the same LDS region is overwritten with lrelu(c1(.)) as c2's B operand.  Halving the LDS
   // footprint doubles the number of resident workgroups.
+  if (p.dbg) ts[2] = __builtin_readcyclecounter();
   const int ncol0 = wn * NR * 32;
   const float inv_slope = 1.0f / p.slope;
   float resv[NR][16];
@@ -200,9 +205,11 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias2[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
   __syncthreads();
+  if (p.dbg) ts[3] = __builtin_readcyclecounter();
   if (ncol0 >= p.n2 || t0 + ncol0 >= p.L) return;
   fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp2), (long long)mt * p.ksg2 * 64 + lane, p.ksg2, YT, p.yrow,
                         ncol0 + l31, p.ktaps, 1, p.nchunks, hi, 1.0f);
+  if (p.dbg) ts[4] = __builtin_readcyclecounter();
   // ---- epilogue: + residual (x recovered from the LDS tile above), sink flags, store
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
@@ -222,6 +229,187 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
       if (p.flags & F_ACC) v = yo[r] + v;
       if (p.flags & F_DIV) v = v / p.div;
       ybase[(long long)lr * p.y_ld] = v;
+    }
+  }
+  if (p.dbg && threadIdx.x == 0) {
+    ts[5] = __builtin_readcyclecounter();
+    long long* d = p.dbg + 8 * (blockIdx.x + (long long)gridDim.x * blockIdx.z);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = ts[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent variant with loader waves.  Phase stamps of the kernel above (tools/fused_phases.py) show the staging
+// phase taking 19-40 % of a workgroup's life although it moves only 35-48 KB: co-resident workgroups run in lock
+// step, so every CU requests its tiles at the same moment and the chip alternates between an HBM burst and an MFMA
+// phase with idle HBM.  Here a workgroup has 4 MFMA waves (same code as above) plus 4 loader waves and walks a list
+// of tiles: the loaders request tile i+1 right after publishing tile i and hold it in registers (12-13 float4 per
+// lane) while the MFMA waves run both GEMMs of tile i, then write it (zero padding + leaky-relu) into the LDS tile
+// as soon as c2 has finished reading it.  Requests are spread over the whole compute time and never sit in the MFMA
+// waves' in-order vmcnt queue.  Barriers are raw s_barrier (a fence would drain the loaders' requests and the MFMA
+// waves' output stores).  MEASURED: correct on the parity suite, but per-CU throughput equals the kernel above
+// (C=64: k=3 0.60 vs 0.59 ms, k=11 1.80 vs 1.75 ms): with two workgroups per CU only two MFMA waves share a SIMD and
+// the exchange / epilogue phases are no longer covered by a third and fourth workgroup.  Opt-in (SVOC_FUSE_WS=1).
+__device__ __forceinline__ void fz_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int WM, int WN, int NR, int XREG>
+__global__ void __launch_bounds__(512, 4) resblock_fused_ws_kernel(const FusedArgs p, const int ntn, const int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const XT = lds;
+  float* const YT = lds;                                   // aliases the x tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h2 = p.pad2;
+  const int ntl = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup (>= 1)
+
+  if (wave >= 4) {
+    // ===================================================================== loader waves
+    const int pl = tid - 256;                              // 0..255
+    const int R4 = p.xrow >> 2;
+    const int total = p.C * R4;
+    const int wc0 = pl / R4, wg0 = pl - wc0 * R4;
+    const int dc = 256 / R4, dg = 256 - dc * R4;
+    float4 v[XREG];
+    auto issue = [&](int tile, float4(&vv)[XREG]) {
+      const int b = tile / ntn;
+      const int xs_start = (tile - b * ntn) * p.n2 + p.xoff0;
+      const float* xb = p.x + (long long)b * p.x_bs;
+      int wc = wc0, wg = wg0;
+#pragma unroll
+      for (int u = 0; u < XREG; ++u) {
+        const int c = min(wc, p.C - 1);
+        int t = xs_start + 4 * wg;
+        t = (t >= 0 && t < p.L) ? t : 0;
+        vv[u] = *reinterpret_cast<const float4*>(xb + (long long)c * p.x_ld + t);
+        wc += dc; wg += dg;
+        if (wg >= R4) { wg -= R4; ++wc; }
+      }
+    };
+    auto publish = [&](int tile, const float4(&vv)[XREG]) {
+      const int b = tile / ntn;
+      const int xs_start = (tile - b * ntn) * p.n2 + p.xoff0;
+      int wc = wc0, wg = wg0;
+#pragma unroll
+      for (int u = 0; u < XREG; ++u) {
+        if (pl + u * 256 < total) {
+          const int t = xs_start + 4 * wg;
+          float4 q = vv[u];
+          q.x = (t >= 0 && t < p.L) ? q.x : 0.f;
+          q.y = (t + 1 >= 0 && t + 1 < p.L) ? q.y : 0.f;
+          q.z = (t + 2 >= 0 && t + 2 < p.L) ? q.z : 0.f;
+          q.w = (t + 3 >= 0 && t + 3 < p.L) ? q.w : 0.f;
+          q.x = fmaxf(q.x, q.x * p.slope);
+          q.y = fmaxf(q.y, q.y * p.slope);
+          q.z = fmaxf(q.z, q.z * p.slope);
+          q.w = fmaxf(q.w, q.w * p.slope);
+          *reinterpret_cast<float4*>(XT + wc * p.xrow + 4 * wg) = q;
+        }
+        wc += dc; wg += dg;
+        if (wg >= R4) { wg -= R4; ++wc; }
+      }
+    };
+    int tile = blockIdx.x;
+    issue(tile, v);
+    for (int j = 0; j < ntl; ++j) {
+      publish(tile, v);                                    // waits for the requests of this tile
+      fz_barrier();                                        // S1: x tile ready
+      tile += gridDim.x;
+      if (j + 1 < ntl) issue(tile, v);                     // in flight until the next publish
+      fz_barrier();                                        // S2: c1 done, residual pulled
+      fz_barrier();                                        // S3: activation tile written
+      fz_barrier();                                        // S4: c2 done -> the LDS tile may be overwritten
+    }
+    return;
+  }
+
+  // ======================================================================= MFMA waves
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int mt_ = wm;
+  const int ncol0_ = wn * NR * 32;
+  const float inv_slope = 1.0f / p.slope;
+  f32x16 acc[NR];
+  int tile = blockIdx.x;
+  for (int j = 0; j < ntl; ++j, tile += gridDim.x) {
+    const int b = tile / ntn;
+    const int t0 = (tile - b * ntn) * p.n2;
+    int opq = 0;
+    asm volatile("" : "+s"(opq));      // opaque zero: keeps tile-invariant loads (bias) and the ~80 tile-invariant LDS /
+    const int mt = mt_ + opq;          // global address registers of the exchange and the epilogue inside the loop
+    const int ncol0 = ncol0_ + opq;    // (hoisted, they push the kernel past the 128 registers two workgroups need)
+    // ---- phase A: c1 on columns m in [0, NA) <-> global time t0 - h2 + m
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias1[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+    fz_barrier();                                          // S1
+    {
+      const int col0 = ncol0 + l31 - h2 - p.pad1 - p.xoff0;
+      fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp1), (long long)mt * p.ksg1 * 64 + lane, p.ksg1, XT, p.xrow, col0,
+                            p.ktaps, p.dil1, p.nchunks, hi, p.slope);
+    }
+    float resv[NR][16];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      const int n = ncol0 + nr * 32 + l31;
+      const int cidx = min(n - p.xoff0, p.xrow - 1);
+      const float* rbase = XT + (mt * 32 + 4 * hi) * p.xrow + cidx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
+        resv[nr][r] = v < 0.f ? v * inv_slope : v;
+      }
+    }
+    fz_barrier();                                          // S2
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      const int m = ncol0 + nr * 32 + l31;
+      const int tA = t0 - h2 + m;
+      const bool ok = tA >= 0 && tA < p.L;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float v = acc[nr][r];
+        v = fmaxf(v, v * p.slope);
+        YT[row * p.yrow + m] = ok ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias2[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+    fz_barrier();                                          // S3
+    const bool live = !(ncol0 >= p.n2 || t0 + ncol0 >= p.L);
+    if (live)
+      fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp2), (long long)mt * p.ksg2 * 64 + lane, p.ksg2, YT, p.yrow,
+                            ncol0 + l31, p.ktaps, 1, p.nchunks, hi, 1.0f);
+    fz_barrier();                                          // S4: the loaders may overwrite the tile while the stores go out
+    if (!live) continue;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      const int n = ncol0 + nr * 32 + l31;
+      const int t = t0 + n;
+      if (n >= p.n2 || t >= p.L) continue;
+      float* ybase = p.y + (long long)b * p.y_bs + (long long)(mt * 32 + 4 * hi) * p.y_ld + t;
+      float yo[16];
+      if (p.flags & F_ACC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2);
+        float v = acc[nr][r] + resv[nr][r];
+        if (p.flags & F_ACC) v = yo[r] + v;
+        if (p.flags & F_DIV) v = v / p.div;
+        ybase[(long long)lr * p.y_ld] = v;
+      }
     }
   }
 }
@@ -251,6 +439,7 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
   a.xrow = round_up(std::max(last_col + 1, a.n2 - a.xoff0), 4);
   a.yrow = round_up(NA + k - 1, 4) + 1;                                // odd stride: both half-waves hit distinct banks
   a.slope = 0.1f;
+  a.dbg = debug_stamp_buffer();
   const size_t lds = (size_t)C * std::max(a.xrow, a.yrow) * sizeof(float);
   if (lds > 160 * 1024) return 1;
   const int ntn = (L + a.n2 - 1) / a.n2;
@@ -262,7 +451,27 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
     snprintf(d, sizeof(d), "fusedRB C%-4d k%-2d d%-2d N%-7d B%-3d NA%d", C, k, c1.dil, L, B, NA);
     prof_idx = prof_begin(st, d, (c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L);
   }
-  if (C == 32) {
+  static const int ncu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  static const bool ws_on = getenv("SVOC_FUSE_WS") && atoi(getenv("SVOC_FUSE_WS")) != 0;   // opt-in: measured at parity
+  const long long total_tiles = (long long)ntn * B;
+  const int xslots = (C * (a.xrow / 4) + 255) / 256;        // float4 per loader lane
+  // persistent loader-wave variant: two 8-wave workgroups per CU, needs enough tiles to pipeline and the tile in 10/12 float4 per loader lane
+  const bool use_ws = ws_on && total_tiles >= 8LL * ncu && total_tiles < 0x7fffffffLL && xslots <= (C == 32 ? 10 : 12) && 2 * lds <= 160 * 1024;
+  if (use_ws) {
+    const int gx = (int)std::min<long long>(total_tiles, 2LL * ncu);
+    a.dbg = nullptr;
+    if (C == 32) {
+      auto kern = resblock_fused_ws_kernel<1, 4, 2, 10>;
+      static bool attr = false;
+      if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, a, ntn, (int)total_tiles);
+    } else {
+      auto kern = resblock_fused_ws_kernel<2, 2, 2, 12>;
+      static bool attr = false;
+      if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, a, ntn, (int)total_tiles);
+    }
+  } else if (C == 32) {
     auto kern = resblock_fused_kernel<1, 4, 2>;
     static bool attr = false;
     if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }

@@ -136,6 +136,8 @@ int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream
 int launch_conv_ws2(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);  // two consumer sets; 1 = not eligible
 
 // resblock_fused.hip: one ResBlock1 iteration (c1 -> lrelu -> c2 -> + x) in one kernel; returns 1 when not eligible
+void set_debug_stamp_buffer(long long* p);
+long long* debug_stamp_buffer();   // misc_kernels.hip: device buffer for per-workgroup cycle stamps, or nullptr
 int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const float* x, long long x_bs, int x_ld, float* y,
                           long long y_bs, int y_ld, unsigned flags, float div, int B, int L, hipStream_t st);
 
