@@ -439,8 +439,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
 
 template <int WM, int WN, int MR, int NR>
 __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma_kernel(const ConvArgs p) {
-  conv_tile<WM, WN, MR, NR>(p, blockIdx.x, blockIdx.y, blockIdx.z,
-                            blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z));
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int tl = xcd_linear(lin, gridDim.x * gridDim.y * gridDim.z, p.xcd);
+  const int t = tl / (int)gridDim.x;
+  const int bz = t / (int)gridDim.y;
+  conv_tile<WM, WN, MR, NR>(p, tl - t * (int)gridDim.x, t - bz * (int)gridDim.y, bz, lin);
 }
 
 // Several independent convolutions of one tile shape in ONE launch (the three MRF chains' step-i convolutions):
@@ -452,8 +455,9 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_grou
   int pi = 0;
   if (lin >= g.end[0]) pi = 1;
   if (lin >= g.end[1]) pi = 2;
-  const int local = lin - (pi == 0 ? 0 : g.end[pi - 1]);
+  const int first = pi == 0 ? 0 : g.end[pi - 1];
   const ConvArgs& p = g.a[pi];
+  const int local = xcd_linear(lin - first, g.end[pi] - first, p.xcd);
   const int t = local / p.ntn;
   const int bz = t / p.gy;
   conv_tile<WM, WN, MR, NR>(p, local - t * p.ntn, t - bz * p.gy, bz, lin);
@@ -506,6 +510,7 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
   a.ups_s = pc.ups_s;
   a.ups_pad = pc.ups_pad;
   a.vec4 = ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_ld & 3) == 0 && (a.x_bs & 3) == 0) ? 1 : 0;
+  a.xcd = xcd_mapping_enabled();
   if (a.mode == EPI_UPS) {
     const EpiOut& o = a.out[0];
     if (pc.ups_s == 8 && (pc.ups_pad & 3) == 0 && (reinterpret_cast<uintptr_t>(o.y) & 15) == 0 && (o.y_ld & 3) == 0 &&
@@ -621,7 +626,6 @@ int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, i
     flops += pcs[i]->flops_per_col * (double)B * (double)g.a[i].Ncols;
   }
   for (int i = n; i < 3; ++i) g.end[i] = 0x7fffffff;
-  if (n == 2) g.end[1] = 0x7fffffff;
   if (lds > 160 * 1024) return 1;
   for (int i = 0; i < n; ++i) stats_add_conv(pcs[i]->flops_per_col * (double)B * (double)g.a[i].Ncols);
   int prof_idx = -1;

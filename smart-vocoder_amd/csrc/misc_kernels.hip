@@ -1,6 +1,8 @@
 // Small memory-bound kernels of the inference path (everything that is not a convolution GEMM).
 #include "svoc_internal.h"
 
+#include <cstdlib>
+
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -10,6 +12,11 @@
 namespace svoc {
 
 // diagnostics: kernels that support phase stamps write them here when set (svoc_debug_set_stamp_buffer)
+int xcd_mapping_enabled() {
+  static const int on = !(getenv("SVOC_XCD") && atoi(getenv("SVOC_XCD")) == 0);
+  return on;
+}
+
 static long long* g_stamp_buffer = nullptr;
 long long* debug_stamp_buffer() { return g_stamp_buffer; }
 void set_debug_stamp_buffer(long long* p) { g_stamp_buffer = p; }

@@ -26,6 +26,7 @@ struct FusedArgs {
   float* y; long long y_bs; int y_ld; unsigned flags; float div;
   int n2; int xoff0; int xrow; int yrow;
   float slope;
+  int xcd;                   // XCD-aware tile order (svoc_internal.h xcd_linear)
   long long* dbg;            // optional [nblocks][8] cycle stamps (svoc_debug_set_stamp_buffer)
 };
 
@@ -101,8 +102,9 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.x * p.n2;                        // first output sample of this tile
+  const int tl = xcd_linear(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z, p.xcd);
+  const int b = tl / (int)gridDim.x;
+  const int t0 = (tl - b * (int)gridDim.x) * p.n2;         // first output sample of this tile
   const int h2 = p.pad2;
   long long ts[6] = {0, 0, 0, 0, 0, 0};
   if (p.dbg) ts[0] = __builtin_readcyclecounter();
@@ -439,6 +441,7 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
   a.xrow = round_up(std::max(last_col + 1, a.n2 - a.xoff0), 4);
   a.yrow = round_up(NA + k - 1, 4) + 1;                                // odd stride: both half-waves hit distinct banks
   a.slope = 0.1f;
+  a.xcd = xcd_mapping_enabled();
   a.dbg = debug_stamp_buffer();
   const size_t lds = (size_t)C * std::max(a.xrow, a.yrow) * sizeof(float);
   if (lds > 160 * 1024) return 1;

@@ -74,6 +74,7 @@ struct ConvArgs {
   const float* in_mask; long long in_mask_bs;      // optional multiplier [B][>=Lin], applied after the activation
   float pre_slope;                                   // leaky-relu slope applied while staging (1 = none)
   int vec4;                                          // 1: rows are 16-byte aligned -> float4 staging loads
+  int xcd;                                           // 1: XCD-aware tile order (xcd_linear)
   // packed weights / bias
   const float* wp; const float* bias;
   int nchunks; int kcs; int ktaps; int dil; int pad;   // kcs: channels staged per round trip (multiple of 32);          // tap j reads x[n + j*dil - pad]
@@ -129,6 +130,22 @@ int fold_weight_norm(hipStream_t st, const float* v, const float* g, float* w, l
 
 // Fills geometry fields (wp, bias, taps, tiles, LDS tile) of `a` from `pc`; caller sets x/epilogue fields first.
 int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st);
+
+// XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2:
+// in the natural order the time tiles t and t+1 (which share a (k-1)*dilation halo of up to 45 % of a tile) and the
+// row blocks of one tile (which share the whole input tile) always land on different XCDs and are fetched from HBM
+// once per XCD.  xcd_linear() turns workgroup id `lin` of `total` into a tile id such that XCD c walks the
+// contiguous range [start(c), start(c+1)): neighbours are issued back to back on the same L2.  Bijective for any
+// total.  on = 0 keeps the natural order (SVOC_XCD=0, for A/B runs).
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_linear(int lin, int total, int on) {
+  if (!on) return lin;
+  const int c = lin & 7, i = lin >> 3;
+  const int q = total >> 3, r = total & 7;
+  return c * q + min(c, r) + i;
+}
+#endif
+int xcd_mapping_enabled();   // misc_kernels.hip
 
 struct ConvGroup { ConvArgs a[3]; int end[3]; };     // conv_group_kernel: end[i] = first workgroup id after problem i
 int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, int B, hipStream_t st);   // 1 = not eligible
