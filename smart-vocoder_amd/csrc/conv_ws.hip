@@ -82,14 +82,23 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& p, f32x16 (&acc)[MR]
 #pragma unroll
             for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * oy_ld];
           }
+          float vo[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[mr][nr][r];
             if (fl & F_RES) v = v + rv[r];
             if (fl & F_ACC) v = yo[r] + v;
-            if (fl & F_DIV) v = v / odiv;
-            ybase[(long long)((r & 3) + 8 * (r >> 2)) * oy_ld] = v;
+            vo[r] = v;
           }
+          // one uniform branch around all 16 divisions: inside the loop the compiler turns `if (flag) v /= d` into
+          // an unconditional IEEE division sequence (~12 vector instructions per value) plus a select
+          if (fl & F_DIV) {
+            asm volatile("" ::: "memory");     // not speculatable: keeps the branch
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vo[r] = vo[r] / odiv;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ybase[(long long)((r & 3) + 8 * (r >> 2)) * oy_ld] = vo[r];
         }
         continue;
       }

@@ -224,14 +224,20 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld];
     }
+    float vo[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int lr = (r & 3) + 8 * (r >> 2);
       float v = acc[nr][r] + resv[nr][r];
       if (p.flags & F_ACC) v = yo[r] + v;
-      if (p.flags & F_DIV) v = v / p.div;
-      ybase[(long long)lr * p.y_ld] = v;
+      vo[r] = v;
     }
+    if (p.flags & F_DIV) {          // one uniform branch: see conv_mfma.hip (an in-loop `if` becomes 16 unconditional divisions)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vo[r] = vo[r] / p.div;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld] = vo[r];
   }
   if (p.dbg && threadIdx.x == 0) {
     ts[5] = __builtin_readcyclecounter();
@@ -404,14 +410,20 @@ __global__ void __launch_bounds__(512, 4) resblock_fused_ws_kernel(const FusedAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld];
       }
+      float vo[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int lr = (r & 3) + 8 * (r >> 2);
         float v = acc[nr][r] + resv[nr][r];
         if (p.flags & F_ACC) v = yo[r] + v;
-        if (p.flags & F_DIV) v = v / p.div;
-        ybase[(long long)lr * p.y_ld] = v;
+        vo[r] = v;
       }
+      if (p.flags & F_DIV) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vo[r] = vo[r] / p.div;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld] = vo[r];
     }
   }
 }
