@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
       // x from lrelu(x): negative values were scaled by the slope (0.1: 1/slope = 10 exactly in fp32; the round trip
       // x*0.1*10 differs from x by at most one ulp, 6e-8 relative, on negative samples only)
       const float v = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
-      resv[nr][r] = v < 0.f ? v * inv_slope : v;
+      resv[nr][r] = fminf(v, v * inv_slope);      // inv_slope > 1: min picks v*inv_slope for v < 0, v otherwise
     }
   }
   __syncthreads();
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(512, 4) resblock_fused_ws_kernel(const FusedAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
-        resv[nr][r] = v < 0.f ? v * inv_slope : v;
+        resv[nr][r] = fminf(v, v * inv_slope);      // inv_slope > 1: min picks v*inv_slope for v < 0, v otherwise
       }
     }
     fz_barrier();                                          // S2
