@@ -89,6 +89,38 @@ def test_conv1d(M, C, k, d, L, B, res):
     check(f"conv1d C{C} k{k} d{d}", y, ref)
 
 
+def test_conv1d_random_shapes(M):
+    """Seeded sweep over odd shapes: channel counts that are not multiples of 32, every tile configuration (many / few
+    columns), large dilations (wide LDS rows), lengths that leave ragged last tiles and workgroup totals that are not
+    multiples of 8 (XCD remap), against torch's CPU conv1d."""
+    import ctypes
+    rng = np.random.default_rng(20260928)
+    N = M.native
+    for it in range(28):
+        C = int(rng.choice([1, 7, 32, 33, 64, 96, 100, 128, 160, 256]))
+        co = int(rng.choice([1, 5, 32, 48, 64, 128, 130, 256]))
+        k = int(rng.choice([1, 3, 5, 7, 11, 13]))
+        d = int(rng.choice([1, 2, 3, 5, 9]))
+        L = int(rng.choice([1, 2, 31, 64, 129, 500, 1023, 4100]))
+        B = int(rng.choice([1, 2, 3, 5]))
+        slope = float(rng.choice([1.0, 0.1, 0.01]))
+        res = bool(rng.integers(0, 2)) and co == C
+        seed = 9000 + it
+        v = T(cases.rnd(seed, "v", (co, C, k), 1.0 / np.sqrt(C * k)))
+        g = T((0.5 + sw.uniform01(seed, "g", co)).astype(np.float32)).reshape(co, 1, 1)
+        bias = T(cases.rnd(seed, "b", (co,), 0.1))
+        x = T(cases.rnd(seed, "x", (B, C, L), 1.0))
+        w = O.fold_weight_norm(v, g)
+        ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x, slope), w, bias, dilation=d, padding=(k * d - d) // 2)
+        if res:
+            ref = ref + x
+        xc, vc, gc, bc = x.cuda(), v.cuda(), g.cuda(), bias.cuda()
+        y = torch.full((B, co, L), float("nan"), device="cuda")
+        N.check(N.lib().svoc_conv1d(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), N.ptr(xc) if res else None,
+                                    N.ptr(y), B, C, co, L, k, d, ctypes.c_float(slope)))
+        check(f"conv1d#{it} C{C}->{co} k{k} d{d} L{L} B{B} slope{slope} res{res}", y, ref)
+
+
 @pytest.mark.parametrize("name", list(cases.UPS_CASES))
 def test_conv_transpose(M, name):
     import ctypes
