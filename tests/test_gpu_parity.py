@@ -121,6 +121,31 @@ def test_conv1d_random_shapes(M):
         check(f"conv1d#{it} C{C}->{co} k{k} d{d} L{L} B{B} slope{slope} res{res}", y, ref)
 
 
+@pytest.mark.parametrize("k,s", [(16, 8), (4, 2), (8, 8), (2, 2), (6, 2), (12, 4), (3, 1), (1, 1), (7, 3), (16, 4), (10, 4)])
+def test_conv_transpose_geometries(M, k, s):
+    """Polyphase ConvTranspose1d beyond the model's k = 2*stride upsamplers (k < 2s, k > 2s, k % s != 0, stride 1), odd
+    channel counts, ragged lengths; k - stride odd (output length != L*stride) is refused with an error."""
+    import ctypes
+    N = M.native
+    for (ci, co, L, B) in [(64, 32, 50, 2), (33, 7, 129, 1)]:
+        seed = 7000 + 31 * k + s + ci
+        v = T(cases.rnd(seed, "v", (ci, co, k), 1.0 / np.sqrt(ci * k)))
+        g = T((0.5 + sw.uniform01(seed, "g", ci)).astype(np.float32)).reshape(ci, 1, 1)
+        bias = T(cases.rnd(seed, "b", (co,), 0.1))
+        x = T(cases.rnd(seed, "x", (B, ci, L), 1.0))
+        w = O.fold_weight_norm(v, g)
+        ref = torch.nn.functional.conv_transpose1d(torch.nn.functional.leaky_relu(x, 0.1), w, bias, stride=s, padding=(k - s) // 2)
+        assert ref.shape[2] == L * s
+        xc, vc, gc, bc = x.cuda(), v.cuda(), g.cuda(), bias.cuda()
+        y = torch.full((B, co, L * s), float("nan"), device="cuda")
+        N.check(N.lib().svoc_conv_transpose1d(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), N.ptr(y), B, ci, co, L, k, s,
+                                              ctypes.c_float(0.1)))
+        check(f"convT k{k} s{s} ci{ci}", y, ref)
+    xc = torch.zeros(1, 8, 4, device="cuda"); vc = torch.zeros(8, 8, k + 1, device="cuda"); y = torch.zeros(1, 8, 4 * s, device="cuda")
+    rc = N.lib().svoc_conv_transpose1d(N.stream_ptr(), N.ptr(xc), N.ptr(vc), None, None, N.ptr(y), 1, 8, 8, 4, k + 1, s, ctypes.c_float(1.0))
+    assert rc != 0       # (k+1) - s has the other parity
+
+
 @pytest.mark.parametrize("name", list(cases.UPS_CASES))
 def test_conv_transpose(M, name):
     import ctypes
