@@ -173,6 +173,30 @@ def test_resblock1(M, name):
     check(name + " vs golden", y, cases.golden(name)["y"])
 
 
+def test_resblock1_edge_lengths(M):
+    """ResBlock1 (fused kernel for C = 32 / 64, two convolutions for C = 128) at lengths around the tile edges: shorter than
+    the halo, exactly N2 = N_A - (k-1), one more, a ragged last tile, and many tiles; every kernel size of the model and a
+    non-standard one; with the padding mask as well (unfused path)."""
+    rng = np.random.default_rng(11)
+    for it, (C, k) in enumerate([(32, 3), (32, 11), (64, 3), (64, 7), (64, 11), (32, 5), (128, 7)]):
+        NA = 256 if C == 32 else 128
+        n2 = NA - (k - 1)
+        sd = sw.fill_state_dict(cases.resblock1_shapes(C, k), 8100 + it, 1.0)
+        m = load(M.modules.ResBlock1(C, k, (1, 3, 5)), sd)
+        for L in (1, 5, n2 - 1, n2, n2 + 1, 2 * n2 + 3, 1000):
+            B = int(rng.integers(1, 4))
+            x = T(cases.rnd(8200 + it, f"x{L}", (B, C, L), 0.5))
+            with torch.no_grad():
+                ref = O.resblock1(sdT(sd), "", x, k, (1, 3, 5))
+            check(f"resblock1 C{C} k{k} L{L} B{B}", m(x.cuda()), ref.numpy())
+        L = 300
+        x = T(cases.rnd(8300 + it, "xm", (2, C, L), 0.5))
+        mask = T(cases.lengths_mask([L, 111], L))
+        with torch.no_grad():
+            ref = O.resblock1(sdT(sd), "", x, k, (1, 3, 5), mask=mask)
+        check(f"resblock1 masked C{C} k{k}", m(x.cuda(), mask.cuda()), ref.numpy())
+
+
 @pytest.mark.parametrize("name", list(cases.RESBLOCK2_CASES))
 def test_resblock2(M, name):
     c = cases.RESBLOCK2_CASES[name]
