@@ -218,6 +218,24 @@ def test_wn(M, name):
     check(name, y, cases.golden(name)["y"])
 
 
+def test_wn_edge_shapes(M):
+    """WN over hidden sizes with even / odd numbers of 32-channel chunks (K-split 12-wave kernel vs one wave per row pair),
+    lengths around the 32-column tile, short and long batches (NR = 1 / 2 tiles), with and without conditioning."""
+    rng = np.random.default_rng(12)
+    for it, (H, k, dr, n, gin) in enumerate([(192, 5, 1, 2, 0), (64, 3, 2, 3, 16), (96, 5, 1, 2, 0), (160, 3, 1, 2, 8), (256, 5, 1, 2, 0)]):
+        sd = sw.fill_state_dict(cases.wn_shapes(H, k, n, gin), 8400 + it)
+        m = load(M.modules.WN(H, k, dr, n, gin_channels=gin), sd)
+        for Tn, B in ((1, 1), (31, 2), (32, 1), (33, 3), (100, 2), (513, 2), (700, 24)):
+            x = T(cases.rnd(8500 + it, f"x{Tn}", (B, H, Tn), 1.0))
+            lens = [Tn] + [int(rng.integers(1, Tn + 1)) for _ in range(B - 1)]
+            mask = T(cases.lengths_mask(lens, Tn))
+            g = T(cases.rnd(8500 + it, f"g{Tn}", (B, gin, 1), 1.0)) if gin else None
+            with torch.no_grad():
+                ref = O.wn(sdT(sd), "", x * mask, mask, g, hidden=H, kernel_size=k, dilation_rate=dr, n_layers=n)
+            y = m((x * mask).cuda(), mask.cuda(), g=g.cuda() if g is not None else None)
+            check(f"wn H{H} k{k} dr{dr} T{Tn} B{B}", y, ref.numpy())
+
+
 @pytest.mark.parametrize("name", list(cases.POSTERIOR_CASES))
 def test_posterior_encoder(M, name):
     c = cases.POSTERIOR_CASES[name]
