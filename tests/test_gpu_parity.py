@@ -89,6 +89,29 @@ def test_conv1d(M, C, k, d, L, B, res):
     check(f"conv1d C{C} k{k} d{d}", y, ref)
 
 
+def test_error_paths_return_codes(M):
+    """Reference behaviour at the boundary is 'raise'; at the C ABI that is a negative svoc_status plus a message, never a
+    crash: NULL arguments, a convolution whose dilation halo cannot fit the 160 KB LDS, conditioning passed to a module
+    built without gin_channels, a missing tensor at create time."""
+    import ctypes
+    N = M.native
+    lib = N.lib()
+    x = torch.zeros(1, 32, 64, device="cuda"); w = torch.zeros(32, 32, 11, device="cuda"); y = torch.zeros(1, 32, 64, device="cuda")
+    assert lib.svoc_conv1d(N.stream_ptr(), None, N.ptr(w), None, None, None, N.ptr(y), 1, 32, 32, 64, 11, 1, ctypes.c_float(1.0)) == -1
+    rc = lib.svoc_conv1d(N.stream_ptr(), N.ptr(x), N.ptr(w), None, None, None, N.ptr(y), 1, 32, 32, 64, 11, 4000, ctypes.c_float(1.0))
+    assert rc == -5 and b"LDS" in lib.svoc_last_error()
+    torch.cuda.synchronize()
+    sd = sw.fill_state_dict(cases.wn_shapes(64, 3, 2, 0), 1)
+    m = load(M.modules.WN(64, 3, 1, 2, gin_channels=0), sd)
+    xm = torch.zeros(1, 64, 40, device="cuda"); mask = torch.ones(1, 1, 40, device="cuda")
+    with pytest.raises(N.SvocError):
+        m(xm, mask, g=torch.zeros(1, 8, 1, device="cuda"))
+    h = ctypes.c_void_p()
+    empty = N.TensorTable({})
+    rc = lib.svoc_wn_create(ctypes.byref(h), 64, 3, 1, 2, 0, empty.arr, empty.n, b"")
+    assert rc == -2 and not h.value and b"in_layers" in lib.svoc_last_error()
+
+
 def test_conv1d_random_shapes(M):
     """Seeded sweep over odd shapes: channel counts that are not multiples of 32, every tile configuration (many / few
     columns), large dilations (wide LDS rows), lengths that leave ragged last tiles and workgroup totals that are not
