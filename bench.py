@@ -27,41 +27,102 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_SAMPLE = 2568280.0          # 2*MAC of the 184 convolutions per output sample
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 SAMPLE_RATE = 22050
+ROUND_TAG = "r02"                     # only PMC traffic files of this round's code are quoted
 
 
-def cpu_baseline(sd_np, B, T, seed):
-    """The CPU oracle (oracle/vocoder_oracle.py, a port of the reference forward) timed on the host cores on a
-    bounded sample of the same workload: B utterances of T frames.  torch's intra-op thread count is chosen by a
-    short probe (more threads than ~16-32 make oneDNN's small convolutions slower on a 2x64-core host, see
-    profiles/r01_cpu_threads_probe.txt); `cores` reports the count actually used."""
+def _cpu_info():
+    model, phys = "unknown", None
+    try:
+        cores = set()
+        phys_id = core_id = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys_id = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core_id = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys_id is not None and core_id is not None:
+                    cores.add((phys_id, core_id))
+                phys_id = core_id = None
+        phys = len(cores) or None
+    except Exception:   # noqa: BLE001
+        pass
+    return model, phys
+
+
+def cpu_baseline(sd_np, seed):
+    """the CPU oracle (oracle/vocoder_oracle.py, a restatement of the reference forward: kind "port")
+    timed on the host cores with 1 warm-up + best of 3, on C2 (16 x 512, the bench workload: `value`) and on C1 (1 x 200,
+    the reference notebook's shape).  torch's intra-op thread count is chosen by a short probe (more threads than ~16-32
+    make oneDNN's small convolutions slower on a 2x64-core host, profiles/r01_cpu_threads_probe.txt); `cores` is
+    the count actually used; the CPU model and physical core count are recorded."""
     from oracle import vocoder_oracle as O
     from cases import sw
     avail = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
-    except Exception:
+    except Exception:   # noqa: BLE001
         pass
+    model, phys = _cpu_info()
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    t_all = time.perf_counter()
+
+    def run(mel, ln, eps):
+        t0 = time.perf_counter()
+        o, *_ = O.infer(sd, mel, ln, eps, 0.667)
+        return time.perf_counter() - t0, o.numel()
+
     with torch.no_grad():
         pm = torch.from_numpy(sw.synthetic_mel(seed, 1, 96)); pe = torch.from_numpy(sw.synthetic_eps(seed, 1, 96))
         best, cores = None, 1
         for n in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
             torch.set_num_threads(n)
-            O.infer(sd, pm[:, :, :16], torch.tensor([16]), pe[:, :, :16], 0.667)      # thread-pool warm-up
-            t0 = time.perf_counter()
-            O.infer(sd, pm, torch.tensor([96]), pe, 0.667)
-            dt = time.perf_counter() - t0
+            run(pm[:, :, :16], torch.tensor([16]), pe[:, :, :16])      # thread-pool warm-up
+            dt, _ = run(pm, torch.tensor([96]), pe)
             if best is None or dt < best:
                 best, cores = dt, n
         torch.set_num_threads(cores)
-        mel = torch.from_numpy(sw.synthetic_mel(seed, B, T)); eps = torch.from_numpy(sw.synthetic_eps(seed, B, T))
-        ln = torch.full((B,), T, dtype=torch.int64)
-        t0 = time.perf_counter()
-        o, *_ = O.infer(sd, mel, ln, eps, 0.667)
-        dt = time.perf_counter() - t0
-    return dict(value=o.numel() / dt, unit="samples/s", cores=cores, kind="port",
-                sample=f"{B}x{T} frames of the same synthetic workload, one pass, {dt:.2f} s, {cores} of {avail} host threads "
-                       f"(best of a 8/16/32/64 probe), torch {torch.__version__} fp32 oneDNN")
+        rec = {}
+        for tag, (B, T) in (("c2", (16, 512)), ("c1", (1, 200))):
+            mel = torch.from_numpy(sw.synthetic_mel(seed, B, T)); eps = torch.from_numpy(sw.synthetic_eps(seed, B, T))
+            ln = torch.full((B,), T, dtype=torch.int64)
+            wb = max(1, B // 4)
+            run(mel[:wb], ln[:wb], eps[:wb])                                  # warm-up (same T, a quarter of the batch)
+            times = []
+            for _ in range(3):
+                dt, n = run(mel, ln, eps)
+                times.append(dt)
+            rec[tag] = dict(value=n / min(times), unit="samples/s", shape=f"{B}x{T}", best_s=min(times), all_s=[round(t, 3) for t in times])
+    return dict(value=rec["c2"]["value"], unit="samples/s", cores=cores, kind="port",
+                sample=f"16x512 frames (the bench workload, whole batch), 1 warm-up + best of 3 = {rec['c2']['best_s']:.2f} s; "
+                       f"{cores} of {avail} host threads (best of an 8/16/32/64 probe), torch {torch.__version__} fp32 oneDNN",
+                cpu_model=model, physical_cores=phys, logical_cpus=avail, c1_1x200=rec["c1"], c2_16x512=rec["c2"],
+                protocol="SURVEY.md 8(d): 1 warm-up + best of 3, C1 and C2", wall_s=round(time.perf_counter() - t_all, 1))
+
+
+def dominant_kernel_probe(net, mel, ln, eps, steps=2):
+    """Per-launch duration of the dominant kernel, measured live with HIP events on the launch stream by the library's
+    event profiler (every GEMM-family launch bracketed by hipEventRecord): conv_group_kernel on the C=128 stage
+    (3 convolutions k=11/7/3 per launch, 40 % of the step).  Runs after the timed region."""
+    from smart_vocoder_amd import _native
+    _native.profile_enable(True)
+    with torch.no_grad():
+        for _ in range(steps):
+            net.infer(mel, ln, noise_scale=0.667, eps=eps)
+    torch.cuda.synchronize()
+    rep = _native.profile_report()
+    _native.profile_enable(False)
+    best = None
+    for line in rep.splitlines():
+        if not line.startswith("group "):
+            continue
+        f = line.split()
+        n, total_ms, mean_us, tfl = int(f[-4]), float(f[-3]), float(f[-2]), float(f[-1])
+        if best is None or total_ms > best["total_ms"]:
+            best = dict(desc=" ".join(f[:-4]), n=n, total_ms=total_ms, mean_us=mean_us, tflops=tfl)
+    return best, rep
 
 
 def main():
@@ -72,7 +133,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=512, help="mel frames per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--allow-no-collective", action="store_true", help="N>1: do not fail when neither gather nor all_gather works")
     args = ap.parse_args()
 
     import cases
@@ -92,6 +153,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    cdev = dev                                     # device of the small control tensors of the collectives
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -100,6 +162,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+            cdev = torch.device("cpu")
 
     B, T = args.batch, args.frames
     sd_np = cases.full_model_weights(skip_enc_q=True)
@@ -152,7 +215,7 @@ def main():
             o_probe = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
             for mode in ("gather", "all_gather", "none"):
                 gather_mode["v"] = mode
-                ok = torch.ones(1, device=dev)
+                ok = torch.ones(1, device=cdev)
                 try:
                     collect(o_probe)
                     torch.cuda.synchronize()
@@ -162,6 +225,12 @@ def main():
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if ok.item() > 0:
                     break
+        if gather_mode["v"] == "none" and not args.allow_no_collective:
+            if rank == 0:
+                print("[bench] no collective (gather / all_gather) works on this node: the N>1 line would not include the "
+                      "waveform gather; refusing (pass --allow-no-collective to run replicas only)", file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -185,7 +254,7 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)
     stats = _native.stats_get()
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -197,6 +266,7 @@ def main():
         # launches in the timed region (counted by the library, 2*MAC) over the device time of the region measured
         # with HIP events on the launch stream (includes the few % spent in the small non-GEMM kernels).
         conv_tflops = stats["conv_flops"] / (gpu_ms * 1e-3) / 1e12
+        dom, _ = dominant_kernel_probe(net, mel, ln, eps) if (B == 16 and T == 512) else (None, None)
         res = {
             "metric": "audio samples/sec (22.05 kHz), iitp_base batch 16 per GPU",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,29 +277,41 @@ def main():
                        "global_batch": Bj, "frames": T, "samples_per_step": samples_per_step, "parallelism": f"dp{world}", "collective": gather_mode["v"]},
             "real_time_factor": value / SAMPLE_RATE / world,
             "samples_per_s_per_gpu": value / world,
-            "roofline": {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "fp32 MFMA implicit-GEMM family: conv_mfma_kernel, conv_group_kernel, resblock_fused_kernel, wn_layer_fused(_ks)_kernel",
-                         "launches_per_step": stats["conv_launches"] / args.steps,
-                         "flop_per_step": stats["conv_flops"] / args.steps,
-                         "gpu_ms_per_step_rank0": gpu_ms / args.steps},
         }
-        # HBM traffic of the same workload from PMC counters (collected offline with rocprofv3 --pmc in separate passes,
-        # tools/pmc_traffic.py; counters cannot be read from inside this process)
+        # Roofline.  Headline (`achieved`/`frac`): the fp32-MFMA implicit-GEMM family as a whole = algorithmic FLOPs of every
+        # GEMM launch of the timed region (counted by the library, 2*MAC) over the device time of the region, HIP events on
+        # the launch stream (conservative: the region includes the few % of non-GEMM kernels).  `dominant_kernel`: the
+        # single kernel with the largest share, per-launch, measured live after the timed region.
+        res["roofline"] = {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_mfma_kernel, conv_group_kernel, resblock_fused_kernel, wn_layer_fused(_ks)_kernel",
+                           "gemm_launches_per_step": stats["conv_launches"] / args.steps,
+                           "convolutions_per_step": stats["convolutions"] / args.steps,
+                           "small_kernel_launches_per_step": stats["other_launches"] / args.steps,
+                           "flop_per_step": stats["conv_flops"] / args.steps,
+                           "gpu_ms_per_step_rank0": gpu_ms / args.steps}
+        if dom:
+            res["roofline"]["dominant_kernel"] = {
+                "name": "conv_group_kernel<2,2,2,2> " + dom["desc"], "launches_measured": dom["n"],
+                "avg_launch_us": dom["mean_us"], "flop_per_launch": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6,
+                "achieved": dom["tflops"], "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "measured": "hipEventRecord around every launch on the launch stream (library event profiler), after the timed region"}
+        # HBM traffic of the same workload from PMC counters: they cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 --pmc passes of THIS round's code (tools/pmc_traffic.py); older files are ignored.
         import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND_TAG}*_pmc_hbm_traffic.json")))
         if tfiles and B == 16 and T == 512:
             try:
                 tj = json.load(open(tfiles[-1]))
                 step_bytes = tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"]
-                res["roofline"]["traffic"] = step_bytes / max(1.0, res["roofline"]["launches_per_step"])
-                res["roofline"]["traffic_unit"] = "HBM bytes per convolution (mean over the launches_per_step convolutions of a step)"
+                res["roofline"]["traffic"] = step_bytes / max(1.0, res["roofline"]["gemm_launches_per_step"])
+                res["roofline"]["traffic_unit"] = "HBM bytes per GEMM-family launch (mean over gemm_launches_per_step), OFFLINE measurement"
                 res["roofline"]["traffic_bytes_per_step"] = step_bytes
-                res["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*)"
+                res["roofline"]["traffic_source"] = f"offline: profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*, separate passes)"
             except Exception:   # noqa: BLE001
                 pass
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_sample_batch, T, 1001)
+            res["cpu_baseline"] = cpu_baseline(sd_np, 1001)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -14,8 +14,16 @@
  *   - every tensor is fp32, device memory, contiguous NCW unless a stride is
  *     given; lengths are int64 device memory;
  *   - every function returns 0 on success or a negative svoc_status and never
- *     throws, exits or synchronises the device (create/destroy functions may
- *     block while they upload and repack weights);
+ *     throws or exits;
+ *   - blocking behaviour: `*_forward` / `svoc_synth_infer` and the single ops
+ *     only enqueue work, with ONE exception: the first call at a shape larger
+ *     than any seen before grows the handle's workspace, which waits for the
+ *     device (hipDeviceSynchronize) before hipFree/hipMalloc; call
+ *     svoc_synth_reserve(h, B, T) once with the largest shape to make every later
+ *     infer allocation-free.  `*_create` blocks while weights are folded and
+ *     repacked; `*_destroy` waits for the device before freeing; svoc_conv1d /
+ *     svoc_conv_transpose1d (self-contained test entry points that pack their
+ *     weights on the fly) block until their result is ready;
  *   - work is enqueued on the caller's hipStream_t (passed as void*); handles
  *     are per-device and not thread-safe; the caller selects the device
  *     (hipSetDevice) before create;
@@ -57,11 +65,13 @@ typedef struct svoc_tensor {
 int svoc_abi_version(void);
 const char* svoc_last_error(void);       /* thread-local message of the last failure */
 const char* svoc_build_arch(void);       /* "gfx950" */
-/* Launch statistics of the implicit-GEMM convolution kernel since the last
- * reset: number of launches and algorithmic FLOPs (2*MAC) — used by bench.py's
- * roofline block. */
+/* Launch statistics since the last reset: GEMM-family kernel launches (conv_mfma / conv_group / resblock_fused /
+ * wn_layer_fused; a grouped or fused launch counts once), their algorithmic FLOPs (2*MAC), launches of the small
+ * memory-bound kernels, and the number of CONVOLUTIONS those GEMM launches computed (a group launch = 3, a fused
+ * ResBlock iteration or WN layer = 2) — used by bench.py's roofline block. */
 int svoc_stats_reset(void);
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches);
+int64_t svoc_stats_convolutions(void);
 
 /* Diagnostics: bracket every convolution launch with HIP events and aggregate by layer shape. */
 int svoc_profile_enable(int on);
@@ -164,6 +174,10 @@ int svoc_synth_infer(svoc_synth* h, void* stream, const float* mel, const int64_
                      float noise_scale, int max_len, float* o, float* x_mask, float* z, float* z_p, float* m_p,
                      float* logs_p, int B, int T);
 int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T);
+/* Pre-sizes every workspace of the path for batches up to [B, T] (may block, see "blocking behaviour"); afterwards
+ * svoc_synth_infer at that or any smaller shape neither allocates nor synchronises.  Short inputs (B*T <= 4096 frames,
+ * SVOC_GRAPH_MAX_FRAMES) are replayed from a hipGraph captured on their second call (SVOC_GRAPH=0 disables). */
+int svoc_synth_reserve(svoc_synth* h, int B, int T);
 int svoc_synth_hop(svoc_synth* h);         /* prod(upsample_rates) */
 void svoc_synth_destroy(svoc_synth* h);
 
@@ -180,14 +194,30 @@ int svoc_posterior_forward(svoc_posterior* h, void* stream, const float* x, cons
 void svoc_posterior_destroy(svoc_posterior* h);
 
 
+/* ---- models.MelEncoder (models.py:15-47) as a standalone module (inside svoc_synth_infer it is part of the one call) */
+typedef struct svoc_mel_encoder svoc_mel_encoder;
+/* tensors: pre_enc.{weight,bias}, encoder.<WN tensors>, proj.{weight,bias} */
+int svoc_mel_encoder_create(svoc_mel_encoder** out, int n_mel, int out_channels, int hidden_channels, int kernel_size,
+                            int dilation_rate, int n_layers, int gin_channels, const svoc_tensor* tensors, int n_tensors,
+                            const char* prefix);
+/* forward(x, x_lengths) (models.py:35-47; g is discarded there): x [B,n_mel,T], lengths int64 [B] ->
+ * x_out [B,hidden,T] (WN output, may be NULL), m, logs [B,out,T], x_mask [B,1,T] (may be NULL) */
+int svoc_mel_encoder_forward(svoc_mel_encoder* h, void* stream, const float* x, const int64_t* lengths, float* x_out,
+                             float* m, float* logs, float* x_mask, int B, int T);
+void svoc_mel_encoder_destroy(svoc_mel_encoder* h);
+
+/* ---- modules.LayerNorm.forward (modules.py:20-32): F.layer_norm over the channel dim of x [B,C,T]; y [B,C,T] */
+int svoc_layer_norm(void* stream, const float* x, const float* gamma, const float* beta, float eps, float* y, int B,
+                    int C, int T);
+
 /* ---- modules.DDSConv (modules.py:70-108) ---------------------------------- */
 typedef struct svoc_dds svoc_dds;
 /* tensors: convs_sep.{i}.{weight,bias}, convs_1x1.{i}.{weight,bias}, norms_1.{i}.{gamma,beta}, norms_2.{i}.* */
 int svoc_dds_create(svoc_dds** out, int channels, int kernel_size, int n_layers, const svoc_tensor* tensors,
                     int n_tensors, const char* prefix);
-/* forward(x, x_mask, g): x,y [B,C,T]; g NULL or [B,C,T] */
-int svoc_dds_forward(svoc_dds* h, void* stream, const float* x, const float* x_mask, const float* g, float* y, int B,
-                     int T);
+/* forward(x, x_mask, g): x,y [B,C,T]; g NULL or [B,C,g_T] with g_T == T or 1 (broadcast over time) */
+int svoc_dds_forward(svoc_dds* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T, float* y,
+                     int B, int T);
 void svoc_dds_destroy(svoc_dds* h);
 
 /* ---- modules.ConvFlow (modules.py:346-390) -------------------------------- */
@@ -195,7 +225,9 @@ typedef struct svoc_convflow svoc_convflow;
 /* tensors: pre.*, convs.<DDSConv tensors>, proj.* */
 int svoc_convflow_create(svoc_convflow** out, int in_channels, int filter_channels, int kernel_size, int n_layers,
                          int num_bins, float tail_bound, const svoc_tensor* tensors, int n_tensors, const char* prefix);
-int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const float* x_mask, const float* g,
+/* forward(x, x_mask, g, reverse) (modules.py:363-390): g NULL or [B,filter_channels,g_T] (g_T == T or 1), handed to
+ * DDSConv (modules.py:366) */
+int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T,
                           int reverse, float* y, float* logdet, int B, int T);
 void svoc_convflow_destroy(svoc_convflow* h);
 
@@ -215,10 +247,12 @@ void svoc_melspec_destroy(svoc_melspec* h);
 
 /* ---- transforms.piecewise_rational_quadratic_transform (transforms.py:12-193), tails='linear' or none */
 /* inputs [n]; unnormalized widths/heights [n,num_bins]; derivatives [n,num_bins-1] (linear tails) or
- * [n,num_bins+1] (tails==0, domain [0,1]); outputs, logabsdet [n]. */
+ * [n,num_bins+1] (tails==0, domain [0,1]); min_bin_width/min_bin_height/min_derivative as transforms.py:20-22
+ * (defaults 1e-3); outputs, logabsdet [n]. */
 int svoc_rq_spline(void* stream, const float* inputs, const float* unnorm_widths, const float* unnorm_heights,
                    const float* unnorm_derivs, int64_t n, int num_bins, int inverse, int linear_tails,
-                   float tail_bound, float* outputs, float* logabsdet);
+                   float tail_bound, float min_bin_width, float min_bin_height, float min_derivative, float* outputs,
+                   float* logabsdet);
 
 /* ---- single ops (unit-testable pieces of the path) ------------------------- */
 /* commons.sequence_mask (commons.py:121-125) as float [B,1,T] */

@@ -95,10 +95,12 @@ def wn(sd, prefix, x, mask, g, *, hidden, kernel_size, dilation_rate, n_layers):
 
 
 # --------------------------------------------------------------------------- encoder / flow
-def mel_encoder(sd, mel, lengths, prefix="enc_p."):
+def mel_encoder(sd, mel, lengths, prefix="enc_p.", *, hidden=192, kernel_size=5, dilation_rate=1, n_layers=16):
+    """reference models.py:35-47; g is overwritten with None there (models.py:36), so cond_layer is never applied."""
     x = _conv(sd, prefix + "pre_enc", mel)
     mask = sequence_mask(lengths, x.shape[2], x.dtype)
-    x = wn(sd, prefix + "encoder.", x * mask, mask, None, hidden=192, kernel_size=5, dilation_rate=1, n_layers=16)
+    x = wn(sd, prefix + "encoder.", x * mask, mask, None, hidden=hidden, kernel_size=kernel_size,
+           dilation_rate=dilation_rate, n_layers=n_layers)
     stats = _conv(sd, prefix + "proj", x) * mask
     C = stats.shape[1] // 2
     return x, stats[:, :C], stats[:, C:], mask
@@ -237,10 +239,14 @@ def _spline_knots(unnorm, lo, hi, min_size):
     return cum, cum[..., 1:] - cum[..., :-1]
 
 
-def rq_spline(x, uw, uh, ud, inverse=False, left=0.0, right=1.0, bottom=0.0, top=1.0, min_bin=1e-3, min_deriv=1e-3):
-    """Rational-quadratic spline on [left,right]->[bottom,top]; ud has num_bins+1 entries."""
+def rq_spline(x, uw, uh, ud, inverse=False, left=0.0, right=1.0, bottom=0.0, top=1.0, min_bin=1e-3, min_deriv=1e-3,
+              min_bin_height=None):
+    """Rational-quadratic spline on [left,right]->[bottom,top]; ud has num_bins+1 entries (transforms.py:96-193).
+    min_bin = min_bin_width; min_bin_height defaults to the same value."""
+    if x.numel() and (float(x.min()) < left or float(x.max()) > right):
+        raise ValueError('Input to a transform is not within its domain')     # transforms.py:105-106
     cw, w = _spline_knots(uw, left, right, min_bin)
-    ch, h = _spline_knots(uh, bottom, top, min_bin)
+    ch, h = _spline_knots(uh, bottom, top, min_bin if min_bin_height is None else min_bin_height)
     dv = min_deriv + F.softplus(ud)
     knots = (ch if inverse else cw).clone()
     knots[..., -1] += 1e-6
@@ -268,16 +274,17 @@ def rq_spline(x, uw, uh, ud, inverse=False, left=0.0, right=1.0, bottom=0.0, top
     return y_k + h_k * (s_k * th * th + d0 * tt) / den, lad
 
 
-def rq_spline_linear_tails(x, uw, uh, ud, inverse=False, tail_bound=5.0):
-    """transforms.py:55-94: identity outside [-B,B]; boundary derivatives fixed so that softplus+1e-3 == 1."""
+def rq_spline_linear_tails(x, uw, uh, ud, inverse=False, tail_bound=5.0, min_bin=1e-3, min_deriv=1e-3,
+                           min_bin_height=None):
+    """transforms.py:55-94: identity outside [-B,B]; boundary derivatives fixed so that softplus+min_derivative == 1."""
     inside = (x >= -tail_bound) & (x <= tail_bound)
-    c = float(np.log(np.exp(1 - 1e-3) - 1))
+    c = float(np.log(np.exp(1 - min_deriv) - 1))
     ud = F.pad(ud, (1, 1), value=c)
     out = x.clone()
     lad = torch.zeros_like(x)
     if inside.any():
         o, l = rq_spline(x[inside], uw[inside], uh[inside], ud[inside], inverse, -tail_bound, tail_bound,
-                         -tail_bound, tail_bound)
+                         -tail_bound, tail_bound, min_bin, min_deriv, min_bin_height)
         out[inside] = o
         lad[inside] = l
     return out, lad

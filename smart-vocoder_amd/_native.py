@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVOC_LIB selects another build of the same library (A/B comparisons of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("SVOC_LIB") or os.path.join(_HERE, "csrc", "libsvoc_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "svoc_build_arch": (C.c_char_p, []),
     "svoc_stats_reset": (_I, []),
     "svoc_stats_get": (_I, [C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(_L)]),
+    "svoc_stats_convolutions": (_L, []),
     "svoc_profile_enable": (_I, [_I]),
     "svoc_profile_report": (_I, [C.c_char_p, _I]),
     "svoc_debug_set_stamp_buffer": (_I, [_P]),
@@ -73,16 +74,21 @@ SIGNATURES = {
     "svoc_synth_create": (_I, [C.POINTER(_P), C.POINTER(svoc_synth_config), *_TAB]),
     "svoc_synth_infer": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _I]),
     "svoc_synth_workspace_bytes": (_L, [_P, _I, _I]),
+    "svoc_synth_reserve": (_I, [_P, _I, _I]),
     "svoc_synth_hop": (_I, [_P]),
     "svoc_synth_destroy": (None, [_P]),
     "svoc_posterior_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _I, _I, *_TAB, C.c_char_p]),
     "svoc_posterior_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
     "svoc_posterior_destroy": (None, [_P]),
     "svoc_dds_create": (_I, [C.POINTER(_P), _I, _I, _I, *_TAB, C.c_char_p]),
-    "svoc_dds_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I]),
+    "svoc_mel_encoder_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _I, _I, *_TAB, C.c_char_p]),
+    "svoc_mel_encoder_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
+    "svoc_mel_encoder_destroy": (None, [_P]),
+    "svoc_layer_norm": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _I]),
+    "svoc_dds_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I]),
     "svoc_dds_destroy": (None, [_P]),
     "svoc_convflow_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _F, *_TAB, C.c_char_p]),
-    "svoc_convflow_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I]),
+    "svoc_convflow_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I]),
     "svoc_convflow_destroy": (None, [_P]),
     "svoc_melspec_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, C.c_double, C.c_double]),
     "svoc_melspec_frames": (_I, [_P, _L]),
@@ -90,7 +96,7 @@ SIGNATURES = {
     "svoc_melspec_mel": (_I, [_P, _P, _P, _I, _I, _P]),
     "svoc_mel_filterbank": (_I, [_I, _I, _I, C.c_double, C.c_double, _P]),
     "svoc_melspec_destroy": (None, [_P]),
-    "svoc_rq_spline": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _P]),
+    "svoc_rq_spline": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _F, _P, _P]),
     "svoc_sequence_mask": (_I, [_P, _P, _P, _I, _I]),
     "svoc_fused_add_tanh_sigmoid_multiply": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "svoc_flip_channels": (_I, [_P, _P, _P, _I, _I, _I]),
@@ -203,7 +209,7 @@ def stats_reset():
 def stats_get():
     a, b, c = _L(0), C.c_double(0), _L(0)
     lib().svoc_stats_get(C.byref(a), C.byref(b), C.byref(c))
-    return dict(conv_launches=a.value, conv_flops=b.value, other_launches=c.value)
+    return dict(conv_launches=a.value, conv_flops=b.value, other_launches=c.value, convolutions=lib().svoc_stats_convolutions())
 
 
 def profile_enable(on=True):

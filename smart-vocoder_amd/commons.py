@@ -31,7 +31,8 @@ def sequence_mask(length, max_length=None):
         max_length = int(length.max().item())
     ln = length.to(torch.int64).contiguous()
     out = torch.empty(ln.shape[0], int(max_length), dtype=torch.float32, device=ln.device)
-    N.check(N.lib().svoc_sequence_mask(N.stream_ptr(ln.device), N.ptr(ln), N.ptr(out), ln.shape[0], int(max_length)))
+    with torch.cuda.device(ln.device):
+        N.check(N.lib().svoc_sequence_mask(N.stream_ptr(ln.device), N.ptr(ln), N.ptr(out), ln.shape[0], int(max_length)))
     return out.bool()
 
 
@@ -42,6 +43,7 @@ def fused_add_tanh_sigmoid_multiply(input_a, input_b, n_channels):
     if a.shape != b.shape or a.dim() != 3 or a.shape[1] != 2 * n:
         raise ValueError(f"expected two [B, {2 * n}, T] tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
     out = torch.empty(a.shape[0], n, a.shape[2], dtype=torch.float32, device=a.device)
-    N.check(N.lib().svoc_fused_add_tanh_sigmoid_multiply(N.stream_ptr(a.device), N.ptr(a), N.ptr(b), N.ptr(out),
-                                                         a.shape[0], n, a.shape[2]))
+    with torch.cuda.device(a.device):
+        N.check(N.lib().svoc_fused_add_tanh_sigmoid_multiply(N.stream_ptr(a.device), N.ptr(a), N.ptr(b), N.ptr(out),
+                                                             a.shape[0], n, a.shape[2]))
     return out

@@ -488,11 +488,7 @@ template <int WM, int WN, int MR, int NR>
 int launch_cfg(const ConvArgs& a, int B, hipStream_t st) {
   constexpr int BN = WN * NR * 32;
   auto kern = conv_mfma_kernel<WM, WN, MR, NR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const size_t lds = (size_t)a.kcs * a.row_len * sizeof(float);
   if (lds > 160 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "conv LDS tile of %zu bytes exceeds 160 KiB (kernel %d taps, dilation %d)", lds, a.ktaps, a.dil);
   dim3 grid((a.Ncols + BN - 1) / BN, (a.mtiles + WM * MR - 1) / (WM * MR), B);
@@ -534,7 +530,7 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
   // most workgroups: a big tile is a long chain of dependent MFMAs, which is pure latency when it cannot be
   // overlapped with other tiles (small batches / short utterances).
   const int mt = pc.mtiles;
-  static const int ncu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  const int ncu = device_cu_count();
   TileCfg cand[6];
   int ncand = 0;
   if (needs_pair) { cand[ncand++] = CFG_B; cand[ncand++] = CFG_E; }
@@ -593,14 +589,6 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   }
   struct ProfEnd { hipStream_t st; int i; ~ProfEnd() { prof_end(st, i); } } prof_end_guard{st, prof_idx};
 
-  {   // experimental persistent wave-specialised kernels (conv_ws.hip), opt-in with SVOC_WS=1 / 2: at parity with the
-      // kernel below for k >= 7 and slower for small k
-    static const int ws_mode = getenv("SVOC_WS") ? atoi(getenv("SVOC_WS")) : 0;
-    if (ws_mode != 0 && a.mode != EPI_MAG && !((a.out[0].flags | a.out[1].flags) & F_LOGCLAMP)) {
-      const int r = ws_mode == 2 ? launch_conv_ws2(a, B, c.WM, c.WN, c.MR, c.NR, st) : launch_conv_ws(a, B, c.WM, c.WN, c.MR, c.NR, st);
-      if (r <= 0) return r;
-    }
-  }
 #define SVOC_LAUNCH(C) if (c.WM == C.WM && c.WN == C.WN && c.MR == C.MR && c.NR == C.NR) return launch_cfg<C.WM, C.WN, C.MR, C.NR>(a, B, st)
   SVOC_LAUNCH(CFG_A);
   SVOC_LAUNCH(CFG_B);
@@ -636,7 +624,7 @@ int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, i
   }
   for (int i = n; i < 3; ++i) g.end[i] = 0x7fffffff;
   if (lds > 160 * 1024) return 1;
-  for (int i = 0; i < n; ++i) stats_add_conv(pcs[i]->flops_per_col * (double)B * (double)g.a[i].Ncols);
+  stats_add_conv(flops, n);
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
@@ -645,11 +633,7 @@ int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, i
     prof_idx = prof_begin(st, d, flops);
   }
   auto kern = conv_group_kernel<CFG_B.WM, CFG_B.WN, CFG_B.MR, CFG_B.NR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, g);
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());

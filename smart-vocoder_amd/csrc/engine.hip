@@ -62,6 +62,11 @@ struct WNStack {
     return SVOC_OK;
   }
 
+  size_t need(int B, int T, int g_T) const {
+    return (size_t)(3LL * H * pad4(T) * B + 2LL * H * NL * (g_T > 0 ? pad4(g_T) : 0) * B) * sizeof(float);
+  }
+  int reserve(int B, int T, int g_T) { return ws.ensure(need(B, T, g_T)); }
+
   // x (already masked by the caller, as the reference's callers do) -> out; both [B][H][ld]
   int forward(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs,
               const float* g, int g_T, float* out, long long out_bs, int out_ld, int B, int T) {
@@ -69,7 +74,7 @@ struct WNStack {
     const long long per = (long long)H * Tp;
     const int gTp = g ? pad4(g_T) : 0;
     const long long gper = (long long)2 * H * NL * gTp;
-    SVOC_TRY(ws.ensure((size_t)(3 * per * B + gper * B) * sizeof(float)));
+    SVOC_TRY(ws.ensure(need(B, T, g ? g_T : 0)));
     float* xa = ws.f();
     float* xb = xa + per * B;
     float* acts = xb + per * B;
@@ -241,6 +246,11 @@ struct Coupling {
     return SVOC_OK;
   }
 
+  int reserve(int B, int T, int g_T) {
+    SVOC_TRY(ws.ensure((size_t)(2LL * H * pad4(T) * B) * sizeof(float)));
+    return enc.reserve(B, T, g_T);
+  }
+
   // src/dst: physical [B][C][ld] buffers (dst may equal src).  Only the x1 block of dst is written;
   // when dst != src the caller copies the x0 block.
   int run(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld,
@@ -300,6 +310,11 @@ struct Flow {
         fwd_p.push_back(fwd_l.back().get());
       }
     }
+    return SVOC_OK;
+  }
+
+  int reserve(int B, int T, int g_T, int reverse) {
+    for (auto* c : (reverse ? rev_p : fwd_p)) SVOC_TRY(c->reserve(B, T, g_T));
     return SVOC_OK;
   }
 
@@ -486,6 +501,8 @@ struct Generator {
     return SVOC_OK;
   }
 
+  int reserve(int B, int T) { return ws.ensure(workspace_bytes(B, T)); }
+
   int forward(hipStream_t st, const float* x, int x_ld, long long x_bs, const float* in_mask, long long in_mask_bs,
               const float* g, float* out, int B, int T) {
     const size_t sf = stage_floats(T);
@@ -558,8 +575,14 @@ struct Generator {
       else r = (r + 2) & 3;
       ch = cho; L = Lo; ld = ldo;
     }
-    // lrelu(0.01) -> conv_post -> tanh (models.py:156-158)
-    return k_conv_post_tanh(st, bufs[r], (long long)ch * ld, ld, conv_post_w.f(), ch, 7, 0.01f, out, B, L);
+    last_stage = bufs[r]; last_ch = ch; last_L = L; last_ld = ld;
+    return out ? post(st, out, B, T) : SVOC_OK;
+  }
+  // lrelu(0.01) -> conv_post -> tanh (models.py:156-158) on the last MRF stage left by forward(.., B, T)
+  float* last_stage = nullptr; int last_ch = 0, last_L = 0, last_ld = 0;
+  int post(hipStream_t st, float* out, int B, int T) {
+    if (!last_stage || last_L != T * hop) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: post() without a matching forward()");
+    return k_conv_post_tanh(st, last_stage, (long long)last_ch * last_ld, last_ld, conv_post_w.f(), last_ch, 7, 0.01f, out, B, last_L);
   }
 };
 
@@ -572,23 +595,29 @@ struct Posterior {
   WNStack enc;
   DevBuf ws;
 
+  // pre_name / enc_name: "pre" / "enc." for PosteriorEncoder (models.py:99-101), "pre_enc" / "encoder." for MelEncoder
+  // (models.py:31-33)
   int create(int in_channels, int out_channels, int hidden, int k, int dr, int nl, int gin, const TensorTable& tab,
-             const std::string& prefix, hipStream_t st) {
+             const std::string& prefix, hipStream_t st, const char* pre_name = "pre", const char* enc_name = "enc.") {
     if (in_channels <= 0 || out_channels <= 0 || hidden <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "posterior encoder: bad configuration");
     Cin = in_channels; Cout = out_channels; H = hidden;
     PackSpec ps{}; ps.Cin = Cin; ps.Cout = H; ps.K = 1;
-    SVOC_TRY(pack_conv_named(pre, ps, tab, prefix + "pre", st));
-    SVOC_TRY(enc.create(H, k, dr, nl, gin, tab, prefix + "enc.", st));
+    SVOC_TRY(pack_conv_named(pre, ps, tab, prefix + pre_name, st));
+    SVOC_TRY(enc.create(H, k, dr, nl, gin, tab, prefix + enc_name, st));
     PackSpec pj{}; pj.Cin = H; pj.Cout = 2 * Cout; pj.K = 1; pj.paired = true;
     SVOC_TRY(pack_conv_named(proj, pj, tab, prefix + "proj", st));
     return SVOC_OK;
   }
 
+  size_t need(int B, int T) const { const int Tp = pad4(T); return (size_t)((2LL * H * Tp + Tp) * B) * sizeof(float); }
+
+  // eps / z may be NULL (MelEncoder has no draw); x_out (nullable) receives the WN output [B][H][T] that
+  // MelEncoder.forward returns first (models.py:42,47)
   int forward(hipStream_t st, const float* x, const int64_t* lengths, const float* g, int g_T, const float* eps, float* z, float* m,
-              float* logs, float* x_mask, int B, int T) {
+              float* logs, float* x_mask, int B, int T, float* x_out = nullptr) {
     const int Tp = pad4(T);
     const long long hper = (long long)H * Tp;
-    SVOC_TRY(ws.ensure((size_t)((2 * hper + Tp) * B) * sizeof(float)));
+    SVOC_TRY(ws.ensure(need(B, T)));
     float* xe = ws.f();
     float* eo = xe + hper * B;
     float* mask = eo + hper * B;
@@ -612,6 +641,7 @@ struct Posterior {
       a.eps = eps; a.eps_bs = ubs; a.eps_ld = T; a.noise_scale = 1.0f;
       SVOC_TRY(launch_conv(proj, a, B, st));
     }
+    if (x_out) SVOC_TRY(k_copy2d(st, eo, hper, Tp, x_out, (long long)H * T, T, B, H, T, nullptr, 0));
     if (x_mask) SVOC_TRY(k_copy2d(st, mask, Tp, Tp, x_mask, T, T, B, 1, T, nullptr, 0));
     return SVOC_OK;
   }
@@ -640,55 +670,191 @@ struct Synth {
     return SVOC_OK;
   }
 
-  int64_t workspace_bytes(int B, int T) const {
+  size_t own_bytes(int B, int T) const {
     const int Tp = pad4(T);
-    const size_t own = ((size_t)(2 * cfg.hidden_channels + 3 * cfg.inter_channels) * Tp + Tp) * B * sizeof(float);
-    const size_t wn = (size_t)2 * cfg.hidden_channels * Tp * B * sizeof(float);
-    return (int64_t)(own + 3 * wn + dec.workspace_bytes(B, T));
+    return ((size_t)(2 * cfg.hidden_channels + 4 * cfg.inter_channels) * Tp + Tp) * B * sizeof(float);
+  }
+  int64_t workspace_bytes(int B, int T) const {
+    return (int64_t)(own_bytes(B, T) + enc.need(B, T, 0) + (flow.rev_p.empty() ? 0 : flow.rev_p[0]->enc.need(B, T, 0)) * flow.NF +
+                     (size_t)2 * cfg.hidden_channels * pad4(T) * B * sizeof(float) * flow.NF + dec.workspace_bytes(B, T));
+  }
+  // Sizes every workspace of the path for (B, T) up front, so that no later infer at that or a smaller shape allocates
+  // (workspaces are grow-only; growing one frees and re-allocates it after a device synchronisation).
+  int reserve(int B, int T) {
+    SVOC_TRY(ws.ensure(own_bytes(B, T)));
+    SVOC_TRY(enc.reserve(B, T, 0));
+    SVOC_TRY(flow.reserve(B, T, 0, 1));
+    return dec.reserve(B, T);
+  }
+
+  // ---- the launch plan proper.  `mel`, `lengths`, `eps` are read and nothing user-owned is written: the five small
+  // user-visible tensors and the waveform are produced by tail() from library-owned buffers, so the same plan can be
+  // replayed from a captured hipGraph with stable pointers.
+  struct Bufs { float *xe, *eo, *mp, *lp, *P, *zp, *mask; };
+  Bufs bufs(int B, int T) const {
+    const int H = cfg.hidden_channels, IC = cfg.inter_channels, Tp = pad4(T);
+    const long long hper = (long long)H * Tp, iper = (long long)IC * Tp;
+    Bufs b;
+    b.xe = ws.f();                    // masked pre_enc output
+    b.eo = b.xe + hper * B;           // encoder (WN) output
+    b.mp = b.eo + hper * B;           // m_p
+    b.lp = b.mp + iper * B;           // logs_p
+    b.P = b.lp + iper * B;            // z_p, then z (flows run in place)
+    b.zp = b.P + iper * B;            // copy of z_p for the caller (flows overwrite P)
+    b.mask = b.zp + iper * B;         // [B][Tp]
+    return b;
+  }
+
+  int body(hipStream_t st, const float* mel, const int64_t* lengths, const float* eps, float noise_scale, int Td, bool want_zp,
+           int B, int T) {
+    const int H = cfg.hidden_channels, IC = cfg.inter_channels;
+    const int Tp = pad4(T);
+    const long long hper = (long long)H * Tp, iper = (long long)IC * Tp;
+    SVOC_TRY(ws.ensure(own_bytes(B, T)));
+    const Bufs w = bufs(B, T);
+    SVOC_TRY(k_sequence_mask(st, lengths, w.mask, B, Tp));   // row stride Tp; entries >= T are never read
+    {   // pre_enc 1x1, stored already multiplied by x_mask (models.py:38-42)
+      ConvArgs a = mk_args();
+      set_in(a, mel, (long long)cfg.n_mel * T, T, T);
+      a.Ncols = T; a.mask = w.mask; a.mask_bs = Tp;
+      set_out(a.out[0], w.xe, hper, Tp, H, F_OUTMASK);
+      SVOC_TRY(launch_conv(pre_enc, a, B, st));
+    }
+    SVOC_TRY(enc.forward(st, w.xe, hper, Tp, w.mask, Tp, nullptr, 0, w.eo, hper, Tp, B, T));
+    {   // proj -> (m_p, logs_p) * mask, reparameterisation z_p = m_p + eps*exp(logs_p)*noise_scale (models.py:44-46, 336)
+      ConvArgs a = mk_args();
+      set_in(a, w.eo, hper, Tp, T);
+      a.Ncols = T; a.mask = w.mask; a.mask_bs = Tp;
+      a.mode = EPI_PROJ;
+      set_out(a.out[0], w.mp, iper, Tp, IC);
+      a.y2 = w.lp; a.y3 = w.P;
+      a.eps = eps; a.eps_bs = (long long)IC * T; a.eps_ld = T; a.noise_scale = noise_scale;
+      SVOC_TRY(launch_conv(proj, a, B, st));
+    }
+    if (want_zp) SVOC_TRY(k_copy2d(st, w.P, iper, Tp, w.zp, iper, Tp, B, IC, T, nullptr, 0));
+    if (flow.NF % 2) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "synth: odd n_flows is not supported on the fused path");
+    SVOC_TRY(flow.run_inplace(st, w.P, iper, Tp, w.mask, Tp, nullptr, 0, 1, B, T));
+    // dec((z * x_mask)[:, :, :max_len]) (models.py:338), up to the last MRF stage; conv_post runs in tail()
+    return dec.forward(st, w.P, Tp, iper, w.mask, Tp, nullptr, nullptr, B, Td);
+  }
+
+  int tail(hipStream_t st, float* o, float* x_mask, float* z, float* z_p, float* m_p, float* logs_p, int Td, int B, int T) {
+    const int IC = cfg.inter_channels, Tp = pad4(T);
+    const long long iper = (long long)IC * Tp, ubs = (long long)IC * T;
+    const Bufs w = bufs(B, T);
+    if (m_p) SVOC_TRY(k_copy2d(st, w.mp, iper, Tp, m_p, ubs, T, B, IC, T, nullptr, 0));
+    if (logs_p) SVOC_TRY(k_copy2d(st, w.lp, iper, Tp, logs_p, ubs, T, B, IC, T, nullptr, 0));
+    if (z_p) SVOC_TRY(k_copy2d(st, w.zp, iper, Tp, z_p, ubs, T, B, IC, T, nullptr, 0));
+    if (z) SVOC_TRY(k_copy2d(st, w.P, iper, Tp, z, ubs, T, B, IC, T, nullptr, 0));
+    if (x_mask) SVOC_TRY(k_copy2d(st, w.mask, Tp, Tp, x_mask, T, T, B, 1, T, nullptr, 0));
+    return dec.post(st, o, B, Td);
+  }
+
+  // ---- captured plans for short inputs.  At 1 x 200 frames the ~100 dependent launches of the path are a few tens of
+  // microseconds each, so host launch cost and inter-kernel gaps are a sizeable part of the latency.  The body above is
+  // captured once per (B, T, max_len, noise_scale, eps?, z_p?) into a hipGraph that reads its inputs from library-owned
+  // staging buffers; a call then costs three small device-to-device copies, one graph launch and the tail.
+  // identity of every workspace allocation the captured kernels point into: a plan is re-captured when one of them moved
+  // (a larger shape grew it)
+  unsigned long long ws_fingerprint() const {
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const void* q) { h = (h ^ (unsigned long long)reinterpret_cast<uintptr_t>(q)) * 1099511628211ull; };
+    mix(ws.p); mix(enc.ws.p); mix(dec.ws.p);
+    for (auto* c : flow.rev_p) { mix(c->ws.p); mix(c->enc.ws.p); }
+    return h;
+  }
+  struct Plan {
+    unsigned long long fp = 0;
+    int B = 0, T = 0, Td = 0; float noise = 0; bool has_eps = false, want_zp = false;
+    int seen = 0;                       // calls with this key (the first runs uncaptured: per-device kernel attributes, allocation)
+    hipGraphExec_t exec = nullptr;
+    DevBuf stage;                       // mel | eps | lengths
+    long long conv_launches = 0, other_launches = 0, convs = 0; double conv_flops = 0;
+    unsigned long long last_use = 0;
+    ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
+  };
+  std::vector<std::unique_ptr<Plan>> plans;
+  unsigned long long use_clock = 0;
+  hipStream_t cap_st = nullptr;
+  ~Synth() { plans.clear(); if (cap_st) (void)hipStreamDestroy(cap_st); }
+
+  static long long graph_max_frames() {
+    static const long long v = getenv("SVOC_GRAPH_MAX_FRAMES") ? atoll(getenv("SVOC_GRAPH_MAX_FRAMES")) : 4096;
+    static const bool on = !(getenv("SVOC_GRAPH") && atoi(getenv("SVOC_GRAPH")) == 0);
+    return on ? v : 0;
+  }
+
+  int capture(Plan& pl, hipStream_t st) {
+    const int B = pl.B, T = pl.T;
+    const size_t mel_n = (size_t)B * cfg.n_mel * T, eps_n = (size_t)B * cfg.inter_channels * T;
+    SVOC_TRY(pl.stage.ensure((mel_n + eps_n) * sizeof(float) + (size_t)B * sizeof(int64_t)));
+    SVOC_TRY(reserve(B, T));
+    if (!cap_st) SVOC_HIP(hipStreamCreateWithFlags(&cap_st, hipStreamNonBlocking));
+    float* mel_s = pl.stage.f();
+    float* eps_s = mel_s + mel_n;
+    const int64_t* len_s = reinterpret_cast<const int64_t*>(eps_s + eps_n);
+    long long cl0, ol0, cl1, ol1; double cf0, cf1;
+    const long long nc0 = stats_convs();
+    stats_get(&cl0, &cf0, &ol0);
+    SVOC_HIP(hipStreamBeginCapture(cap_st, hipStreamCaptureModeThreadLocal));
+    const int rc = body(cap_st, mel_s, len_s, pl.has_eps ? eps_s : nullptr, pl.noise, pl.Td, pl.want_zp, B, T);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(cap_st, &graph);
+    stats_get(&cl1, &cf1, &ol1);
+    const long long nc1 = stats_convs();
+    stats_add_bulk(cl0 - cl1, cf0 - cf1, ol0 - ol1, nc0 - nc1);          // the capture pass itself executed nothing
+    if (rc != SVOC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) SVOC_FAIL(SVOC_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    const hipError_t ei = hipGraphInstantiate(&pl.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { pl.exec = nullptr; SVOC_FAIL(SVOC_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
+    pl.conv_launches = cl1 - cl0; pl.conv_flops = cf1 - cf0; pl.other_launches = ol1 - ol0; pl.convs = nc1 - nc0;
+    pl.fp = ws_fingerprint();
+    return SVOC_OK;
   }
 
   int infer(hipStream_t st, const float* mel, const int64_t* lengths, const float* eps, float noise_scale, int max_len, float* o,
             float* x_mask, float* z, float* z_p, float* m_p, float* logs_p, int B, int T) {
-    const int H = cfg.hidden_channels, IC = cfg.inter_channels;
-    const int Tp = pad4(T);
-    const long long hper = (long long)H * Tp, iper = (long long)IC * Tp;
-    SVOC_TRY(ws.ensure((size_t)((2 * hper + 3 * iper + Tp) * B) * sizeof(float)));
-    float* xe = ws.f();                 // masked pre_enc output
-    float* eo = xe + hper * B;          // encoder (WN) output
-    float* mp = eo + hper * B;          // m_p
-    float* lp = mp + iper * B;          // logs_p
-    float* P = lp + iper * B;           // z_p, then z (flows run in place)
-    float* mask = P + iper * B;         // [B][Tp]
-    SVOC_TRY(k_sequence_mask(st, lengths, mask, B, Tp));   // row stride Tp; entries >= T are never read
-    {   // pre_enc 1x1, stored already multiplied by x_mask (models.py:38-42)
-      ConvArgs a = mk_args();
-      set_in(a, mel, (long long)cfg.n_mel * T, T, T);
-      a.Ncols = T; a.mask = mask; a.mask_bs = Tp;
-      set_out(a.out[0], xe, hper, Tp, H, F_OUTMASK);
-      SVOC_TRY(launch_conv(pre_enc, a, B, st));
-    }
-    SVOC_TRY(enc.forward(st, xe, hper, Tp, mask, Tp, nullptr, 0, eo, hper, Tp, B, T));
-    {   // proj -> (m_p, logs_p) * mask, reparameterisation z_p = m_p + eps*exp(logs_p)*noise_scale (models.py:44-46, 336)
-      ConvArgs a = mk_args();
-      set_in(a, eo, hper, Tp, T);
-      a.Ncols = T; a.mask = mask; a.mask_bs = Tp;
-      a.mode = EPI_PROJ;
-      set_out(a.out[0], mp, iper, Tp, IC);
-      a.y2 = lp; a.y3 = P;
-      a.eps = eps; a.eps_bs = (long long)IC * T; a.eps_ld = T; a.noise_scale = noise_scale;
-      SVOC_TRY(launch_conv(proj, a, B, st));
-    }
-    const long long ubs = (long long)IC * T;
-    if (m_p) SVOC_TRY(k_copy2d(st, mp, iper, Tp, m_p, ubs, T, B, IC, T, nullptr, 0));
-    if (logs_p) SVOC_TRY(k_copy2d(st, lp, iper, Tp, logs_p, ubs, T, B, IC, T, nullptr, 0));
-    if (z_p) SVOC_TRY(k_copy2d(st, P, iper, Tp, z_p, ubs, T, B, IC, T, nullptr, 0));
-    SVOC_TRY(flow.run_inplace(st, P, iper, Tp, mask, Tp, nullptr, 0, 1, B, T));
-    if (flow.NF % 2) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "synth: odd n_flows is not supported on the fused path");
-    if (z) SVOC_TRY(k_copy2d(st, P, iper, Tp, z, ubs, T, B, IC, T, nullptr, 0));
-    if (x_mask) SVOC_TRY(k_copy2d(st, mask, Tp, Tp, x_mask, T, T, B, 1, T, nullptr, 0));
     const int Td = (max_len > 0 && max_len < T) ? max_len : T;
-    // dec((z * x_mask)[:, :, :max_len]) (models.py:338)
-    return dec.forward(st, P, Tp, iper, mask, Tp, nullptr, o, B, Td);
+    const bool want_zp = z_p != nullptr;
+    Plan* pl = nullptr;
+    if ((long long)B * T <= graph_max_frames() && !prof_enabled()) {
+      for (auto& q : plans)
+        if (q->B == B && q->T == T && q->Td == Td && q->noise == noise_scale && q->has_eps == (eps != nullptr) && q->want_zp == want_zp) pl = q.get();
+      if (!pl) {
+        if (plans.size() >= 16) {   // evict the least recently used plan (its graph may still be executing: wait for it)
+          size_t v = 0;
+          for (size_t i = 1; i < plans.size(); ++i) if (plans[i]->last_use < plans[v]->last_use) v = i;
+          SVOC_HIP(hipDeviceSynchronize());
+          plans.erase(plans.begin() + v);
+        }
+        plans.emplace_back(new Plan());
+        pl = plans.back().get();
+        pl->B = B; pl->T = T; pl->Td = Td; pl->noise = noise_scale; pl->has_eps = eps != nullptr; pl->want_zp = want_zp;
+      }
+      pl->last_use = ++use_clock;
+      ++pl->seen;
+    }
+    if (pl && pl->seen >= 2) {
+      if (pl->exec && pl->fp != ws_fingerprint()) { (void)hipGraphExecDestroy(pl->exec); pl->exec = nullptr; }
+      if (!pl->exec) {
+        const int rc = capture(*pl, st);
+        if (rc != SVOC_OK) { pl->seen = -(1 << 30); pl = nullptr; }      // capture unavailable: stay on direct launches
+      }
+      if (pl && pl->exec) {
+        const size_t mel_n = (size_t)B * cfg.n_mel * T, eps_n = (size_t)B * cfg.inter_channels * T;
+        float* mel_s = pl->stage.f();
+        float* eps_s = mel_s + mel_n;
+        SVOC_HIP(hipMemcpyAsync(mel_s, mel, mel_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (eps) SVOC_HIP(hipMemcpyAsync(eps_s, eps, eps_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        SVOC_HIP(hipMemcpyAsync(eps_s + eps_n, lengths, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        SVOC_HIP(hipGraphLaunch(pl->exec, st));
+        stats_add_bulk(pl->conv_launches, pl->conv_flops, pl->other_launches, pl->convs);
+        return tail(st, o, x_mask, z, z_p, m_p, logs_p, Td, B, T);
+      }
+    }
+    SVOC_TRY(body(st, mel, lengths, eps, noise_scale, Td, want_zp, B, T));
+    return tail(st, o, x_mask, z, z_p, m_p, logs_p, Td, B, T);
   }
 };
 
@@ -704,6 +870,7 @@ struct svoc_flow { Flow m; };
 struct svoc_generator { Generator m; };
 struct svoc_synth { Synth m; };
 struct svoc_posterior { Posterior m; };
+struct svoc_mel_encoder { Posterior m; };
 
 #define SVOC_GUARD_BEGIN try {
 #define SVOC_GUARD_END } catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
@@ -839,6 +1006,12 @@ int svoc_synth_infer(svoc_synth* h, void* stream, const float* mel, const int64_
   SVOC_GUARD_END
 }
 int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T) { return h ? h->m.workspace_bytes(B, T) : 0; }
+int svoc_synth_reserve(svoc_synth* h, int B, int T) {
+  if (!h || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_synth_reserve: bad arguments");
+  SVOC_GUARD_BEGIN
+  return h->m.reserve(B, T);
+  SVOC_GUARD_END
+}
 int svoc_synth_hop(svoc_synth* h) { return h ? h->m.dec.hop : 0; }
 void svoc_synth_destroy(svoc_synth* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
 
@@ -863,6 +1036,30 @@ int svoc_posterior_forward(svoc_posterior* h, void* stream, const float* x, cons
   SVOC_GUARD_END
 }
 void svoc_posterior_destroy(svoc_posterior* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+
+int svoc_mel_encoder_create(svoc_mel_encoder** out, int n_mel, int out_channels, int hidden_channels, int kernel_size,
+                            int dilation_rate, int n_layers, int gin_channels, const svoc_tensor* tensors, int n_tensors,
+                            const char* prefix) {
+  if (!out || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_mel_encoder_create: null argument");
+  *out = nullptr;
+  SVOC_GUARD_BEGIN
+  std::unique_ptr<svoc_mel_encoder> h(new svoc_mel_encoder());
+  TensorTable tab(tensors, n_tensors);
+  SVOC_TRY(h->m.create(n_mel, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, tab,
+                       prefix ? prefix : "", nullptr, "pre_enc", "encoder."));
+  *out = h.release();
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_mel_encoder_forward(svoc_mel_encoder* h, void* stream, const float* x, const int64_t* lengths, float* x_out, float* m,
+                             float* logs, float* x_mask, int B, int T) {
+  if (!h || !x || !lengths || !m || !logs || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_mel_encoder_forward: bad arguments");
+  SVOC_GUARD_BEGIN
+  // g is overwritten with None by the reference (models.py:36)
+  return h->m.forward(as_stream(stream), x, lengths, nullptr, 0, nullptr, nullptr, m, logs, x_mask, B, T, x_out);
+  SVOC_GUARD_END
+}
+void svoc_mel_encoder_destroy(svoc_mel_encoder* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
 
 // ---- diagnostics: device buffer ([workgroup][8] int64, zeroed by the caller) that resblock_fused_kernel fills with its
 // phase cycle stamps; NULL switches the stamps off

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
+#include <set>
 
 namespace svoc {
 
@@ -15,6 +17,29 @@ namespace svoc {
 int xcd_mapping_enabled() {
   static const int on = !(getenv("SVOC_XCD") && atoi(getenv("SVOC_XCD")) == 0);
   return on;
+}
+
+static std::mutex g_dev_mu;
+int device_cu_count() {
+  static int cus[64] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 256;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (cus[d] == 0) {
+    int n = 0;
+    cus[d] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[d];
+}
+int ensure_max_dyn_lds(const void* kernel) {
+  static std::set<std::pair<const void*, int>> done;
+  int d = 0;
+  SVOC_HIP(hipGetDevice(&d));
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (done.count({kernel, d})) return SVOC_OK;
+  SVOC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done.insert({kernel, d});
+  return SVOC_OK;
 }
 
 static long long* g_stamp_buffer = nullptr;
@@ -32,15 +57,24 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
-static std::atomic<long long> g_conv_launches{0}, g_other_launches{0};
+static std::atomic<long long> g_conv_launches{0}, g_other_launches{0}, g_convs{0};
 static std::atomic<double> g_conv_flops{0.0};
-void stats_add_conv(double flops) {
+long long stats_convs() { return g_convs.load(); }
+void stats_add_conv(double flops, int nconv) {
   g_conv_launches.fetch_add(1, std::memory_order_relaxed);
+  g_convs.fetch_add(nconv, std::memory_order_relaxed);
   double cur = g_conv_flops.load(std::memory_order_relaxed);
   while (!g_conv_flops.compare_exchange_weak(cur, cur + flops, std::memory_order_relaxed)) {}
 }
 void stats_add_other() { g_other_launches.fetch_add(1, std::memory_order_relaxed); }
-void stats_reset() { g_conv_launches = 0; g_other_launches = 0; g_conv_flops = 0.0; }
+void stats_add_bulk(long long cl, double cf, long long ol, long long nc) {
+  g_conv_launches.fetch_add(cl, std::memory_order_relaxed);
+  g_convs.fetch_add(nc, std::memory_order_relaxed);
+  g_other_launches.fetch_add(ol, std::memory_order_relaxed);
+  double cur = g_conv_flops.load(std::memory_order_relaxed);
+  while (!g_conv_flops.compare_exchange_weak(cur, cur + cf, std::memory_order_relaxed)) {}
+}
+void stats_reset() { g_conv_launches = 0; g_other_launches = 0; g_conv_flops = 0.0; g_convs = 0; }
 void stats_get(long long* cl, double* cf, long long* ol) {
   if (cl) *cl = g_conv_launches.load();
   if (cf) *cf = g_conv_flops.load();
@@ -298,7 +332,7 @@ int k_fill(hipStream_t st, float* p, size_t n, float v) {
 
 extern "C" {
 const char* svoc_last_error(void) { return svoc::last_error(); }
-int svoc_abi_version(void) { return 1; }
+int svoc_abi_version(void) { return 2; }
 const char* svoc_build_arch(void) { return "gfx950"; }
 int svoc_stats_reset(void) { svoc::stats_reset(); return SVOC_OK; }
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches) {
@@ -309,6 +343,7 @@ int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_la
   if (other_launches) *other_launches = ol;
   return SVOC_OK;
 }
+int64_t svoc_stats_convolutions(void) { return svoc::stats_convs(); }
 int svoc_profile_enable(int on) { svoc::prof_enable(on != 0); return SVOC_OK; }
 int svoc_profile_report(char* buf, int buflen) {
   if (!buf || buflen <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_profile_report: bad buffer");

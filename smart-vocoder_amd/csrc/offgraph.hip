@@ -28,6 +28,7 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 // [optional depthwise dilated conv on x*mask] -> LayerNorm over channels -> GELU [-> x += . ; * mask]
 //   MODE 0: y = gelu(LN(dwconv(x*mask)))                      (modules.py:99-101)
 //   MODE 1: x = x + gelu(LN(y_in)); if last: x *= mask        (modules.py:103-108)
+//   MODE 2: y = LN(x)   (standalone modules.LayerNorm.forward, modules.py:28-32; mask unused)
 // One block owns TT time steps x all C channels; the tile lives in LDS between the passes.
 template <int MODE>
 __global__ void __launch_bounds__(256) dds_ln_gelu_kernel(const float* __restrict__ src, long long s_bs, int s_ld,
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(256) dds_ln_gelu_kernel(const float* __restric
   const int t = t0 + tl;
   const bool tv = t < T;
   const float* sb = src + (long long)b * s_bs;
-  const float* mb = mask + (long long)b * mask_bs;
+  const float* mb = MODE == 2 ? nullptr : mask + (long long)b * mask_bs;
   float s1 = 0.f;
   for (int c = cg; c < C; c += ncg) {
     float v = 0.f;
@@ -83,11 +84,12 @@ __global__ void __launch_bounds__(256) dds_ln_gelu_kernel(const float* __restric
   const float rstd = 1.0f / sqrtf(var + eps);
   if (!tv) return;
   float* db = dst + (long long)b * d_bs;
-  const float mk = mb[t];
+  const float mk = MODE == 2 ? 1.0f : mb[t];
   for (int c = cg; c < C; c += ncg) {
-    const float v = gelu_erf((tile[(size_t)c * TT + tl] - mean) * rstd * gamma[c] + beta[c]);
+    const float ln = (tile[(size_t)c * TT + tl] - mean) * rstd * gamma[c] + beta[c];
+    const float v = MODE == 2 ? ln : gelu_erf(ln);
     float* dp = db + (long long)c * d_ld + t;
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
       *dp = v;
     } else {
       float r = *dp + v;
@@ -97,13 +99,16 @@ __global__ void __launch_bounds__(256) dds_ln_gelu_kernel(const float* __restric
   }
 }
 
-__global__ void add2d_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ dst, long long d_bs,
-                             int d_ld, int rows, int T) {
+// dst = a (+ g): a [B][rows][a_ld] strided, g NULL or [B][rows][g_T] contiguous with g_T == T or 1 (broadcast over time,
+// the speaker-embedding case of DDSConv's `x = x + g`, modules.py:97-98)
+__global__ void add2d_kernel(const float* __restrict__ a, long long a_bs, int a_ld, const float* __restrict__ g, int g_T,
+                             float* __restrict__ dst, long long d_bs, int d_ld, int rows, int T) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
-  const long long i = ((long long)b * rows + r) * T + t;
-  dst[(long long)b * d_bs + (long long)r * d_ld + t] = a[i] + (g ? g[i] : 0.f);
+  float v = a[(long long)b * a_bs + (long long)r * a_ld + t];
+  if (g) v += g[((long long)b * rows + r) * g_T + (g_T == 1 ? 0 : t)];
+  dst[(long long)b * d_bs + (long long)r * d_ld + t] = v;
 }
 
 struct DDS {
@@ -147,9 +152,10 @@ struct DDS {
     return tt;
   }
 
-  // x [B][C][x_ld] -> y [B][C][y_ld]; g nullable, contiguous [B][C][T]
-  int forward(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs, const float* g,
+  // x [B][C][x_ld] -> y [B][C][y_ld]; g nullable, contiguous [B][C][g_T], g_T == T or 1
+  int forward(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs, const float* g, int g_T,
               float* y, long long y_bs, int y_ld, int B, int T) {
+    if (g && g_T != 1 && g_T != T) SVOC_FAIL(SVOC_ERR_SHAPE, "DDSConv: g must have 1 or T=%d frames, got %d", T, g_T);
     const int Tp = round_up(T, 4);
     const long long per = (long long)C * Tp;
     SVOC_TRY(ws.ensure((size_t)(3 * per * B) * sizeof(float)));
@@ -160,14 +166,9 @@ struct DDS {
     const size_t lds = ((size_t)C * TT + 512) * sizeof(float);
     if (lds > 64 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "DDSConv: %d channels do not fit the LayerNorm tile", C);
     // xw = x (+ g)
-    if (x_ld == T && x_bs == (long long)C * T) {
-      hipLaunchKernelGGL(add2d_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, st, x, g, xw, per, Tp, C, T);
-      SVOC_HIP(hipGetLastError());
-      stats_add_other();
-    } else {
-      if (g) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "DDSConv: g with a strided input");
-      SVOC_TRY(k_copy2d(st, x, x_bs, x_ld, xw, per, Tp, B, C, T, nullptr, 0));
-    }
+    hipLaunchKernelGGL(add2d_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, st, x, x_bs, x_ld, g, g_T, xw, per, Tp, C, T);
+    SVOC_HIP(hipGetLastError());
+    stats_add_other();
     int d = 1;
     for (int i = 0; i < NL; ++i) {
       const float* P = params.f() + stride() * i;
@@ -202,10 +203,12 @@ __device__ __forceinline__ float softplus_f(float v) { return v > 20.0f ? v : lo
 
 struct SplineOut { float y, lad; };
 
+struct SplineMin { float w, h, d; };     // min_bin_width / min_bin_height / min_derivative (transforms.py:7-9, 20-22)
+
 template <class LoadW, class LoadH, class LoadD>
 __device__ SplineOut rq_spline_elem(float x, int nb, bool inverse, float left, float right, float bottom, float top,
-                                    LoadW lw, LoadH lh, LoadD ld_) {
-  const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+                                    LoadW lw, LoadH lh, LoadD ld_, SplineMin mn = SplineMin{1e-3f, 1e-3f, 1e-3f}) {
+  const float min_w = mn.w, min_h = mn.h, min_d = mn.d;
   float cw[MAXB + 1], chh[MAXB + 1];
   {   // knots from softmax widths / heights
     float mx = -INFINITY;
@@ -278,7 +281,7 @@ __device__ SplineOut rq_spline_elem(float x, int nb, bool inverse, float left, f
 // derivative loader for linear tails: index 0 and nb are the constant log(exp(1-1e-3)-1) (transforms.py:72-75)
 __global__ void rq_spline_kernel(const float* __restrict__ x, const float* __restrict__ uw, const float* __restrict__ uh,
                                  const float* __restrict__ ud, long long n, int nb, int inverse, int linear_tails, float bound,
-                                 float tail_const, float* __restrict__ y, float* __restrict__ lad) {
+                                 float tail_const, SplineMin mn, float* __restrict__ y, float* __restrict__ lad) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const float xv = x[e];
@@ -289,7 +292,7 @@ __global__ void rq_spline_kernel(const float* __restrict__ x, const float* __res
   const float lo = linear_tails ? -bound : 0.f, hi = linear_tails ? bound : 1.f;
   SplineOut o = rq_spline_elem(
       xv, nb, inverse != 0, lo, hi, lo, hi, [&](int k) { return pw[k]; }, [&](int k) { return ph[k]; },
-      [&](int k) { return linear_tails ? ((k == 0 || k == nb) ? tail_const : pd[k - 1]) : pd[k]; });
+      [&](int k) { return linear_tails ? ((k == 0 || k == nb) ? tail_const : pd[k - 1]) : pd[k]; }, mn);
   y[e] = o.y;
   lad[e] = o.lad;
 }
@@ -330,7 +333,8 @@ __global__ void convflow_spline_kernel(const float* __restrict__ x, const float*
   }
 }
 
-static float tail_constant() { return (float)std::log(std::exp(1.0 - 1e-3) - 1.0); }
+// boundary derivative of the linear tails: softplus(c) + min_derivative == 1 (transforms.py:73)
+static float tail_constant(double min_derivative = 1e-3) { return (float)std::log(std::exp(1.0 - min_derivative) - 1.0); }
 
 struct ConvFlow {
   int Cin = 0, half = 0, F = 0, K = 0, NL = 0, nb = 10;
@@ -351,7 +355,8 @@ struct ConvFlow {
     return SVOC_OK;
   }
 
-  int forward(hipStream_t st, const float* x, const float* mask, const float* g, int reverse, float* y, float* logdet, int B, int T) {
+  // g: NULL or [B][F][g_T] (g_T == 1 or T), added to pre(x0) inside DDSConv (modules.py:365-366 -> 97-98)
+  int forward(hipStream_t st, const float* x, const float* mask, const float* g, int g_T, int reverse, float* y, float* logdet, int B, int T) {
     const int Tp = round_up(T, 4);
     const long long fper = (long long)F * Tp;
     const int P = half * (3 * nb - 1);
@@ -366,8 +371,7 @@ struct ConvFlow {
       a.out[0].y = h0; a.out[0].y_bs = fper; a.out[0].y_ld = Tp; a.out[0].nrows = F;
       SVOC_TRY(launch_conv(pre, a, B, st));
     }
-    if (g) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "ConvFlow: g conditioning is not supported");
-    SVOC_TRY(dds.forward(st, h0, fper, Tp, mask, T, nullptr, h1, fper, Tp, B, T));
+    SVOC_TRY(dds.forward(st, h0, fper, Tp, mask, T, g, g_T, h1, fper, Tp, B, T));
     {
       ConvArgs a = mk_args2();
       a.x = h1; a.x_bs = fper; a.x_ld = Tp; a.Lin = T; a.Ncols = T;
@@ -407,11 +411,11 @@ int svoc_dds_create(svoc_dds** out, int channels, int kernel_size, int n_layers,
   return SVOC_OK;
   SVOC_GUARD_END
 }
-int svoc_dds_forward(svoc_dds* h, void* stream, const float* x, const float* x_mask, const float* g, float* y, int B, int T) {
+int svoc_dds_forward(svoc_dds* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T, float* y, int B, int T) {
   if (!h || !x || !x_mask || !y || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_dds_forward: bad arguments");
   SVOC_GUARD_BEGIN
   const long long bs = (long long)h->m.C * T;
-  return h->m.forward(as_stream(stream), x, bs, T, x_mask, T, g, y, bs, T, B, T);
+  return h->m.forward(as_stream(stream), x, bs, T, x_mask, T, g, g_T, y, bs, T, B, T);
   SVOC_GUARD_END
 }
 void svoc_dds_destroy(svoc_dds* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
@@ -428,25 +432,42 @@ int svoc_convflow_create(svoc_convflow** out, int in_channels, int filter_channe
   return SVOC_OK;
   SVOC_GUARD_END
 }
-int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const float* x_mask, const float* g, int reverse, float* y,
-                          float* logdet, int B, int T) {
+int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const float* x_mask, const float* g, int g_T, int reverse,
+                          float* y, float* logdet, int B, int T) {
   if (!h || !x || !x_mask || !y || B <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_convflow_forward: bad arguments");
   SVOC_GUARD_BEGIN
-  return h->m.forward(as_stream(stream), x, x_mask, g, reverse, y, logdet, B, T);
+  return h->m.forward(as_stream(stream), x, x_mask, g, g_T, reverse, y, logdet, B, T);
   SVOC_GUARD_END
 }
 void svoc_convflow_destroy(svoc_convflow* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
 
+/* modules.LayerNorm.forward (modules.py:28-32): layer norm over dim 1 of x [B, C, T] */
+int svoc_layer_norm(void* stream, const float* x, const float* gamma, const float* beta, float eps, float* y, int B, int C, int T) {
+  if (!x || !gamma || !beta || !y || B <= 0 || C <= 0 || T <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_layer_norm: bad arguments");
+  int TT = 64;
+  while (TT > 1 && ((size_t)C * TT + 512) * sizeof(float) > 64 * 1024) TT >>= 1;
+  const size_t lds = ((size_t)C * TT + 512) * sizeof(float);
+  if (lds > 64 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "LayerNorm: %d channels do not fit the tile", C);
+  const long long bs = (long long)C * T;
+  hipLaunchKernelGGL(dds_ln_gelu_kernel<2>, dim3((T + TT - 1) / TT, B), dim3(256), lds, as_stream(stream), x, bs, T, nullptr, 0,
+                     nullptr, nullptr, 1, 1, gamma, beta, eps, y, bs, T, C, T, TT, 0);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
 int svoc_rq_spline(void* stream, const float* inputs, const float* unnorm_widths, const float* unnorm_heights,
                    const float* unnorm_derivs, int64_t n, int num_bins, int inverse, int linear_tails, float tail_bound,
-                   float* outputs, float* logabsdet) {
+                   float min_bin_width, float min_bin_height, float min_derivative, float* outputs, float* logabsdet) {
+  if (min_bin_width * num_bins > 1.0f) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "Minimal bin width too large for the number of bins");
+  if (min_bin_height * num_bins > 1.0f) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "Minimal bin height too large for the number of bins");
   if (!inputs || !unnorm_widths || !unnorm_heights || !unnorm_derivs || !outputs || !logabsdet || n < 0 || num_bins <= 0 ||
       num_bins > MAXB)
     SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_rq_spline: bad arguments (num_bins must be in 1..%d)", MAXB);
   if (n == 0) return SVOC_OK;
   hipLaunchKernelGGL(rq_spline_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, as_stream(stream), inputs, unnorm_widths,
-                     unnorm_heights, unnorm_derivs, (long long)n, num_bins, inverse, linear_tails, tail_bound, tail_constant(),
-                     outputs, logabsdet);
+                     unnorm_heights, unnorm_derivs, (long long)n, num_bins, inverse, linear_tails, tail_bound,
+                     tail_constant(min_derivative), SplineMin{min_bin_width, min_bin_height, min_derivative}, outputs, logabsdet);
   SVOC_HIP(hipGetLastError());
   stats_add_other();
   return SVOC_OK;

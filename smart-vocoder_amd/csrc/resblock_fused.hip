@@ -459,14 +459,14 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
   if (lds > 160 * 1024) return 1;
   const int ntn = (L + a.n2 - 1) / a.n2;
   dim3 grid(ntn, 1, B);
-  stats_add_conv((c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L);
+  stats_add_conv((c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L, 2);
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
     snprintf(d, sizeof(d), "fusedRB C%-4d k%-2d d%-2d N%-7d B%-3d NA%d", C, k, c1.dil, L, B, NA);
     prof_idx = prof_begin(st, d, (c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L);
   }
-  static const int ncu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  const int ncu = device_cu_count();
   static const bool ws_on = getenv("SVOC_FUSE_WS") && atoi(getenv("SVOC_FUSE_WS")) != 0;   // opt-in: measured at parity
   const long long total_tiles = (long long)ntn * B;
   const int xslots = (C * (a.xrow / 4) + 255) / 256;        // float4 per loader lane
@@ -477,24 +477,20 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
     a.dbg = nullptr;
     if (C == 32) {
       auto kern = resblock_fused_ws_kernel<1, 4, 2, 10>;
-      static bool attr = false;
-      if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
       hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, a, ntn, (int)total_tiles);
     } else {
       auto kern = resblock_fused_ws_kernel<2, 2, 2, 12>;
-      static bool attr = false;
-      if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
       hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, a, ntn, (int)total_tiles);
     }
   } else if (C == 32) {
     auto kern = resblock_fused_kernel<1, 4, 2>;
-    static bool attr = false;
-    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   } else {
     auto kern = resblock_fused_kernel<2, 2, 2>;
-    static bool attr = false;
-    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   }
   prof_end(st, prof_idx);

@@ -146,11 +146,13 @@ __device__ __forceinline__ int xcd_linear(int lin, int total, int on) {
 }
 #endif
 int xcd_mapping_enabled();   // misc_kernels.hip
+// Per-device launch prerequisites (misc_kernels.hip).  A process may drive several GPUs (one handle per device), so
+// neither the compute-unit count nor "this kernel may use 160 KiB of dynamic LDS" can live in a function-local static.
+int device_cu_count();                       // compute units of the CURRENT device (cached per device)
+int ensure_max_dyn_lds(const void* kernel);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB) once per (kernel, device)
 
 struct ConvGroup { ConvArgs a[3]; int end[3]; };     // conv_group_kernel: end[i] = first workgroup id after problem i
 int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, int B, hipStream_t st);   // 1 = not eligible
-int launch_conv_ws(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);   // conv_ws.hip; 1 = not eligible
-int launch_conv_ws2(ConvArgs& a, int B, int WM, int WN, int MR, int NR, hipStream_t st);  // two consumer sets; 1 = not eligible
 
 // resblock_fused.hip: one ResBlock1 iteration (c1 -> lrelu -> c2 -> + x) in one kernel; returns 1 when not eligible
 void set_debug_stamp_buffer(long long* p);
@@ -180,8 +182,11 @@ int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int h
 bool prof_enabled();
 int prof_begin(hipStream_t st, const std::string& desc, double flops);
 void prof_end(hipStream_t st, int idx);
-void stats_add_conv(double flops);
+void stats_add_conv(double flops, int nconv = 1);   // one GEMM-family kernel launch computing nconv convolutions
 void stats_add_other();
+void stats_get(long long* conv_launches, double* conv_flops, long long* other_launches);
+void stats_add_bulk(long long conv_launches, double conv_flops, long long other_launches, long long convs);   // replay of a captured plan
+long long stats_convs();
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

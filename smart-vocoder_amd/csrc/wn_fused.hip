@@ -452,7 +452,7 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   a.H = H; a.ktaps = in_l.ktaps; a.nchunks = H / KC; a.npairs = npairs; a.T = T;
   a.first = first; a.last = last;
   // narrow tiles when there are few columns: every CU should get a workgroup
-  static const int ncu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  const int ncu = device_cu_count();
   const int NR = ((long long)B * ((T + 63) / 64) >= 2LL * ncu) ? 2 : 1;
   const int NA = NR * 32;
   const int minoff = -in_l.pad, maxoff = (in_l.ktaps - 1) * in_l.dil - in_l.pad;
@@ -467,7 +467,7 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   if (lds > 160 * 1024) return 1;
   dim3 grid((T + NA - 1) / NA, 1, B);
   const double flops = (in_l.flops_per_col + rs_l.flops_per_col) * (double)B * (double)T;
-  stats_add_conv(flops);
+  stats_add_conv(flops, 2);
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
@@ -476,18 +476,15 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   }
   if (ksplit) {
     auto kern = wn_layer_fused_ks_kernel;
-    static bool attr = false;
-    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, grid, dim3(2 * npairs * 64), lds, st, a);
   } else if (NR == 2) {
     auto kern = wn_layer_fused_kernel<2>;
-    static bool attr = false;
-    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, grid, dim3(npairs * 64), lds, st, a);
   } else {
     auto kern = wn_layer_fused_kernel<1>;
-    static bool attr = false;
-    if (!attr) { SVOC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, grid, dim3(npairs * 64), lds, st, a);
   }
   prof_end(st, prof_idx);

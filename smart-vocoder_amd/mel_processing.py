@@ -44,6 +44,17 @@ def _handle(n_fft, hop_size, win_size, num_mels, sampling_rate, fmin, fmax, devi
     return h
 
 
+def _to_gpu(t):
+    """The reference notebook (inference.ipynb cell 4) calls these functions on CPU tensors and moves the mel to the GPU
+    afterwards.  The DFT / mel kernels run only on the GPU: host tensors are moved to the current device for the call and
+    the result is returned on the caller's device, so the notebook cell runs unchanged."""
+    N.require_gpu()
+    src = t.device
+    if not t.is_cuda:
+        t = t.cuda()
+    return N.f32(t), src
+
+
 def _check_range(y):
     if torch.min(y) < -1.:
         print('min value is ', torch.min(y))
@@ -55,42 +66,45 @@ def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False)
     """y [B, samples] in [-1, 1] -> magnitude spectrogram [B, n_fft/2+1, frames] (reference mel_processing.py:51-70)."""
     if center:
         raise NotImplementedError("center=True is not used by the reference and not built")
-    y = N.f32(y)
+    y, src = _to_gpu(y)
     _check_range(y)
     B, Lw = y.shape
     h = _handle(n_fft, hop_size, win_size, 80, sampling_rate, 0.0, None, y.device)
     F = N.lib().svoc_melspec_frames(h.h, Lw)
     spec = torch.empty(B, n_fft // 2 + 1, F, dtype=torch.float32, device=y.device)
-    N.check(N.lib().svoc_melspec_spectrogram(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, N.ptr(spec)))
-    return spec
+    with torch.cuda.device(y.device):
+        N.check(N.lib().svoc_melspec_spectrogram(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, N.ptr(spec)))
+    return spec.to(src)
 
 
 def spec_to_mel_torch(spec, n_fft, num_mels, sampling_rate, fmin, fmax):
     """spec [B, n_fft/2+1, F] -> log-mel [B, num_mels, F] (reference mel_processing.py:73-82)."""
-    spec = N.f32(spec)
+    spec, src = _to_gpu(spec)
     B, nb, F = spec.shape
     if nb != n_fft // 2 + 1:
         raise ValueError(f"expected {n_fft // 2 + 1} frequency bins, got {nb}")
     h = _handle(n_fft, n_fft // 4, n_fft, num_mels, sampling_rate, fmin, fmax, spec.device)
     mel = torch.empty(B, num_mels, F, dtype=torch.float32, device=spec.device)
-    N.check(N.lib().svoc_melspec_mel(h.h, N.stream_ptr(spec.device), N.ptr(spec), B, F, N.ptr(mel)))
-    return mel
+    with torch.cuda.device(spec.device):
+        N.check(N.lib().svoc_melspec_mel(h.h, N.stream_ptr(spec.device), N.ptr(spec), B, F, N.ptr(mel)))
+    return mel.to(src)
 
 
 def mel_spectrogram_torch(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
     """reference mel_processing.py:85-112"""
     if center:
         raise NotImplementedError("center=True is not used by the reference and not built")
-    y = N.f32(y)
+    y, src = _to_gpu(y)
     _check_range(y)
     B, Lw = y.shape
     h = _handle(n_fft, hop_size, win_size, num_mels, sampling_rate, fmin, fmax, y.device)
     F = N.lib().svoc_melspec_frames(h.h, Lw)
     spec = torch.empty(B, n_fft // 2 + 1, F, dtype=torch.float32, device=y.device)
     mel = torch.empty(B, num_mels, F, dtype=torch.float32, device=y.device)
-    N.check(N.lib().svoc_melspec_spectrogram(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, N.ptr(spec)))
-    N.check(N.lib().svoc_melspec_mel(h.h, N.stream_ptr(y.device), N.ptr(spec), B, F, N.ptr(mel)))
-    return mel
+    with torch.cuda.device(y.device):
+        N.check(N.lib().svoc_melspec_spectrogram(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, N.ptr(spec)))
+        N.check(N.lib().svoc_melspec_mel(h.h, N.stream_ptr(y.device), N.ptr(spec), B, F, N.ptr(mel)))
+    return mel.to(src)
 
 
 def mel_filterbank(sampling_rate, n_fft, num_mels, fmin=0.0, fmax=None):

@@ -17,17 +17,21 @@ try:
     from . import _native as N
     from . import commons, modules
     from .commons import get_padding, init_weights
-    from .modules import _Conv1dParams, _WNConvTranspose1dParams, _HipModule, _fold_in_place, _g_args, _mask_arg
+    from .modules import (_Conv1dParams, _WNConvTranspose1dParams, _HipModule, _fold_in_place, _g_args, _mask_arg,
+                          _check_channels, _same_device)
 except ImportError:
     import _native as N
     import commons
     import modules
     from commons import get_padding, init_weights
-    from modules import _Conv1dParams, _WNConvTranspose1dParams, _HipModule, _fold_in_place, _g_args, _mask_arg
+    from modules import (_Conv1dParams, _WNConvTranspose1dParams, _HipModule, _fold_in_place, _g_args, _mask_arg,
+                         _check_channels, _same_device)
 
 
-class MelEncoder(nn.Module):
-    """reference models.py:15-47.  Runs as part of SynthesizerTrn.infer's single native call."""
+class MelEncoder(_HipModule):
+    """reference models.py:15-47.  Inside SynthesizerTrn.infer it is part of the single native call; called on its own
+    (``net_g.enc_p(mel, lengths)``) it runs the same kernels behind svoc_mel_encoder_forward."""
+    _destroy = "svoc_mel_encoder_destroy"
 
     def __init__(self, out_channels, hidden_channels, filter_channels, n_layers, kernel_size, dilation_rate, gin_channels):
         super().__init__()
@@ -38,12 +42,30 @@ class MelEncoder(nn.Module):
         self.kernel_size = kernel_size
         self.dilation_rate = dilation_rate
         self.encoder = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
+        self.gin_channels = gin_channels
         self.pre_enc = _Conv1dParams(80, hidden_channels, 1)
         self.proj = _Conv1dParams(hidden_channels, out_channels * 2, 1)
 
+    def _create(self, h, tab):
+        N.check(N.lib().svoc_mel_encoder_create(h.out(), 80, self.out_channels, self.hidden_channels, self.kernel_size,
+                                                self.dilation_rate, self.n_layers, self.gin_channels, tab.arr, tab.n, b""))
+
     def forward(self, x, x_lengths, g=None):
-        raise NotImplementedError("MelEncoder runs inside SynthesizerTrn.infer (one fused native call); "
-                                  "use SynthesizerTrn.infer(...)[2] for m_p/logs_p")
+        """-> (x, m, logs, x_mask) like the reference; `g` is discarded there too (models.py:36)."""
+        x = N.f32(x)
+        if x.dim() != 3:
+            raise ValueError(f"expected mel [B, 80, T], got {tuple(x.shape)}")
+        B, Cc, T = x.shape
+        _check_channels("MelEncoder", Cc, 80)
+        ln = x_lengths.to(device=x.device, dtype=torch.int64).contiguous()
+        dev = x.device
+        xo = torch.empty(B, self.hidden_channels, T, dtype=torch.float32, device=dev)
+        m, logs = (torch.empty(B, self.out_channels, T, dtype=torch.float32, device=dev) for _ in range(2))
+        x_mask = torch.empty(B, 1, T, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib().svoc_mel_encoder_forward(self._native(), N.stream_ptr(dev), N.ptr(x), N.ptr(ln), N.ptr(xo), N.ptr(m),
+                                                     N.ptr(logs), N.ptr(x_mask), B, T))
+        return xo, m, logs, x_mask
 
 
 class ResidualCouplingBlock(_HipModule):
@@ -72,11 +94,14 @@ class ResidualCouplingBlock(_HipModule):
     def forward(self, x, x_mask, g=None, reverse=False):
         x = N.f32(x)
         B, Cc, T = x.shape
+        _check_channels("ResidualCouplingBlock", Cc, self.channels)
         m = _mask_arg(x_mask, B, T, x.device)
-        g, gT = _g_args(g, T)
+        g, gT = _g_args(g, T, B, self.gin_channels)
         y = torch.empty_like(x)
-        N.check(N.lib().svoc_flow_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
-                                          1 if reverse else 0, N.ptr(y), B, T))
+        _same_device(x, m, g)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_flow_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
+                                              1 if reverse else 0, N.ptr(y), B, T))
         return y
 
 
@@ -110,7 +135,7 @@ class PosteriorEncoder(_HipModule):
         if Cc != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {Cc}")
         lengths = x_lengths.to(device=x.device, dtype=torch.int64).contiguous()
-        g, gT = modules._g_args(g, T)
+        g, gT = modules._g_args(g, T, B, self.gin_channels)
         if eps is None:
             eps = torch.randn(B, self.out_channels, T, device=x.device, dtype=torch.float32)
         eps = N.f32(eps)
@@ -118,8 +143,10 @@ class PosteriorEncoder(_HipModule):
             raise ValueError(f"eps must be [{B}, {self.out_channels}, {T}], got {tuple(eps.shape)}")
         z, m, logs = (torch.empty(B, self.out_channels, T, device=x.device, dtype=torch.float32) for _ in range(3))
         x_mask = torch.empty(B, 1, T, device=x.device, dtype=torch.float32)
-        N.check(N.lib().svoc_posterior_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(lengths), N.ptr(g), gT,
-                                               N.ptr(eps), N.ptr(z), N.ptr(m), N.ptr(logs), N.ptr(x_mask), B, T))
+        _same_device(x, g, eps)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_posterior_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(lengths), N.ptr(g), gT,
+                                                   N.ptr(eps), N.ptr(z), N.ptr(m), N.ptr(logs), N.ptr(x_mask), B, T))
         return z, m, logs, x_mask
 
 
@@ -184,13 +211,16 @@ class Generator(_HipModule):
     def forward(self, x, g=None):
         x = N.f32(x)
         B, Cc, T = x.shape
+        _check_channels("Generator", Cc, self._cfg_args[0])
         if g is not None:
-            g = N.f32(g)
             if g.dim() != 3 or g.shape[2] != 1:
                 raise ValueError("g must be [B, gin_channels, 1]")
+            g, _ = _g_args(g, T, B, self.gin_channels)
         out = torch.empty(B, 1, T * self.hop, dtype=torch.float32, device=x.device)
-        N.check(N.lib().svoc_generator_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), T, Cc * T, None, 0,
-                                               N.ptr(g), N.ptr(out), B, T))
+        _same_device(x, g)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_generator_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), T, Cc * T, None, 0,
+                                                   N.ptr(g), N.ptr(out), B, T))
         return out
 
     def remove_weight_norm(self):
@@ -238,6 +268,11 @@ class SynthesizerTrn(_HipModule):
     def _state(self):
         return {k: v for k, v in self.state_dict(keep_vars=True).items() if not k.startswith("enc_q.")}
 
+    def _dev(self):
+        p = self.dec.conv_pre.weight
+        N.require_gpu(p)
+        return p.device
+
     def _create(self, h, tab):
         c = N.svoc_synth_config()
         c.n_mel = 80
@@ -277,10 +312,19 @@ class SynthesizerTrn(_HipModule):
         z, z_p, m_p, logs_p = (torch.empty(B, IC, T, dtype=torch.float32, device=dev) for _ in range(4))
         if Td == 0:
             raise ValueError("max_len leaves no frames to decode")
-        N.check(N.lib().svoc_synth_infer(self._native(), N.stream_ptr(dev), N.ptr(x), N.ptr(ln), N.ptr(eps),
-                                         float(noise_scale), Td, N.ptr(o), N.ptr(x_mask), N.ptr(z), N.ptr(z_p),
-                                         N.ptr(m_p), N.ptr(logs_p), B, T))
+        _same_device(x, eps)
+        with torch.cuda.device(dev):
+            N.check(N.lib().svoc_synth_infer(self._native(), N.stream_ptr(dev), N.ptr(x), N.ptr(ln), N.ptr(eps),
+                                             float(noise_scale), Td, N.ptr(o), N.ptr(x_mask), N.ptr(z), N.ptr(z_p),
+                                             N.ptr(m_p), N.ptr(logs_p), B, T))
         return o, x_mask, (z, z_p, m_p, logs_p)
+
+    def reserve(self, batch, frames):
+        """Extension: size the library's workspaces for batches up to [batch, 80, frames] now, so that later ``infer``
+        calls neither allocate nor synchronise (svoc_synth_reserve)."""
+        with torch.cuda.device(self._dev()):
+            N.check(N.lib().svoc_synth_reserve(self._native(), int(batch), int(frames)))
+        return self
 
     # receptive half-width of the whole path in mel frames: encoder WN 16*2 + flow 4*8*2 + decoder (conv_pre 3,
     # and <= 60/8 + 60/64 + 60/128 + 60/256 + upsampler taps) -- 128 covers it with margin (SURVEY.md §7)
@@ -289,8 +333,10 @@ class SynthesizerTrn(_HipModule):
     def infer_chunked(self, x, x_lengths, chunk_frames=1024, noise_scale=1, eps=None, halo_frames=None):
         """Long-form inference by time tiling: the mel is cut into chunks of `chunk_frames`, each is
         run with `halo_frames` of real context on both sides, and only the interior samples are kept.  With a halo
-        of at least RECEPTIVE_FRAMES the result equals one-shot `infer` (every output sample sees the same inputs in
-        the same summation order), while the activation workspace stays bounded by the chunk size.
+        of at least RECEPTIVE_FRAMES every output sample sees exactly the inputs it sees in one-shot `infer`, so the
+        result equals it up to fp32 summation order (the library picks tile shapes / K splits from the batch and
+        length, e.g. the K-split WN kernel for short chunks, so the two are not guaranteed bit-identical: the test
+        bounds the difference at 1e-5 absolute), while the activation workspace stays bounded by the chunk size.
         Returns the waveform [B, 1, T*hop] only."""
         x = N.f32(x)
         B, _, T = x.shape

@@ -81,8 +81,9 @@ def _fold_tensor(weight_v, weight_g):
     v = N.f32(weight_v.detach())
     g = N.f32(weight_g.detach())
     w = torch.empty_like(v)
-    N.check(N.lib().svoc_fold_weight_norm(N.stream_ptr(v.device), N.ptr(v), N.ptr(g), N.ptr(w), v.shape[0],
-                                          v[0].numel()))
+    with torch.cuda.device(v.device):
+        N.check(N.lib().svoc_fold_weight_norm(N.stream_ptr(v.device), N.ptr(v), N.ptr(g), N.ptr(w), v.shape[0],
+                                              v[0].numel()))
     return w
 
 
@@ -98,10 +99,43 @@ def _fold_in_place(m):
     _STRUCT_EPOCH[0] += 1          # every cached tensor list is rebuilt on next use
 
 
+def _check_channels(what, got, want):
+    """The reference raises a conv shape error on a wrong channel count; the library derives strides from its own
+    configuration, so a mismatch must be refused here (it would read or write out of bounds on the device)."""
+    if got != want:
+        raise ValueError(f"{what}: expected {want} channels, got {got}")
+
+
 class _HipModule(nn.Module):
-    """Caches the library handle built from this module's parameters."""
+    """Caches the library handle built from this module's parameters.
+
+    Change detection: the handle is rebuilt when a parameter is replaced (``.cuda()``, ``load_state_dict``,
+    ``remove_weight_norm``) or modified in place through autograd-visible ops (``Parameter._version``).  Writes that
+    bypass the version counter (``p.data.copy_()``, ``p.data = ...`` after the first forward) are NOT seen: call
+    ``invalidate()`` afterwards.  Handles are per process and per device; ``copy.deepcopy`` / pickling drop them.
+    """
 
     _destroy = None
+
+    def invalidate(self):
+        """Drop every cached library handle below this module (weights are re-folded and re-packed on next use)."""
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m._invalidate()
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        for k in ("_nh", "_nh_sig", "_nh_tensors", "_nh_epoch"):
+            d.pop(k, None)
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            object.__setattr__(new, k, copy.deepcopy(v, memo))
+        return new
 
     def _state(self):
         """{state_dict key: tensor} handed to the library (parameters only; subclasses may filter)."""
@@ -141,7 +175,14 @@ class _HipModule(nn.Module):
                 m._invalidate()
         return r
 
+    def _dev(self):
+        p = next(self.parameters())
+        N.require_gpu(p)
+        return p.device
+
     def _native(self):
+        """Library handle (created on first use).  Call inside ``with torch.cuda.device(self._dev())``: the library
+        allocates and launches on the CURRENT device."""
         N.require_gpu(next(self.parameters()))
         sig = self._sig()
         if self.__dict__.get("_nh") is None or self.__dict__.get("_nh_sig") != sig:
@@ -151,8 +192,9 @@ class _HipModule(nn.Module):
             sig = self._sig()
             h = N.Handle(self._destroy)
             tab = self._table()
-            self._create(h, tab)
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.device(self._dev()):
+                self._create(h, tab)
+                torch.cuda.current_stream().synchronize()
             object.__setattr__(self, "_nh", h)
             object.__setattr__(self, "_nh_sig", sig)
         return self._nh.h
@@ -165,13 +207,27 @@ class _HipModule(nn.Module):
             raise NotImplementedError("dropout (training mode) is outside the inference path; call .eval()")
 
 
-def _g_args(g, T):
+def _g_args(g, T, B=None, gin=None):
     if g is None:
         return None, 0
     g = N.f32(g)
     if g.dim() != 3 or g.shape[2] not in (1, T):
         raise ValueError(f"g must be [B, gin, 1] or [B, gin, {T}], got {tuple(g.shape)}")
+    if gin is not None:
+        if gin == 0:
+            raise N.SvocError("g given but the module was built with gin_channels == 0")
+        _check_channels("g", g.shape[1], gin)
+    if B is not None and g.shape[0] != B:
+        if g.shape[0] != 1:
+            raise ValueError(f"g has batch {g.shape[0]}, expected {B}")
+        g = g.expand(B, g.shape[1], g.shape[2]).contiguous()
     return g, g.shape[2]
+
+
+def _same_device(x, *others):
+    for t in others:
+        if t is not None and t.device != x.device:
+            raise N.SvocError(f"tensors on different devices: {x.device} and {t.device}")
 
 
 def _mask_arg(x_mask, B, T, device):
@@ -185,7 +241,8 @@ def _mask_arg(x_mask, B, T, device):
 
 # ----------------------------------------------------------------------------- LayerNorm / DDSConv
 class LayerNorm(nn.Module):
-    """Parameter container of the channel LayerNorm (reference modules.py:20-32); applied inside DDSConv's kernels."""
+    """Channel LayerNorm (reference modules.py:20-32).  Inside DDSConv it runs fused with the depthwise conv / GELU
+    kernels; the standalone forward is the HIP kernel behind svoc_layer_norm."""
 
     def __init__(self, channels, eps=1e-5):
         super().__init__()
@@ -195,7 +252,21 @@ class LayerNorm(nn.Module):
         self.beta = nn.Parameter(torch.zeros(channels))
 
     def forward(self, x):
-        raise NotImplementedError("LayerNorm runs fused inside DDSConv's HIP kernels; it has no standalone forward")
+        # x.transpose(1, -1) -> F.layer_norm over the last dim -> transpose back == normalise dim 1 at every other index
+        x = N.f32(x)
+        if x.dim() < 2:
+            raise ValueError("LayerNorm expects [B, C, ...]")
+        _check_channels("LayerNorm", x.shape[1], self.channels)
+        B, Cc = x.shape[0], x.shape[1]
+        inner = x[0, 0].numel() if x.dim() > 2 else 1
+        y = torch.empty_like(x)
+        if x.numel() == 0:
+            return y
+        _same_device(x, self.gamma)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_layer_norm(N.stream_ptr(x.device), N.ptr(x), N.ptr(N.f32(self.gamma.detach())),
+                                            N.ptr(N.f32(self.beta.detach())), float(self.eps), N.ptr(y), B, Cc, inner))
+        return y
 
 
 class DDSConv(_HipModule):
@@ -225,11 +296,14 @@ class DDSConv(_HipModule):
         self._check_eval()
         x = N.f32(x)
         B, Cc, T = x.shape
+        _check_channels("DDSConv", Cc, self.channels)
         m = _mask_arg(x_mask, B, T, x.device)
-        if g is not None:
-            g = N.f32(g.expand_as(x))
+        g, gT = _g_args(g, T, B, self.channels)      # `x + g`: g is [B, C, T] or broadcast over time [B, C, 1]
         y = torch.empty_like(x)
-        N.check(N.lib().svoc_dds_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), N.ptr(y), B, T))
+        _same_device(x, m, g)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_dds_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
+                                             N.ptr(y), B, T))
         return y
 
 
@@ -265,11 +339,14 @@ class WN(_HipModule):
         self._check_eval()
         x = N.f32(x)
         B, H, T = x.shape
+        _check_channels("WN", H, self.hidden_channels)
         m = _mask_arg(x_mask, B, T, x.device)
-        g, gT = _g_args(g, T)
+        g, gT = _g_args(g, T, B, self.gin_channels)
         out = torch.empty_like(x)
-        N.check(N.lib().svoc_wn_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
-                                        N.ptr(out), B, T))
+        _same_device(x, m, g)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_wn_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
+                                            N.ptr(out), B, T))
         return out
 
     def remove_weight_norm(self):
@@ -294,9 +371,12 @@ class _ResBlockBase(_HipModule):
     def forward(self, x, x_mask=None):
         x = N.f32(x)
         B, Cc, L = x.shape
+        _check_channels(type(self).__name__, Cc, self.channels)
         m = _mask_arg(x_mask, B, L, x.device) if x_mask is not None else None
         y = torch.empty_like(x)
-        N.check(N.lib().svoc_resblock_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(y), B, L))
+        _same_device(x, m)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_resblock_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(y), B, L))
         return y
 
 
@@ -340,7 +420,8 @@ class Flip(nn.Module):
         x = N.f32(x)
         B, Cc, T = x.shape
         y = torch.empty_like(x)
-        N.check(N.lib().svoc_flip_channels(N.stream_ptr(x.device), N.ptr(x), N.ptr(y), B, Cc, T))
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_flip_channels(N.stream_ptr(x.device), N.ptr(x), N.ptr(y), B, Cc, T))
         if not reverse:
             logdet = torch.zeros(B, dtype=x.dtype, device=x.device)
             return y, logdet
@@ -379,12 +460,15 @@ class ResidualCouplingLayer(_HipModule):
         self._check_eval()
         x = N.f32(x)
         B, Cc, T = x.shape
+        _check_channels("ResidualCouplingLayer", Cc, self.channels)
         m = _mask_arg(x_mask, B, T, x.device)
-        g, gT = _g_args(g, T)
+        g, gT = _g_args(g, T, B, self.gin_channels)
         y = torch.empty_like(x)
         logdet = None if reverse else torch.empty(B, dtype=torch.float32, device=x.device)
-        N.check(N.lib().svoc_coupling_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
-                                              1 if reverse else 0, N.ptr(y), N.ptr(logdet), B, T))
+        _same_device(x, m, g)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_coupling_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
+                                                  1 if reverse else 0, N.ptr(y), N.ptr(logdet), B, T))
         return y if reverse else (y, logdet)
 
 
@@ -414,11 +498,14 @@ class ConvFlow(_HipModule):
     def forward(self, x, x_mask, g=None, reverse=False):
         x = N.f32(x)
         B, Cc, T = x.shape
+        _check_channels("ConvFlow", Cc, self.in_channels)
         m = _mask_arg(x_mask, B, T, x.device)
-        if g is not None:
-            raise NotImplementedError("ConvFlow with g conditioning is not built")
+        # g goes to DDSConv unchanged (reference modules.py:366), i.e. it is added to pre(x0): [B, filter_channels, T or 1]
+        g, gT = _g_args(g, T, B, self.filter_channels)
         y = torch.empty_like(x)
         logdet = None if reverse else torch.empty(B, dtype=torch.float32, device=x.device)
-        N.check(N.lib().svoc_convflow_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), None,
-                                              1 if reverse else 0, N.ptr(y), N.ptr(logdet), B, T))
+        _same_device(x, m, g)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().svoc_convflow_forward(self._native(), N.stream_ptr(x.device), N.ptr(x), N.ptr(m), N.ptr(g), gT,
+                                                  1 if reverse else 0, N.ptr(y), N.ptr(logdet), B, T))
         return y if reverse else (y, logdet)

@@ -26,26 +26,33 @@ def sort_by_length(lengths):
     return order, torch.argsort(order)
 
 
+def _wire_device(device, group=None):
+    """Device the collective runs on: the GPU for RCCL ("nccl"); host memory for gloo (its scatter/gather take CPU
+    tensors), which is how the N>1 path is exercised on a single GPU or on CPU."""
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else device
+
+
 def scatter_batch(tensors, shapes_tail, dtypes, B, src=0, device=None, group=None):
     """Scatter dim-0 chunks of each tensor from `src`.  `tensors` is the list of full tensors on `src`
-    (ignored elsewhere); shapes_tail/dtypes describe them on every rank.  Returns the local chunks."""
+    (ignored elsewhere); shapes_tail/dtypes describe them on every rank.  Returns the local chunks on `device`."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bounds = shard_bounds(B, world)
     nloc = bounds[rank][1] - bounds[rank][0]
     nmax = max(b - a for a, b in bounds)
+    wire = _wire_device(device, group)
     outs = []
     for i, (tail, dt) in enumerate(zip(shapes_tail, dtypes)):
-        recv = torch.empty((nmax,) + tuple(tail), dtype=dt, device=device)
+        recv = torch.empty((nmax,) + tuple(tail), dtype=dt, device=wire)
         chunks = None
         if rank == src:
-            full = tensors[i].to(device)
+            full = tensors[i].to(wire)
             chunks = []
             for a, b in bounds:
-                c = torch.zeros((nmax,) + tuple(tail), dtype=dt, device=device)   # equal-size chunks (scatter needs them)
+                c = torch.zeros((nmax,) + tuple(tail), dtype=dt, device=wire)   # equal-size chunks (scatter needs them)
                 c[: b - a] = full[a:b]
                 chunks.append(c)
         dist.scatter(recv, chunks, src=src, group=group)
-        outs.append(recv[:nloc].contiguous())
+        outs.append(recv[:nloc].to(device).contiguous())
     return outs
 
 
@@ -55,15 +62,17 @@ def gather_waveforms(o_local, B, dst=0, group=None):
     bounds = shard_bounds(B, world)
     nmax = max(b - a for a, b in bounds)
     tail = tuple(o_local.shape[1:])
-    send = o_local
+    dev = o_local.device
+    wire = _wire_device(dev, group)
+    send = o_local.to(wire)
     if o_local.shape[0] != nmax:
-        send = torch.zeros((nmax,) + tail, dtype=o_local.dtype, device=o_local.device)
+        send = torch.zeros((nmax,) + tail, dtype=o_local.dtype, device=wire)
         send[: o_local.shape[0]] = o_local
-    bufs = [torch.empty((nmax,) + tail, dtype=o_local.dtype, device=o_local.device) for _ in range(world)] if rank == dst else None
+    bufs = [torch.empty((nmax,) + tail, dtype=o_local.dtype, device=wire) for _ in range(world)] if rank == dst else None
     dist.gather(send.contiguous(), bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([bufs[i][: b - a] for i, (a, b) in enumerate(bounds)], 0)
+    return torch.cat([bufs[i][: b - a] for i, (a, b) in enumerate(bounds)], 0).to(dev)
 
 
 def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0, group=None):
@@ -71,7 +80,7 @@ def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0
     mel/lengths/eps need to be valid on `src` only (pass shapes via the src tensors broadcast below)."""
     rank = dist.get_rank(group)
     dev = next(net.parameters()).device
-    meta = torch.zeros(3, dtype=torch.int64, device=dev)
+    meta = torch.zeros(3, dtype=torch.int64, device=_wire_device(dev, group))
     if rank == src:
         meta[0], meta[1], meta[2] = mel.shape[0], mel.shape[2], eps.shape[1]
     dist.broadcast(meta, src=src, group=group)

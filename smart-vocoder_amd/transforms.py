@@ -21,10 +21,12 @@ def piecewise_rational_quadratic_transform(inputs, unnormalized_widths, unnormal
     Returns (outputs, logabsdet), both shaped like inputs."""
     if tails not in (None, "linear"):
         raise RuntimeError("{} tails are not implemented.".format(tails))
-    if (min_bin_width, min_bin_height, min_derivative) != (1e-3, 1e-3, 1e-3):
-        raise NotImplementedError("only the reference's default minimum bin width/height/derivative (1e-3) are built in")
     x = N.f32(inputs)
     nb = unnormalized_widths.shape[-1]
+    if min_bin_width * nb > 1.0:           # reference transforms.py:110-113
+        raise ValueError('Minimal bin width too large for the number of bins')
+    if min_bin_height * nb > 1.0:
+        raise ValueError('Minimal bin height too large for the number of bins')
     uw = N.f32(unnormalized_widths).reshape(-1, nb)
     uh = N.f32(unnormalized_heights).reshape(-1, nb)
     nd = nb - 1 if tails == "linear" else nb + 1
@@ -36,7 +38,9 @@ def piecewise_rational_quadratic_transform(inputs, unnormalized_widths, unnormal
         raise ValueError("Input to a transform is not within its domain")
     out = torch.empty_like(x)
     lad = torch.empty_like(x)
-    N.check(N.lib().svoc_rq_spline(N.stream_ptr(x.device), N.ptr(x), N.ptr(uw), N.ptr(uh), N.ptr(ud), n, nb,
-                                   1 if inverse else 0, 1 if tails == "linear" else 0, float(tail_bound),
-                                   N.ptr(out), N.ptr(lad)))
+    with torch.cuda.device(x.device):
+        N.check(N.lib().svoc_rq_spline(N.stream_ptr(x.device), N.ptr(x), N.ptr(uw), N.ptr(uh), N.ptr(ud), n, nb,
+                                       1 if inverse else 0, 1 if tails == "linear" else 0, float(tail_bound),
+                                       float(min_bin_width), float(min_bin_height), float(min_derivative),
+                                       N.ptr(out), N.ptr(lad)))
     return out, lad

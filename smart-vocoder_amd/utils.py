@@ -165,3 +165,36 @@ def load_wav_to_torch(full_path):
     from scipy.io.wavfile import read
     sampling_rate, data = read(full_path)
     return torch.FloatTensor(data.astype(np.float32)), sampling_rate
+
+
+def save_wav(path, sampling_rate, audio):
+    """The notebook's (commented-out) last line, ``write('./generated_files/'+f_name, 22050, audio_)`` (inference.ipynb
+    cell 4), for tensors straight out of ``infer``: `audio` is [samples], [1, samples] or [1, 1, samples] (any device)
+    or a numpy array; written as 32-bit float PCM exactly as scipy writes the notebook's float32 array."""
+    from scipy.io.wavfile import write
+    if isinstance(audio, torch.Tensor):
+        audio = audio.detach().float().cpu().numpy()
+    audio = np.asarray(audio, dtype=np.float32)
+    while audio.ndim > 1 and audio.shape[0] == 1:
+        audio = audio[0]
+    if audio.ndim != 1:
+        raise ValueError(f"expected one utterance, got shape {audio.shape}")
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    write(path, int(sampling_rate), audio)
+    return path
+
+
+def infer_to_wavs(net_g, mel, lengths, out_paths, sampling_rate=22050, chunk_frames=None, **infer_kw):
+    """Long-form convenience: run ``infer`` (or ``infer_chunked`` when `chunk_frames` is given) and write
+    every utterance, cut to its own length, to out_paths[b]."""
+    hop = net_g.dec.hop
+    if chunk_frames:
+        o = net_g.infer_chunked(mel, lengths, chunk_frames=chunk_frames, **infer_kw)
+    else:
+        o = net_g.infer(mel, lengths, **infer_kw)[0]
+    ln = lengths.cpu().tolist()
+    for b, path in enumerate(out_paths):
+        save_wav(path, sampling_rate, o[b, 0, :int(ln[b]) * hop])
+    return o

@@ -106,10 +106,50 @@ CONVFLOW_CASES = {
     "cf_fwd": dict(Cin=2, F=192, k=3, n=3, B=2, T=40, lengths=[40, 25], reverse=False, seed=9002),
     "cf_c4_fwd": dict(Cin=4, F=64, k=3, n=2, B=1, T=33, lengths=[33], reverse=False, seed=9003),
 }
+CONVFLOW_G_CASES = {   # g is handed to DDSConv (reference modules.py:366): [B, filter_channels, 1] or [B, filter_channels, T]
+    "cf_g1_fwd": dict(Cin=2, F=64, k=3, n=2, B=2, T=33, lengths=[33, 20], reverse=False, gT=1, seed=9011),
+    "cf_gT_rev": dict(Cin=4, F=64, k=3, n=2, B=2, T=29, lengths=[29, 11], reverse=True, gT=29, seed=9012),
+}
+LAYERNORM_CASES = {    # standalone modules.LayerNorm.forward (reference modules.py:28-32)
+    "ln_c192": dict(C=192, shape=(2, 192, 45), seed=9201),
+    "ln_c7_4d": dict(C=7, shape=(3, 7, 5, 6), seed=9202),
+}
+MELENC_CASES = {       # standalone MelEncoder.forward (reference models.py:35-47): (out, hidden, n_layers, k, dr, gin)
+    "melenc_small": dict(Cout=16, H=32, n=3, k=5, dr=1, gin=0, B=2, T=41, lengths=[41, 18], seed=9301),
+    "melenc_h192": dict(Cout=192, H=192, n=2, k=5, dr=1, gin=8, B=1, T=30, lengths=[30], seed=9302),
+}
 SPLINE_CASES = {
     "spline_fwd": dict(N=4096, inverse=False, seed=9101),
     "spline_inv": dict(N=4096, inverse=True, seed=9102),
 }
+# tails=None (domain [0,1], transforms.py:23-25 -> rational_quadratic_spline) and non-default minimums (transforms.py:20-22)
+SPLINE_EXTRA_CASES = {
+    "spline_unc_fwd": dict(N=2048, inverse=False, tails=None, mins=(1e-3, 1e-3, 1e-3), seed=9111),
+    "spline_unc_inv": dict(N=2048, inverse=True, tails=None, mins=(1e-3, 1e-3, 1e-3), seed=9112),
+    "spline_min_fwd": dict(N=2048, inverse=False, tails="linear", mins=(1e-2, 5e-3, 2e-2), seed=9113),
+    "spline_min_inv": dict(N=2048, inverse=True, tails="linear", mins=(1e-2, 5e-3, 2e-2), seed=9114),
+    "spline_unc_min_fwd": dict(N=1024, inverse=False, tails=None, mins=(2e-2, 1e-2, 5e-2), seed=9115),
+}
+# a checkpoint written by the REFERENCE's utils.save_checkpoint (reference utils.py:46-56) for the gen_small_rb2 Generator
+REF_CHECKPOINT = dict(file="G_7.pth", case="gen_small_rb2", iteration=7, learning_rate=2e-4)
+
+
+def spline_extra_inputs(case):
+    c = SPLINE_EXTRA_CASES[case]
+    N = c["N"]
+    nb = 10
+    if c["tails"] is None:
+        x = sw.uniform01(c["seed"], "x", N).astype(np.float32)
+        x[:4] = np.array([0.0, 1.0, 0.5, 0.999999], dtype=np.float32)
+        nd = nb + 1
+    else:
+        x = rnd(c["seed"], "x", (N,), 3.0)
+        x[:6] = np.array([-5.0, 5.0, -7.5, 9.0, 0.0, 4.999999], dtype=np.float32)
+        nd = nb - 1
+    uw = rnd(c["seed"], "uw", (N, nb), 1.0)
+    uh = rnd(c["seed"], "uh", (N, nb), 1.0)
+    ud = rnd(c["seed"], "ud", (N, nd), 1.0)
+    return x, uw, uh, ud
 
 
 def spline_inputs(case):
@@ -220,6 +260,14 @@ def dds_shapes(C, k, n, prefix=""):
         for nm in ("norms_1", "norms_2"):
             d[f"{prefix}{nm}.{i}.gamma"] = (C,)
             d[f"{prefix}{nm}.{i}.beta"] = (C,)
+    return d
+
+
+def melenc_shapes(Cout, H, k, n, gin, prefix=""):
+    d = {}
+    _conv(d, prefix + "pre_enc", H, 80, 1)
+    d.update(wn_shapes(H, k, n, gin, prefix + "encoder."))
+    _conv(d, prefix + "proj", 2 * Cout, H, 1)
     return d
 
 

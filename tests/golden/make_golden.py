@@ -168,4 +168,54 @@ for name, c in cases.SPLINE_CASES.items():
                                                                    tails="linear", tail_bound=5.0)
     save(name, y=y.numpy(), logabsdet=lad.numpy())
 
+for name, c in cases.CONVFLOW_G_CASES.items():
+    m = load_synth(ref_modules.ConvFlow(c["Cin"], c["F"], c["k"], c["n"]), c["seed"], gain=2.0)
+    x = cases.rnd(c["seed"], "x", (c["B"], c["Cin"], c["T"]), 2.5)
+    mask = T(cases.lengths_mask(c["lengths"], c["T"]))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["F"], c["gT"]), 0.7))
+    r = m(T(x), mask, g=g, reverse=c["reverse"])
+    if c["reverse"]:
+        save(name, y=r.numpy())
+    else:
+        save(name, y=r[0].numpy(), logdet=r[1].numpy())
+
+for name, c in cases.LAYERNORM_CASES.items():
+    m = ref_modules.LayerNorm(c["C"])
+    m.gamma.data.copy_(T(1.0 + cases.rnd(c["seed"], "gamma", (c["C"],), 0.3)))
+    m.beta.data.copy_(T(cases.rnd(c["seed"], "beta", (c["C"],), 0.2)))
+    x = cases.rnd(c["seed"], "x", c["shape"], 1.5)
+    save(name, y=m(T(x)).numpy())
+
+for name, c in cases.MELENC_CASES.items():
+    m = load_synth(ref_models.MelEncoder(c["Cout"], c["H"], 768, c["n"], c["k"], c["dr"], c["gin"]), c["seed"])
+    x = cases.rnd(c["seed"], "x", (c["B"], 80, c["T"]), 1.0)
+    xo, mm, logs, mask = m(T(x), torch.tensor(c["lengths"], dtype=torch.int64))
+    save(name, x=xo.numpy(), m=mm.numpy(), logs=logs.numpy(), mask=mask.numpy())
+
+for name, c in cases.SPLINE_EXTRA_CASES.items():
+    x, uw, uh, ud = cases.spline_extra_inputs(name)
+    kw = dict(min_bin_width=c["mins"][0], min_bin_height=c["mins"][1], min_derivative=c["mins"][2])
+    if c["tails"] is None:
+        if c["inverse"]:      # inverse inputs must lie in [0,1] too: feed the forward outputs' range
+            pass
+        y, lad = ref_transforms.piecewise_rational_quadratic_transform(T(x), T(uw), T(uh), T(ud), inverse=c["inverse"], **kw)
+    else:
+        y, lad = ref_transforms.piecewise_rational_quadratic_transform(T(x), T(uw), T(uh), T(ud), inverse=c["inverse"],
+                                                                       tails="linear", tail_bound=5.0, **kw)
+    save(name, y=y.numpy(), logabsdet=lad.numpy())
+
+# ---------------------------------------------------------------- a checkpoint written by the reference itself
+if not ONLY or any(f in "G_7.pth" for f in ONLY):
+    import utils as ref_utils  # noqa: E402  (reference)
+    rc = cases.REF_CHECKPOINT
+    c = cases.GENERATOR_CASES[rc["case"]]
+    m = ref_models.Generator(c["initial_channel"], c["resblock"], c["rks"], c["rds"], c["ur"], c["uic"], c["uks"], gin_channels=c["gin"])
+    load_synth(m, c["seed"], gain=1.0)
+    opt = torch.optim.AdamW(m.parameters(), rc["learning_rate"])
+    import logging
+    logging.disable(logging.CRITICAL)
+    ref_utils.save_checkpoint(m, opt, rc["learning_rate"], rc["iteration"], os.path.join(HERE, rc["file"]))
+    logging.disable(logging.NOTSET)
+    print(rc["file"], os.path.getsize(os.path.join(HERE, rc["file"])) // 1024, "KB")
+
 print("done")

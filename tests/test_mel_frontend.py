@@ -77,3 +77,41 @@ def test_notebook_flow_wav_to_audio():
     ln = torch.LongTensor([mel.size(2)]).cuda()
     audio = net.infer(mel, ln, sid=None, noise_scale=.667, noise_scale_w=0.8, length_scale=1)[0][0, 0].data.cpu().float().numpy()
     assert audio.shape == (mel.size(2) * 256,) and np.isfinite(audio).all() and np.abs(audio).max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_notebook_cell4_verbatim_with_host_tensors(tmp_path):
+    """inference.ipynb cell 4 as written: load_wav_to_torch -> /32768 -> spectrogram_torch / spec_to_mel_torch on HOST
+    tensors -> mel.cuda() -> infer -> .cpu().numpy() -> scipy write.  Host inputs give host outputs equal to the
+    device path's."""
+    from scipy.io.wavfile import write
+    from smart_vocoder_amd import mel_processing as MP, models, utils
+    wav = (np.clip(_audio(13, 1, 16000)[0], -1, 1) * 32767).astype(np.int16)
+    write(str(tmp_path / "in.wav"), 22050, wav)
+    audio, sampling_rate = utils.load_wav_to_torch(str(tmp_path / "in.wav"))
+    audio_norm = (audio / 32768.0).unsqueeze(0)
+    assert not audio_norm.is_cuda
+    spec = MP.spectrogram_torch(audio_norm, 1024, 22050, 256, 1024, center=False)
+    mel = MP.spec_to_mel_torch(spec, 1024, 80, 22050, 0.0, None)
+    assert not spec.is_cuda and not mel.is_cuda
+    assert torch.equal(mel, MP.mel_spectrogram_torch(audio_norm.cuda(), 1024, 80, 22050, 256, 1024, 0.0, None).cpu())
+    net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}, strict=False)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        mel = mel.cuda()
+        spec_lengths = torch.LongTensor([mel.size(2)]).cuda()
+        audio_ = net.infer(mel, spec_lengths, sid=None, noise_scale=.667, noise_scale_w=0.8, length_scale=1)[0][0, 0].data.cpu().float().numpy()
+    write(str(tmp_path / "out.wav"), 22050, audio_)
+    assert audio_.shape == (mel.size(2) * 256,) and np.isfinite(audio_).all()
+
+
+def test_save_wav_round_trip(tmp_path):
+    from scipy.io.wavfile import read
+    from smart_vocoder_amd import utils
+    a = torch.linspace(-0.9, 0.9, 1000).reshape(1, 1, 1000)
+    p = utils.save_wav(str(tmp_path / "d" / "x.wav"), 22050, a)
+    sr, data = read(p)
+    assert sr == 22050 and data.dtype == np.float32 and np.array_equal(data, a[0, 0].numpy())
+    with pytest.raises(ValueError):
+        utils.save_wav(str(tmp_path / "y.wav"), 22050, torch.zeros(2, 100))

@@ -178,3 +178,83 @@ def test_spline(name):
     gold = cases.golden(name)
     close(y, gold["y"], 2e-6)
     close(lad, gold["logabsdet"], 2e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.CONVFLOW_G_CASES))
+def test_convflow_with_g(name):
+    c = cases.CONVFLOW_G_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.convflow_shapes(c["Cin"], c["F"], c["k"], c["n"]), c["seed"], 2.0))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], c["Cin"], c["T"]), 2.5))
+    mask = T(cases.lengths_mask(c["lengths"], c["T"]))
+    g = T(cases.rnd(c["seed"], "g", (c["B"], c["F"], c["gT"]), 0.7))
+    r = O.conv_flow(sd, "", x, mask, g, reverse=c["reverse"], filter_channels=c["F"], kernel_size=c["k"], n_layers=c["n"])
+    gold = cases.golden(name)
+    if c["reverse"]:
+        close(r, gold["y"], 2e-5)
+    else:
+        close(r[0], gold["y"], 2e-5)
+        close(r[1], gold["logdet"], 1e-3)
+
+
+@pytest.mark.parametrize("name", list(cases.LAYERNORM_CASES))
+def test_layer_norm(name):
+    c = cases.LAYERNORM_CASES[name]
+    gamma = T(1.0 + cases.rnd(c["seed"], "gamma", (c["C"],), 0.3)); beta = T(cases.rnd(c["seed"], "beta", (c["C"],), 0.2))
+    x = T(cases.rnd(c["seed"], "x", c["shape"], 1.5))
+    close(O.layer_norm_c(x, gamma, beta), cases.golden(name)["y"], 2e-6)
+
+
+@pytest.mark.parametrize("name", list(cases.MELENC_CASES))
+def test_mel_encoder(name):
+    c = cases.MELENC_CASES[name]
+    sd = sdT(sw.fill_state_dict(cases.melenc_shapes(c["Cout"], c["H"], c["k"], c["n"], c["gin"]), c["seed"]))
+    x = T(cases.rnd(c["seed"], "x", (c["B"], 80, c["T"]), 1.0))
+    xo, m, logs, mask = O.mel_encoder(sd, x, torch.tensor(c["lengths"]), "", hidden=c["H"], kernel_size=c["k"],
+                                      dilation_rate=c["dr"], n_layers=c["n"])
+    gold = cases.golden(name)
+    close(xo, gold["x"], 4e-6); close(m, gold["m"], 4e-6); close(logs, gold["logs"], 4e-6)
+    assert np.array_equal(mask.numpy(), gold["mask"])
+
+
+@pytest.mark.parametrize("name", list(cases.SPLINE_EXTRA_CASES))
+def test_spline_no_tails_and_minimums(name):
+    c = cases.SPLINE_EXTRA_CASES[name]
+    x, uw, uh, ud = cases.spline_extra_inputs(name)
+    mw, mh, md = c["mins"]
+    if c["tails"] is None:
+        y, lad = O.rq_spline(T(x), T(uw), T(uh), T(ud), c["inverse"], min_bin=mw, min_deriv=md, min_bin_height=mh)
+    else:
+        y, lad = O.rq_spline_linear_tails(T(x), T(uw), T(uh), T(ud), inverse=c["inverse"], tail_bound=5.0, min_bin=mw,
+                                          min_deriv=md, min_bin_height=mh)
+    gold = cases.golden(name)
+    close(y, gold["y"], 2e-6)
+    close(lad, gold["logabsdet"], 2e-5)
+
+
+def test_reference_written_checkpoint_loads(tmp_path):
+    """tests/golden/G_7.pth was written by the REFERENCE's utils.save_checkpoint (reference utils.py:46-56,
+    via make_golden.py).  Our utils.load_checkpoint must read it into our same-named module (tolerant-load semantics,
+    reference utils.py:18-43) and recover exactly the weights the reference held.  CPU-only: parameter containers."""
+    import os
+    from smart_vocoder_amd import models, utils
+    rc = cases.REF_CHECKPOINT
+    c = cases.GENERATOR_CASES[rc["case"]]
+    m = models.Generator(c["initial_channel"], c["resblock"], c["rks"], c["rds"], c["ur"], c["uic"], c["uks"], gin_channels=c["gin"])
+    path = os.path.join(cases.GOLDEN_DIR, rc["file"])
+    raw = torch.load(path, map_location="cpu")
+    assert set(raw) == {"model", "iteration", "optimizer", "learning_rate"}
+    assert list(raw["model"]) == list(m.state_dict())                       # same keys, same order
+    opt = torch.optim.AdamW(m.parameters(), 1.0)
+    _, opt2, lr, it = utils.load_checkpoint(path, m, opt)
+    assert it == rc["iteration"] and lr == rc["learning_rate"] and opt2 is opt
+    assert opt.param_groups[0]["lr"] == rc["learning_rate"]
+    want = sw.fill_state_dict(cases.generator_shapes(c), c["seed"], 1.0)
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.numpy(), want[k]), k
+    assert utils.latest_checkpoint_path(cases.GOLDEN_DIR, "G_*.pth") == path
+    # tolerant load: a key missing from the file keeps the model's value
+    del raw["model"]["conv_post.weight"]
+    torch.save(raw, tmp_path / "G_9.pth")
+    keep = m.conv_post.weight.detach().clone()
+    utils.load_checkpoint(str(tmp_path / "G_9.pth"), m, None)
+    assert torch.equal(m.conv_post.weight, keep)
