@@ -43,20 +43,25 @@ __device__ __forceinline__ float pick4(const float4& v, int s) {
 }
 
 // One output tile: workgroup (bx, by, bz) = (time tile, row block, batch element) of problem p.
-template <int WM, int WN, int MR, int NR>
+// KS (K split, short inputs): the four waves of the workgroup share ONE (32*MR) x (32*NR) tile and each multiplies over a
+// quarter of K - wave w takes the 8-channel group w of every (32-channel chunk, tap) - then the partial accumulators
+// are summed through LDS and wave 0 runs the epilogue.  A tile's serial MFMA chain is 4x shorter and there are 4x more
+// workgroups than with a 64x64 four-wave tile: at 1 x 200 frames the decoder's C=256 stage has 1600 columns, 100
+// conventional workgroups each chaining 1408 MFMAs (117 us per convolution) against 400 workgroups chaining 352.
+template <int WM, int WN, int MR, int NR, bool KS = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const int by, const int bz, const long long dbg_lin) {
   constexpr int NT = WM * WN * 64;
-  constexpr int BN = WN * NR * 32;
+  constexpr int BN = (KS ? 1 : WN) * NR * 32;
   extern __shared__ __attribute__((aligned(16))) float xs[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = KS ? 0 : wave / WN, wn = KS ? 0 : wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
   const int b = bz;
   const int n0 = bx * BN;
-  const int mt0 = (by * WM + wm) * MR;
+  const int mt0 = (by * (KS ? 1 : WM) + wm) * MR;
   const int ncol0 = n0 + wn * NR * 32;
   const bool wave_active = (mt0 < p.mtiles) && (ncol0 < p.Ncols);
 
@@ -67,7 +72,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
     for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
       for (int i = 0; i < 16; ++i)   // bias folded into the accumulator (no dependent loads in the epilogue)
-        acc[mr][nr][i] = p.bias[min(mt0 + mr, p.mtiles - 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
+        acc[mr][nr][i] = (KS && wave != 0) ? 0.f : p.bias[min(mt0 + mr, p.mtiles - 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
 
   // ---- weight fragment stream (prefetched one group of 4 k-steps ahead)
   const float4* wp4 = reinterpret_cast<const float4*>(p.wp);
@@ -176,6 +181,49 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
     __syncthreads();
     if (p.dbg && ch == 0) tstamp[1] = dbg_clock();
 
+    if constexpr (KS) {
+      if (wave_active) {
+        // this wave's groups: (sub-chunk q, tap j) -> packed group ((ch + q) * ktaps + j) * 4 + wave, LDS rows
+        // q*32 + 8*wave + 2s + hi at column offset j*dil; one group ahead in registers
+        const int nsub = min(sub_per_stage, p.nchunks - ch);
+        const int ng = nsub * p.ktaps;
+        const float* bpw = bp0 + 8 * wave * p.row_len;
+        float4 an[MR];
+        float bn[4][NR];
+        auto req = [&](int q, int j) {
+          const long long kg = ((long long)(ch + q) * p.ktaps + j) * 4 + wave;
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) an[mr] = wp4[abase[mr] + kg * 64];
+          const float* bq = bpw + q * KC * p.row_len + j * p.dil;
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bq[(2 * s) * p.row_len + nr * 32];
+        };
+        req(0, 0);
+        int q = 0, j = 0;
+        for (int g = 0; g < ng; ++g) {
+          float4 ac[MR];
+          float bc[4][NR];
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) ac[mr] = an[mr];
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) bc[s][nr] = bn[s][nr];
+          if (++j == p.ktaps) { j = 0; ++q; }
+          if (g + 1 < ng) req(q, j);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+              const float av = pick4(ac[mr], s);
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[mr][nr], 0, 0, 0);
+            }
+        }
+      }
+    } else
     if (wave_active) {
       // Group-level software pipeline (a group = 4 k-steps = 8 input channels of one tap): at the top of
       // iteration gi the fragments of group gi (requested one iteration earlier) are moved into the "cur"
@@ -241,6 +289,29 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
   }
 
   if (p.dbg) tstamp[2] = dbg_clock();
+  if constexpr (KS) {
+    // sum the four K-quarters: waves 1..3 park their accumulators in LDS (the staging tile is dead), wave 0 adds them
+    __syncthreads();
+    float* red = xs;                                       // [3][MR*NR][16][64]
+    if (wave != 0) {
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) red[(((wave - 1) * MR * NR + mr * NR + nr) * 16 + i) * 64 + lane] = acc[mr][nr][i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mr][nr][i] += red[((w * MR * NR + mr * NR + nr) * 16 + i) * 64 + lane];
+  }
   if (!wave_active) return;
 
   auto run_epilogue = [&]() {
@@ -455,6 +526,16 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_mfma
   conv_tile<WM, WN, MR, NR>(p, tl - t * (int)gridDim.x, t - bz * (int)gridDim.y, bz, lin);
 }
 
+// K-split variant for launches that cannot fill the chip otherwise (see conv_tile): 4 waves, one (32*MR) x 32 tile.
+template <int MR>
+__global__ void __launch_bounds__(256, 3) conv_ksplit_kernel(const ConvArgs p) {
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int tl = xcd_linear(lin, gridDim.x * gridDim.y * gridDim.z, p.xcd);
+  const int t = tl / (int)gridDim.x;
+  const int bz = t / (int)gridDim.y;
+  conv_tile<2, 2, MR, 1, true>(p, tl - t * (int)gridDim.x, t - bz * (int)gridDim.y, bz, lin);
+}
+
 // Several independent convolutions of one tile shape in ONE launch (the three MRF chains' step-i convolutions):
 // workgroups are numbered problem by problem, longest tiles first, so the short ones fill the tail of the long ones
 // and there is one tail per launch instead of one per convolution.
@@ -475,7 +556,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_grou
 // ------------------------------------------------------------------ host side
 namespace {
 
-struct TileCfg { int WM, WN, MR, NR; };
+struct TileCfg { int WM, WN, MR, NR; int ks = 0; };
 constexpr TileCfg CFG_A{4, 1, 2, 4};   // 256 rows x 128 cols
 constexpr TileCfg CFG_B{2, 2, 2, 2};   // 128 x 128
 constexpr TileCfg CFG_C{2, 2, 1, 4};   //  64 x 256
@@ -483,6 +564,18 @@ constexpr TileCfg CFG_D2{1, 4, 1, 2};  //  32 x 256
 constexpr TileCfg CFG_E{2, 2, 2, 1};   // 128 x  64  (short sequences, paired)
 constexpr TileCfg CFG_F{2, 2, 1, 1};   //  64 x  64  (short sequences)
 constexpr TileCfg CFG_G{1, 4, 1, 1};   //  32 x 128  (short sequences, odd tile counts)
+
+template <int MR>
+int launch_ks(const ConvArgs& a, int B, hipStream_t st) {
+  auto kern = conv_ksplit_kernel<MR>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const size_t lds = std::max((size_t)a.kcs * a.row_len * sizeof(float), (size_t)3 * MR * 16 * 64 * sizeof(float));
+  if (lds > 160 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "conv LDS tile of %zu bytes exceeds 160 KiB (kernel %d taps, dilation %d)", lds, a.ktaps, a.dil);
+  dim3 grid((a.Ncols + 31) / 32, (a.mtiles + MR - 1) / MR, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
 
 template <int WM, int WN, int MR, int NR>
 int launch_cfg(const ConvArgs& a, int B, hipStream_t st) {
@@ -554,6 +647,16 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
     if (nb > best) { c = cand[i]; best = nb; }
   }
 
+  {   // short inputs: when even the smallest tile leaves most CUs without a workgroup, split K over the four waves
+    static const bool ks_on = !(getenv("SVOC_KSPLIT") && atoi(getenv("SVOC_KSPLIT")) == 0);
+    const int mrk = needs_pair ? 2 : 1;
+    const long long nbk = (long long)((a.Ncols + 31) / 32) * ((mt + mrk - 1) / mrk) * B;
+    const int groups = a.nchunks * pc.ktaps;             // per wave: groups of 4 k-steps
+    // (measured: extending this to "fewer than two workgroups per CU" is neutral at 1 x 200 and 7 % slower at 4 x 512)
+    if (ks_on && best < (long long)ncu && nbk > best && groups >= 2 && a.mode != EPI_UPS && a.mode != EPI_MAG) {
+      c = TileCfg{1, 1, mrk, 1, 1};
+    }
+  }
   const int BN = c.WN * c.NR * 32;
   const int off_first = -pc.pad, off_last = (pc.ktaps - 1) * pc.dil - pc.pad;
   const int minoff = std::min(off_first, off_last), maxoff = std::max(off_first, off_last);
@@ -561,13 +664,13 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
   a.row_len = round_up(BN + maxoff - a.xoff0, 4);
   {   // input channels staged per memory round trip: as many 32-channel chunks as fit the per-block LDS budget
     // ... and one batch of staging loads (9 float4 per thread x 256 threads)
-    const int budget = ((c.MR * c.NR >= 8) ? 6 : 9) * 256 * 16;
+    const int budget = ((c.MR * c.NR >= 8 && !c.ks) ? 6 : 9) * 256 * 16;
     const int per32 = KC * a.row_len * (int)sizeof(float);
     const int nfit = std::max(1, budget / per32);
     a.kcs = KC * std::min(a.nchunks, nfit);
   }
   a.ntn = (a.Ncols + BN - 1) / BN;
-  a.gy = (a.mtiles + c.WM * c.MR - 1) / (c.WM * c.MR);
+  a.gy = c.ks ? (a.mtiles + c.MR - 1) / c.MR : (a.mtiles + c.WM * c.MR - 1) / (c.WM * c.MR);
   a.B = B;
   return SVOC_OK;
 }
@@ -583,12 +686,13 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%dx%dx%d m%d", pc.transposed ? "convT" : "conv ", pc.Cin, pc.Cout,
-             pc.transposed ? pc.ktaps * pc.ups_s : pc.ktaps, pc.dil, a.Ncols, B, c.WM, c.WN, c.MR, c.NR, a.mode);
+    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%dx%dx%d%s m%d", pc.transposed ? "convT" : "conv ", pc.Cin, pc.Cout,
+             pc.transposed ? pc.ktaps * pc.ups_s : pc.ktaps, pc.dil, a.Ncols, B, c.WM, c.WN, c.MR, c.NR, c.ks ? " ksplit" : "", a.mode);
     prof_idx = prof_begin(st, d, flops);
   }
   struct ProfEnd { hipStream_t st; int i; ~ProfEnd() { prof_end(st, i); } } prof_end_guard{st, prof_idx};
 
+  if (c.ks) return c.MR == 2 ? launch_ks<2>(a, B, st) : launch_ks<1>(a, B, st);
 #define SVOC_LAUNCH(C) if (c.WM == C.WM && c.WN == C.WN && c.MR == C.MR && c.NR == C.NR) return launch_cfg<C.WM, C.WN, C.MR, C.NR>(a, B, st)
   SVOC_LAUNCH(CFG_A);
   SVOC_LAUNCH(CFG_B);

@@ -575,14 +575,16 @@ struct Generator {
       else r = (r + 2) & 3;
       ch = cho; L = Lo; ld = ldo;
     }
-    last_stage = bufs[r]; last_ch = ch; last_L = L; last_ld = ld;
-    return out ? post(st, out, B, T) : SVOC_OK;
+    last = LastStage{bufs[r], ch, L, ld};
+    return out ? post(st, last, out, B) : SVOC_OK;
   }
-  // lrelu(0.01) -> conv_post -> tanh (models.py:156-158) on the last MRF stage left by forward(.., B, T)
-  float* last_stage = nullptr; int last_ch = 0, last_L = 0, last_ld = 0;
-  int post(hipStream_t st, float* out, int B, int T) {
-    if (!last_stage || last_L != T * hop) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: post() without a matching forward()");
-    return k_conv_post_tanh(st, last_stage, (long long)last_ch * last_ld, last_ld, conv_post_w.f(), last_ch, 7, 0.01f, out, B, last_L);
+  // lrelu(0.01) -> conv_post -> tanh (models.py:156-158) on the last MRF stage left by a forward(); a captured plan keeps
+  // its own copy of `last` (a replay does not run forward())
+  struct LastStage { float* p = nullptr; int ch = 0, L = 0, ld = 0; };
+  LastStage last;
+  int post(hipStream_t st, const LastStage& ls, float* out, int B) {
+    if (!ls.p) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: post() without a forward()");
+    return k_conv_post_tanh(st, ls.p, (long long)ls.ch * ls.ld, ls.ld, conv_post_w.f(), ls.ch, 7, 0.01f, out, B, ls.L);
   }
 };
 
@@ -738,7 +740,8 @@ struct Synth {
     return dec.forward(st, w.P, Tp, iper, w.mask, Tp, nullptr, nullptr, B, Td);
   }
 
-  int tail(hipStream_t st, float* o, float* x_mask, float* z, float* z_p, float* m_p, float* logs_p, int Td, int B, int T) {
+  int tail(hipStream_t st, const Generator::LastStage& ls, float* o, float* x_mask, float* z, float* z_p, float* m_p, float* logs_p,
+           int B, int T) {
     const int IC = cfg.inter_channels, Tp = pad4(T);
     const long long iper = (long long)IC * Tp, ubs = (long long)IC * T;
     const Bufs w = bufs(B, T);
@@ -747,7 +750,7 @@ struct Synth {
     if (z_p) SVOC_TRY(k_copy2d(st, w.zp, iper, Tp, z_p, ubs, T, B, IC, T, nullptr, 0));
     if (z) SVOC_TRY(k_copy2d(st, w.P, iper, Tp, z, ubs, T, B, IC, T, nullptr, 0));
     if (x_mask) SVOC_TRY(k_copy2d(st, w.mask, Tp, Tp, x_mask, T, T, B, 1, T, nullptr, 0));
-    return dec.post(st, o, B, Td);
+    return dec.post(st, ls, o, B);
   }
 
   // ---- captured plans for short inputs.  At 1 x 200 frames the ~100 dependent launches of the path are a few tens of
@@ -768,6 +771,7 @@ struct Synth {
     int B = 0, T = 0, Td = 0; float noise = 0; bool has_eps = false, want_zp = false;
     int seen = 0;                       // calls with this key (the first runs uncaptured: per-device kernel attributes, allocation)
     hipGraphExec_t exec = nullptr;
+    Generator::LastStage last;          // where the captured body leaves the last MRF stage
     DevBuf stage;                       // mel | eps | lengths
     long long conv_launches = 0, other_launches = 0, convs = 0; double conv_flops = 0;
     unsigned long long last_use = 0;
@@ -810,6 +814,7 @@ struct Synth {
     if (ei != hipSuccess) { pl.exec = nullptr; SVOC_FAIL(SVOC_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
     pl.conv_launches = cl1 - cl0; pl.conv_flops = cf1 - cf0; pl.other_launches = ol1 - ol0; pl.convs = nc1 - nc0;
     pl.fp = ws_fingerprint();
+    pl.last = dec.last;
     return SVOC_OK;
   }
 
@@ -850,11 +855,11 @@ struct Synth {
         SVOC_HIP(hipMemcpyAsync(eps_s + eps_n, lengths, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
         SVOC_HIP(hipGraphLaunch(pl->exec, st));
         stats_add_bulk(pl->conv_launches, pl->conv_flops, pl->other_launches, pl->convs);
-        return tail(st, o, x_mask, z, z_p, m_p, logs_p, Td, B, T);
+        return tail(st, pl->last, o, x_mask, z, z_p, m_p, logs_p, B, T);
       }
     }
     SVOC_TRY(body(st, mel, lengths, eps, noise_scale, Td, want_zp, B, T));
-    return tail(st, o, x_mask, z, z_p, m_p, logs_p, Td, B, T);
+    return tail(st, dec.last, o, x_mask, z, z_p, m_p, logs_p, B, T);
   }
 };
 

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace svoc {
 
@@ -248,187 +249,362 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Persistent variant with loader waves.  Phase stamps of the kernel above (tools/fused_phases.py) show the staging
-// phase taking 19-40 % of a workgroup's life although it moves only 35-48 KB: co-resident workgroups run in lock
-// step, so every CU requests its tiles at the same moment and the chip alternates between an HBM burst and an MFMA
-// phase with idle HBM.  Here a workgroup has 4 MFMA waves (same code as above) plus 4 loader waves and walks a list
-// of tiles: the loaders request tile i+1 right after publishing tile i and hold it in registers (12-13 float4 per
-// lane) while the MFMA waves run both GEMMs of tile i, then write it (zero padding + leaky-relu) into the LDS tile
-// as soon as c2 has finished reading it.  Requests are spread over the whole compute time and never sit in the MFMA
-// waves' in-order vmcnt queue.  Barriers are raw s_barrier (a fence would drain the loaders' requests and the MFMA
-// waves' output stores).  MEASURED: correct on the parity suite, but per-CU throughput equals the kernel above
-// (C=64: k=3 0.60 vs 0.59 ms, k=11 1.80 vs 1.75 ms): with two workgroups per CU only two MFMA waves share a SIMD and
-// the exchange / epilogue phases are no longer covered by a third and fourth workgroup.  Opt-in (SVOC_FUSE_WS=1).
-__device__ __forceinline__ void fz_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+// Generation 2: the same algorithm with every piece of geometry known at compile time (C, k, c1 dilation).
+// Round-1 PMC counters (profiles/r01_e_pmc_instruction_mix.txt) show the generic kernel issuing 2.5 (C=64) / 4.0 (C=32)
+// vector-ALU instructions per MFMA, and on gfx950 every vector instruction takes matrix-pipe time (fp32 MFMA runs at
+// the vector rate on the same lanes).  With compile-time row strides the LDS fragment reads, the residual pull and the
+// activation exchange use immediate offsets; the staging walks an exact slot count, interior tiles (all but two per
+// row) skip the zero-padding clamps and selects, the weight stream is addressed as a uniform base + 32-bit lane offset,
+// and the output rows as uniform row bases + one per-lane offset.  Summation order is unchanged: results are
+// bit-identical to the generic kernel above (tools/rb_bench.py checks it).
+template <int C, int K, int D, int NRT = 2>
+struct RbGeo {
+  static constexpr int WM = C / 32;                       // waves along the rows (one 32-row tile each)
+  static constexpr int WN = 4 / WM;
+  static constexpr int NR = NRT;                          // 32-column tiles per wave (1: half-width tiles for short inputs)
+  static constexpr int NA = WN * NR * 32;                 // c1 columns per workgroup
+  static constexpr int PAD1 = (K - 1) * D / 2;
+  static constexpr int PAD2 = (K - 1) / 2;
+  static constexpr int N2 = (NA - (K - 1)) & ~3;          // output columns per workgroup
+  static constexpr int XOFF0 = -((PAD1 + PAD2 + 3) & ~3); // x tile starts at t0 + XOFF0 (multiple of 4)
+  static constexpr int LASTC = NA - 1 - PAD2 + (K - 1) * D - PAD1 - XOFF0;
+  static constexpr int XROW = ((LASTC + 1 > N2 - XOFF0 ? LASTC + 1 : N2 - XOFF0) + 3) & ~3;
+  static constexpr int YROW = ((NA + K - 1 + 3) & ~3) + 1;
+  static constexpr int NCH = C / KC;
+  static constexpr int KSG = NCH * K * (KC / 8);          // groups of 4 k-steps per 32-row tile
+  static constexpr int R4 = XROW / 4;
+  static constexpr int RPP = 256 / R4;                    // tile rows staged per pass (one float4 per thread)
+  static constexpr int NPASS = (C + RPP - 1) / RPP;
+  static constexpr int LDS_BYTES = C * (XROW > YROW ? XROW : YROW) * 4;
+};
+
+__device__ __forceinline__ float4 ld_w(const char* __restrict__ base, unsigned off) {
+  return *reinterpret_cast<const float4*>(base + off);
 }
 
-template <int WM, int WN, int NR, int XREG>
-__global__ void __launch_bounds__(512, 4) resblock_fused_ws_kernel(const FusedArgs p, const int ntn, const int total_tiles) {
+// acc[nr] += W[32 rows][K] * B.  `wbase` is wave-uniform (packed weights of this wave's row tile), `voff` = lane * 16;
+// `bp` = this lane's LDS pointer: tile + hi * ROW + (first column).  Group order = packing order: chunk, tap, 8-channel
+// group.  Ping-pong fragment registers; the next group's requests go out after the first k-step's MFMAs.
+// LDS fragment read with an immediate byte offset.  hipcc merges neighbouring fragment reads into ds_read2_b32, whose
+// 8-bit dword offsets cannot span the row strides of the tiles, and then spends one v_add_u32 per pair on a new base
+// register; every such vector instruction takes matrix-pipe time.  ds_read_b32 has a 16-bit byte offset: one base
+// register per lane serves the whole tile.  The compiler does not track inline-asm memory operations, so the consumer
+// waits explicitly (lds_wait) before the first use.
+template <int OFF>
+__device__ __forceinline__ float lds_rd(unsigned addr) {
+  float v;
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset field");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int NR>
+__device__ __forceinline__ void lds_wait(float (&b)[4][NR]) {
+  if constexpr (NR == 2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1]));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0][0]), "+v"(b[1][0]), "+v"(b[2][0]), "+v"(b[3][0]));
+  }
+}
+template <int NR, int ROW, int BASE>
+__device__ __forceinline__ void ld_frag(float (&b)[4][NR], unsigned addr) {
+  b[0][0] = lds_rd<BASE * 4>(addr);
+  b[1][0] = lds_rd<(BASE + 2 * ROW) * 4>(addr);
+  b[2][0] = lds_rd<(BASE + 4 * ROW) * 4>(addr);
+  b[3][0] = lds_rd<(BASE + 6 * ROW) * 4>(addr);
+  if constexpr (NR == 2) {
+    b[0][1] = lds_rd<(BASE + 32) * 4>(addr);
+    b[1][1] = lds_rd<(BASE + 2 * ROW + 32) * 4>(addr);
+    b[2][1] = lds_rd<(BASE + 4 * ROW + 32) * 4>(addr);
+    b[3][1] = lds_rd<(BASE + 6 * ROW + 32) * 4>(addr);
+  }
+}
+
+// acc[nr] += W[32 rows][K] * B.  `wbase` is wave-uniform (packed weights of this wave's row tile), `voff` = lane * 16;
+// `baddr` = this lane's LDS byte address: tile + hi * ROW + (first column).  Group order = packing order: chunk, tap,
+// 8-channel group.  Ping-pong fragment registers; the next group's requests go out after the first k-step's MFMAs.
+template <int NR, int ROW, int NCH, int K, int DIL>
+__device__ __forceinline__ void gemm_ct(f32x16 (&acc)[NR], const char* __restrict__ wbase, unsigned voff, unsigned baddr) {
+  static_assert((NCH * KC + 6) * ROW * 4 + 128 + 4 < 65536, "fragment offsets must fit the ds_read_b32 offset field");
+  static_assert(NCH <= 2, "C <= 64");
+  float4 a0 = ld_w(wbase, voff), a1;
+  float b0[4][NR], b1[4][NR];
+  ld_frag<NR, ROW, 0>(b0, baddr);
+  // MFMAs of one group (4 k-steps); the next group's requests (weights: global/L2, fragments: LDS) are issued after the
+  // first k-step.  (Requesting the weights two groups ahead changes nothing: profiles/r02_fused_resblock_ab.txt.)
+  auto mfma_head = [&](const float4& ac, float(&bc)[4][NR]) {
+    lds_wait<NR>(bc);
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, bc[0][nr], acc[nr], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_tail = [&](const float4& ac, float(&bc)[4][NR]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+      const float av = fz_pick4(ac, s);
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[nr], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one tap of chunk CH = 4 groups (8 channels each); NEXT: 0 = the following tap of the same chunk (column + DIL),
+  // 1 = first tap of the next chunk, 2 = nothing follows
+  auto tap = [&](auto chc, auto nextc, unsigned ba, unsigned va) {
+    constexpr int CH = decltype(chc)::value, NEXT = decltype(nextc)::value;
+    constexpr int R0 = CH * KC * ROW;
+    mfma_head(a0, b0); a1 = ld_w(wbase, va + 1024); ld_frag<NR, ROW, R0 + 8 * ROW>(b1, ba); mfma_tail(a0, b0);
+    mfma_head(a1, b1); a0 = ld_w(wbase, va + 2048); ld_frag<NR, ROW, R0 + 16 * ROW>(b0, ba); mfma_tail(a1, b1);
+    mfma_head(a0, b0); a1 = ld_w(wbase, va + 3072); ld_frag<NR, ROW, R0 + 24 * ROW>(b1, ba); mfma_tail(a0, b0);
+    mfma_head(a1, b1);
+    if constexpr (NEXT == 0) { a0 = ld_w(wbase, va + 4096); ld_frag<NR, ROW, R0 + DIL>(b0, ba); }
+    if constexpr (NEXT == 1) { a0 = ld_w(wbase, va + 4096); ld_frag<NR, ROW, R0 + KC * ROW - (K - 1) * DIL>(b0, ba); }
+    mfma_tail(a1, b1);
+  };
+  unsigned va = voff;
+  auto chunk = [&](auto chc) {
+    constexpr int CH = decltype(chc)::value;
+    unsigned ba = baddr;
+#pragma unroll 1
+    for (int j = 0; j < K - 1; ++j) {
+      tap(chc, std::integral_constant<int, 0>{}, ba, va);
+      ba += DIL * 4;
+      va += 4096u;
+    }
+    tap(chc, std::integral_constant<int, (CH + 1 < NCH) ? 1 : 2>{}, ba, va);
+    va += 4096u;
+  };
+  chunk(std::integral_constant<int, 0>{});
+  if constexpr (NCH > 1) chunk(std::integral_constant<int, 1>{});
+}
+
+template <int C, int K, int D, int NRT>
+__global__ void __launch_bounds__(256, 2) resblock_fused_ct_kernel(const FusedArgs p) {
+  using G = RbGeo<C, K, D, NRT>;
+  constexpr int WN = G::WN, NR = G::NR, XROW = G::XROW, YROW = G::YROW, R4 = G::R4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const XT = lds;
-  float* const YT = lds;                                   // aliases the x tile
+  float* const XT = lds;                                   // lrelu(x) tile  [C][XROW]
+  float* const YT = lds;                                   // lrelu(c1(.)) tile [C][YROW], aliases the x tile
+
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h2 = p.pad2;
-  const int ntl = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup (>= 1)
-
-  if (wave >= 4) {
-    // ===================================================================== loader waves
-    const int pl = tid - 256;                              // 0..255
-    const int R4 = p.xrow >> 2;
-    const int total = p.C * R4;
-    const int wc0 = pl / R4, wg0 = pl - wc0 * R4;
-    const int dc = 256 / R4, dg = 256 - dc * R4;
-    float4 v[XREG];
-    auto issue = [&](int tile, float4(&vv)[XREG]) {
-      const int b = tile / ntn;
-      const int xs_start = (tile - b * ntn) * p.n2 + p.xoff0;
-      const float* xb = p.x + (long long)b * p.x_bs;
-      int wc = wc0, wg = wg0;
-#pragma unroll
-      for (int u = 0; u < XREG; ++u) {
-        const int c = min(wc, p.C - 1);
-        int t = xs_start + 4 * wg;
-        t = (t >= 0 && t < p.L) ? t : 0;
-        vv[u] = *reinterpret_cast<const float4*>(xb + (long long)c * p.x_ld + t);
-        wc += dc; wg += dg;
-        if (wg >= R4) { wg -= R4; ++wc; }
-      }
-    };
-    auto publish = [&](int tile, const float4(&vv)[XREG]) {
-      const int b = tile / ntn;
-      const int xs_start = (tile - b * ntn) * p.n2 + p.xoff0;
-      int wc = wc0, wg = wg0;
-#pragma unroll
-      for (int u = 0; u < XREG; ++u) {
-        if (pl + u * 256 < total) {
-          const int t = xs_start + 4 * wg;
-          float4 q = vv[u];
-          q.x = (t >= 0 && t < p.L) ? q.x : 0.f;
-          q.y = (t + 1 >= 0 && t + 1 < p.L) ? q.y : 0.f;
-          q.z = (t + 2 >= 0 && t + 2 < p.L) ? q.z : 0.f;
-          q.w = (t + 3 >= 0 && t + 3 < p.L) ? q.w : 0.f;
-          q.x = fmaxf(q.x, q.x * p.slope);
-          q.y = fmaxf(q.y, q.y * p.slope);
-          q.z = fmaxf(q.z, q.z * p.slope);
-          q.w = fmaxf(q.w, q.w * p.slope);
-          *reinterpret_cast<float4*>(XT + wc * p.xrow + 4 * wg) = q;
-        }
-        wc += dc; wg += dg;
-        if (wg >= R4) { wg -= R4; ++wc; }
-      }
-    };
-    int tile = blockIdx.x;
-    issue(tile, v);
-    for (int j = 0; j < ntl; ++j) {
-      publish(tile, v);                                    // waits for the requests of this tile
-      fz_barrier();                                        // S1: x tile ready
-      tile += gridDim.x;
-      if (j + 1 < ntl) issue(tile, v);                     // in flight until the next publish
-      fz_barrier();                                        // S2: c1 done, residual pulled
-      fz_barrier();                                        // S3: activation tile written
-      fz_barrier();                                        // S4: c2 done -> the LDS tile may be overwritten
-    }
-    return;
-  }
-
-  // ======================================================================= MFMA waves
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int mt_ = wm;
-  const int ncol0_ = wn * NR * 32;
-  const float inv_slope = 1.0f / p.slope;
+  const int tl = xcd_linear(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z, p.xcd);
+  const int b = tl / (int)gridDim.x;
+  const int t0 = (tl - b * (int)gridDim.x) * G::N2;        // first output sample of this tile
+  const int L = p.L;
+  const float slope = p.slope;
+  long long ts[6] = {0, 0, 0, 0, 0, 0};                    // diagnostics: 100 MHz wall-clock stamps of the phases
+  if (p.dbg) ts[0] = (long long)wall_clock64();
+  // ---- stage the x tile: all C channels, columns [t0 + XOFF0, +XROW); zero outside [0, L); holds lrelu(x).
+  // Thread (r0, g) of the first RPP * R4 threads owns float4 group g of rows r0, r0 + RPP, r0 + 2 RPP, ...: the global
+  // address of pass u is a wave-uniform row base plus one per-thread offset, the LDS address one per-thread base plus
+  // an immediate - no per-slot address arithmetic on the vector ALU.
+  {
+    constexpr int RPP = G::RPP, NPASS = G::NPASS;
+    const int xs_start = t0 + G::XOFF0;
+    const int r0 = tid / R4, g = tid - r0 * R4;
+    const bool mine = tid < RPP * R4;
+    const char* const xb = reinterpret_cast<const char*>(p.x + (long long)b * p.x_bs);
+    const long long ldb = (long long)p.x_ld * 4;
+    const bool interior = xs_start >= 0 && xs_start + XROW <= L;
+    float4 v[NPASS];
+    if (interior) {
+      const int r0c = mine ? r0 : 0;                       // idle threads (tid >= RPP * R4) re-read row 0
+      const unsigned toff = (unsigned)(r0c * p.x_ld + xs_start + 4 * g) * 4u;
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u) {
+        if (u * RPP + RPP - 1 < C) {                       // compile time: every row of this pass exists
+          v[u] = *reinterpret_cast<const float4*>(xb + (long long)(u * RPP) * ldb + toff);
+        } else {                                           // last, partial pass: rows beyond C re-read row C-1 (not written)
+          const int c = min(r0c + u * RPP, C - 1);
+          v[u] = *reinterpret_cast<const float4*>(xb + (long long)c * ldb + (long long)(xs_start + 4 * g) * 4);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u) {
+        const int c = min(r0 + u * RPP, C - 1);
+        int t = xs_start + 4 * g;
+        t = (t >= 0 && t + 3 < L) ? t : 0;
+        v[u] = *reinterpret_cast<const float4*>(xb + (long long)c * ldb + (long long)t * 4);
+      }
+      const int t = xs_start + 4 * g;
+      if (!(t >= 0 && t + 3 < L)) {      // a group that straddles an end: element-wise (rows are only 16-byte aligned as a whole)
+#pragma unroll
+        for (int u = 0; u < NPASS; ++u) {
+          const int c = min(r0 + u * RPP, C - 1);
+          const float* row = reinterpret_cast<const float*>(xb + (long long)c * ldb);
+          v[u].x = (t >= 0 && t < L) ? row[t] : 0.f;
+          v[u].y = (t + 1 >= 0 && t + 1 < L) ? row[t + 1] : 0.f;
+          v[u].z = (t + 2 >= 0 && t + 2 < L) ? row[t + 2] : 0.f;
+          v[u].w = (t + 3 >= 0 && t + 3 < L) ? row[t + 3] : 0.f;
+        }
+      }
+    }
+    float* const dst = XT + r0 * XROW + 4 * g;
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u) {
+      const bool full = u * RPP + RPP - 1 < C;            // compile time: every row of this pass exists
+      if (mine && (full || r0 + u * RPP < C)) {
+        float4 q = v[u];
+        q.x = fmaxf(q.x, q.x * slope);
+        q.y = fmaxf(q.y, q.y * slope);
+        q.z = fmaxf(q.z, q.z * slope);
+        q.w = fmaxf(q.w, q.w * slope);
+        *reinterpret_cast<float4*>(dst + u * RPP * XROW) = q;
+      }
+    }
+  }
+  const int mt = wm;                                       // this wave's 32-row tile
+  const int ncol0 = wn * NR * 32;
+  const char* const w1 = reinterpret_cast<const char*>(p.wp1) + (size_t)mt * G::KSG * 1024;
+  const char* const w2 = reinterpret_cast<const char*>(p.wp2) + (size_t)mt * G::KSG * 1024;
+  const unsigned voff = (unsigned)lane * 16u;
   f32x16 acc[NR];
-  int tile = blockIdx.x;
-  for (int j = 0; j < ntl; ++j, tile += gridDim.x) {
-    const int b = tile / ntn;
-    const int t0 = (tile - b * ntn) * p.n2;
-    int opq = 0;
-    asm volatile("" : "+s"(opq));      // opaque zero: keeps tile-invariant loads (bias) and the ~80 tile-invariant LDS /
-    const int mt = mt_ + opq;          // global address registers of the exchange and the epilogue inside the loop
-    const int ncol0 = ncol0_ + opq;    // (hoisted, they push the kernel past the 128 registers two workgroups need)
-    // ---- phase A: c1 on columns m in [0, NA) <-> global time t0 - h2 + m
+  // ---- phase A: c1 on columns m in [0, NA) <-> global time t0 - PAD2 + m
+  {
+    const float* bias = p.bias1 + mt * 32 + 4 * hi;
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr)
+    for (int i = 0; i < 16; ++i) {
+      const float bv = bias[(i & 3) + 8 * (i >> 2)];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias1[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
-    fz_barrier();                                          // S1
-    {
-      const int col0 = ncol0 + l31 - h2 - p.pad1 - p.xoff0;
-      fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp1), (long long)mt * p.ksg1 * 64 + lane, p.ksg1, XT, p.xrow, col0,
-                            p.ktaps, p.dil1, p.nchunks, hi, p.slope);
+      for (int nr = 0; nr < NR; ++nr) acc[nr][i] = bv;
     }
-    float resv[NR][16];
+  }
+  __syncthreads();
+  if (p.dbg) ts[1] = (long long)wall_clock64();
+  const unsigned lds0 = (unsigned)(size_t)lds;           // LDS byte address of the dynamic segment
+  gemm_ct<NR, XROW, G::NCH, K, D>(acc, w1, voff, lds0 + (unsigned)(hi * XROW + (ncol0 + l31 - G::PAD2 - G::PAD1 - G::XOFF0)) * 4u);
+  if (p.dbg) ts[2] = (long long)wall_clock64();
+  // The x tile is now only needed for the residual: pull this wave's values into registers, then (after a barrier) the
+  // same LDS region is overwritten with lrelu(c1(.)) as c2's B operand.
+  const float inv_slope = 1.0f / slope;
+  float resv[NR][16];
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-      const int n = ncol0 + nr * 32 + l31;
-      const int cidx = min(n - p.xoff0, p.xrow - 1);
-      const float* rbase = XT + (mt * 32 + 4 * hi) * p.xrow + cidx;
+  for (int nr = 0; nr < NR; ++nr) {
+    const int cidx = min(ncol0 + nr * 32 + l31 - G::XOFF0, XROW - 1);
+    const float* rbase = XT + (mt * 32 + 4 * hi) * XROW + cidx;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
-        resv[nr][r] = fminf(v, v * inv_slope);      // inv_slope > 1: min picks v*inv_slope for v < 0, v otherwise
+    for (int r = 0; r < 16; ++r) {
+      const float v = rbase[((r & 3) + 8 * (r >> 2)) * XROW];
+      resv[nr][r] = fminf(v, v * inv_slope);               // x from lrelu(x) (see the generic kernel)
+    }
+  }
+  __syncthreads();
+  {
+    float* ybase = YT + (mt * 32 + 4 * hi) * YROW + ncol0 + l31;
+    const int tA0 = t0 - G::PAD2 + ncol0 + l31;            // global time of this lane's first c1 column
+    if (t0 - G::PAD2 >= 0 && t0 - G::PAD2 + G::NA <= L) {  // whole c1 range inside [0, L): no zero padding to apply
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[nr][r];
+          ybase[((r & 3) + 8 * (r >> 2)) * YROW + nr * 32] = fmaxf(v, v * slope);
+        }
+    } else {
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) {
+        const int tA = tA0 + nr * 32;
+        const bool ok = tA >= 0 && tA < L;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[nr][r];
+          ybase[((r & 3) + 8 * (r >> 2)) * YROW + nr * 32] = ok ? fmaxf(v, v * slope) : 0.f;
+        }
       }
     }
-    fz_barrier();                                          // S2
+  }
+  // ---- phase B: c2 on the interior columns n in [0, N2) <-> global time t0 + n
+  {
+    const float* bias = p.bias2 + mt * 32 + 4 * hi;
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-      const int m = ncol0 + nr * 32 + l31;
-      const int tA = t0 - h2 + m;
-      const bool ok = tA >= 0 && tA < p.L;
+    for (int i = 0; i < 16; ++i) {
+      const float bv = bias[(i & 3) + 8 * (i >> 2)];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float v = acc[nr][r];
-        v = fmaxf(v, v * p.slope);
-        YT[row * p.yrow + m] = ok ? v : 0.f;
-      }
+      for (int nr = 0; nr < NR; ++nr) acc[nr][i] = bv;
     }
+  }
+  __syncthreads();
+  if (p.dbg) ts[3] = (long long)wall_clock64();
+  if (ncol0 >= G::N2 || t0 + ncol0 >= L) return;
+  gemm_ct<NR, YROW, G::NCH, K, 1>(acc, w2, voff, lds0 + (unsigned)(hi * YROW + ncol0 + l31) * 4u);
+  if (p.dbg) ts[4] = (long long)wall_clock64();
+  // ---- epilogue: + residual, sink flags, store.  Row bases are wave-uniform, the lane adds one offset.
+  const long long row0 = (long long)b * p.y_bs + (long long)(mt * 32) * p.y_ld;
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr)
+  for (int nr = 0; nr < NR; ++nr) {
+    const int n = ncol0 + nr * 32 + l31;
+    const int t = t0 + n;
+    if (n >= G::N2 || t >= L) continue;
+    const unsigned lo = (unsigned)(4 * hi * p.y_ld + t) * 4u;
+    char* const yb = reinterpret_cast<char*>(p.y + row0);
+    float vo[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias2[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
-    fz_barrier();                                          // S3
-    const bool live = !(ncol0 >= p.n2 || t0 + ncol0 >= p.L);
-    if (live)
-      fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp2), (long long)mt * p.ksg2 * 64 + lane, p.ksg2, YT, p.yrow,
-                            ncol0 + l31, p.ktaps, 1, p.nchunks, hi, 1.0f);
-    fz_barrier();                                          // S4: the loaders may overwrite the tile while the stores go out
-    if (!live) continue;
-#pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-      const int n = ncol0 + nr * 32 + l31;
-      const int t = t0 + n;
-      if (n >= p.n2 || t >= p.L) continue;
-      float* ybase = p.y + (long long)b * p.y_bs + (long long)(mt * 32 + 4 * hi) * p.y_ld + t;
+    for (int r = 0; r < 16; ++r) vo[r] = acc[nr][r] + resv[nr][r];
+    if (p.flags & F_ACC) {
       float yo[16];
-      if (p.flags & F_ACC) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld];
-      }
-      float vo[16];
+      for (int r = 0; r < 16; ++r) yo[r] = *reinterpret_cast<const float*>(yb + (size_t)((r & 3) + 8 * (r >> 2)) * p.y_ld * 4 + lo);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[nr][r] + resv[nr][r];
-        if (p.flags & F_ACC) v = yo[r] + v;
-        vo[r] = v;
-      }
-      if (p.flags & F_DIV) {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vo[r] = vo[r] / p.div;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld] = vo[r];
+      for (int r = 0; r < 16; ++r) vo[r] = yo[r] + vo[r];
     }
+    if (p.flags & F_DIV) {          // one uniform branch (an in-loop `if` becomes 16 unconditional divisions)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vo[r] = vo[r] / p.div;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yb + (size_t)((r & 3) + 8 * (r >> 2)) * p.y_ld * 4 + lo) = vo[r];
+  }
+  if (p.dbg && threadIdx.x == 0) {
+    ts[5] = (long long)wall_clock64();
+    long long* d = p.dbg + 8 * (blockIdx.x + (long long)gridDim.x * blockIdx.z);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = ts[i];
+    d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_ID: wave, simd, cu, sh, se
+    d[7] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);      // XCC_ID
   }
 }
 
+// (Half-width tiles, NRT = 1, for launches with fewer workgroups than CUs were measured neutral at 1 x 200 frames.)
+template <int C, int K, int D>
+static int launch_ct(const FusedArgs& a, int B, int L, hipStream_t st) {
+  using G = RbGeo<C, K, D, 2>;
+  static_assert(G::N2 > 0 && G::LDS_BYTES <= 160 * 1024, "tile does not fit");
+  auto kern = resblock_fused_ct_kernel<C, K, D, 2>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const int ntn = (L + G::N2 - 1) / G::N2;
+  size_t lds = (size_t)G::LDS_BYTES;
+  if (const char* e = getenv("SVOC_RB_LDS_MIN")) lds = std::max(lds, (size_t)atoi(e));      // diagnostics (tools/rb_timeline.py): cap the occupancy
+  hipLaunchKernelGGL(kern, dim3(ntn, 1, B), dim3(256), lds, st, a);
+  return SVOC_OK;
+}
+
+// Dispatch on the compile-time geometries of the model (C = 32 / 64, k = 3 / 7 / 11, c1 dilation 1 / 3 / 5).  Returns
+// false (nothing launched) for any other shape: the generic kernel above handles it.
+static bool launch_v2(const FusedArgs& a, const PackedConv& c1, const PackedConv& c2, int B, int L, hipStream_t st, int* rc) {
+  const int C = c1.Cin, k = c1.ktaps, d = c1.dil;
+  if (!resblock_fused_ct_supported(C, k, d)) return false;
+  if ((long long)4 * 32 * a.y_ld + L >= (1LL << 30)) return false;     // 32-bit lane offsets
+#define SVOC_RB(CC, KK, DD) if (C == CC && k == KK && d == DD) { *rc = launch_ct<CC, KK, DD>(a, B, L, st); return true; }
+  SVOC_RB(32, 3, 1) SVOC_RB(32, 3, 3) SVOC_RB(32, 3, 5) SVOC_RB(32, 7, 1) SVOC_RB(32, 7, 3) SVOC_RB(32, 7, 5)
+  SVOC_RB(32, 11, 1) SVOC_RB(32, 11, 3) SVOC_RB(32, 11, 5)
+  SVOC_RB(64, 3, 1) SVOC_RB(64, 3, 3) SVOC_RB(64, 3, 5) SVOC_RB(64, 7, 1) SVOC_RB(64, 7, 3) SVOC_RB(64, 7, 5)
+  SVOC_RB(64, 11, 1) SVOC_RB(64, 11, 3) SVOC_RB(64, 11, 5)
+#undef SVOC_RB
+  return false;
+}
+
 // Eligibility + launch.  Returns 1 if the fused kernel does not apply (caller runs the two convolutions).
+bool resblock_fused_ct_supported(int C, int k, int dil) {
+  const char* ev = getenv("SVOC_FUSE_V");
+  if (ev && atoi(ev) == 1) return false;
+  return (C == 32 || C == 64) && (k == 3 || k == 7 || k == 11) && (dil == 1 || dil == 3 || dil == 5);
+}
+
 int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const float* x, long long x_bs, int x_ld, float* y,
                           long long y_bs, int y_ld, unsigned flags, float div, int B, int L, hipStream_t st) {
   static const bool enabled = !(getenv("SVOC_FUSE") && atoi(getenv("SVOC_FUSE")) == 0);
@@ -466,24 +642,9 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
     snprintf(d, sizeof(d), "fusedRB C%-4d k%-2d d%-2d N%-7d B%-3d NA%d", C, k, c1.dil, L, B, NA);
     prof_idx = prof_begin(st, d, (c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L);
   }
-  const int ncu = device_cu_count();
-  static const bool ws_on = getenv("SVOC_FUSE_WS") && atoi(getenv("SVOC_FUSE_WS")) != 0;   // opt-in: measured at parity
-  const long long total_tiles = (long long)ntn * B;
-  const int xslots = (C * (a.xrow / 4) + 255) / 256;        // float4 per loader lane
-  // persistent loader-wave variant: two 8-wave workgroups per CU, needs enough tiles to pipeline and the tile in 10/12 float4 per loader lane
-  const bool use_ws = ws_on && total_tiles >= 8LL * ncu && total_tiles < 0x7fffffffLL && xslots <= (C == 32 ? 10 : 12) && 2 * lds <= 160 * 1024;
-  if (use_ws) {
-    const int gx = (int)std::min<long long>(total_tiles, 2LL * ncu);
-    a.dbg = nullptr;
-    if (C == 32) {
-      auto kern = resblock_fused_ws_kernel<1, 4, 2, 10>;
-      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-      hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, a, ntn, (int)total_tiles);
-    } else {
-      auto kern = resblock_fused_ws_kernel<2, 2, 2, 12>;
-      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-      hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, a, ntn, (int)total_tiles);
-    }
+  int rc2 = SVOC_OK;
+  if (launch_v2(a, c1, c2, B, L, st, &rc2)) {
+    if (rc2 != SVOC_OK) return rc2;       // launched by the compile-time-specialised kernel
   } else if (C == 32) {
     auto kern = resblock_fused_kernel<1, 4, 2>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));

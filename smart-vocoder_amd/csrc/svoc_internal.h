@@ -159,6 +159,7 @@ void set_debug_stamp_buffer(long long* p);
 long long* debug_stamp_buffer();   // misc_kernels.hip: device buffer for per-workgroup cycle stamps, or nullptr
 int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const float* x, long long x_bs, int x_ld, float* y,
                           long long y_bs, int y_ld, unsigned flags, float div, int B, int L, hipStream_t st);
+bool resblock_fused_ct_supported(int C, int k, int dil);   // shapes served by the compile-time-specialised kernel
 
 // wn_fused.hip: one WN layer (in_layer -> gate -> res_skip -> residual/skip) in one kernel; returns 1 when not eligible
 int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H, const float* x, long long x_bs, int x_ld,

@@ -463,19 +463,26 @@ def test_folded_weight_file_round_trip(M, net, tmp_path):
     assert (o - o_ref).abs().max().item() <= 1e-6
 
 
+BATCH_TOL = 2e-6      # |waveform| <= 1: kernel variants (tile shape, K split) are chosen from the launch size, so an utterance run
+                      # alone and inside a batch may be summed in a different order; equal to fp32 rounding, deterministic per shape
+
+
 def test_infer_batch_independence(M, net):
-    """utterances are independent: a batch equals the same utterances run one by one (basis of the multi-GPU shard)."""
+    """utterances are independent: a batch equals the same utterances run one by one (basis of the multi-GPU shard), to
+    fp32 rounding (see BATCH_TOL), and two runs of the same shape are bit-identical."""
     mel, ln, eps = cases.infer_inputs("ragged")
     o, *_ = net.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=0.667, eps=T(eps).cuda())
+    o2, *_ = net.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=0.667, eps=T(eps).cuda())
+    assert torch.equal(o, o2)
     for b in range(mel.shape[0]):
         ob, *_ = net.infer(T(mel[b:b + 1]).cuda(), T(ln[b:b + 1]).cuda(), noise_scale=0.667, eps=T(eps[b:b + 1]).cuda())
-        assert torch.equal(ob[0], o[b]), b
+        assert (ob[0] - o[b]).abs().max().item() <= BATCH_TOL, b
 
 
 def test_full_size_properties(M, net):
     """BASELINE.json configs[1] (16 x 512 frames, the bench workload), where the oracle is too slow: size-independent
     properties instead.  (a) two runs are bit-identical (no atomics / race in the grouped and multi-stream launches);
-    (b) every utterance equals its single-utterance run bit for bit; (c) max_len truncates the
+    (b) every utterance equals its single-utterance run to fp32 rounding (BATCH_TOL); (c) max_len truncates the
     decoder INPUT (models.py:338), so its output equals the full one up to the decoder's receptive field from the cut;
     (d) flow^-1 followed by flow returns z_p; (e) the waveform is finite and inside tanh's range."""
     Bn, Tn = 16, 512
@@ -487,10 +494,10 @@ def test_full_size_properties(M, net):
     assert torch.equal(o1, o2)                                         # (a)
     for b in (0, 3, 9, 15):                                            # (b)
         ob = net.infer(mel[b:b + 1], ln[b:b + 1], noise_scale=0.667, eps=eps[b:b + 1])[0]
-        assert torch.equal(ob[0], o1[b]), b
+        assert (ob[0] - o1[b]).abs().max().item() <= BATCH_TOL, b
     om = net.infer(mel, ln, noise_scale=0.667, eps=eps, max_len=300)[0]
     keep = (300 - M.models.SynthesizerTrn.RECEPTIVE_FRAMES) * 256      # (c)
-    assert om.shape[2] == 300 * 256 and torch.equal(om[:, :, :keep], o1[:, :, :keep])
+    assert om.shape[2] == 300 * 256 and (om[:, :, :keep] - o1[:, :, :keep]).abs().max().item() <= BATCH_TOL
     assert not torch.equal(om[:, :, -256:], o1[:, :, 299 * 256:300 * 256])    # the cut really is upstream of the decoder
     back = net.flow(z, mask, reverse=False)                            # (d)
     err = ((back - z_p * mask).abs().max() / z_p.abs().max()).item()
@@ -572,11 +579,13 @@ def test_c5_full_size(M, net):
         assert (ob[0] - o1[b]).abs().max().item() <= 1e-5, b
     sd = sdT(cases.full_model_weights())
     for b in (7, 2):                                                               # (d)
-        end = int(ln[b]); ctx = 256; a = end - ctx
+        # frames beyond an utterance's length are masked to z = 0 but still decoded (the decoder takes no mask,
+        # models.py:338), and their bias-driven signal reaches the valid tail: give the oracle the same right context
+        end = int(ln[b]); ctx = 256; a = end - ctx; e2 = min(Tn, end + 128)
         with torch.no_grad():
-            o_ref, *_ = O.infer(sd, T(mel[b:b + 1, :, a:end]), torch.tensor([ctx]), T(eps[b:b + 1, :, a:end]), 0.667)
+            o_ref, *_ = O.infer(sd, T(mel[b:b + 1, :, a:e2]), torch.tensor([ctx]), T(eps[b:b + 1, :, a:e2]), 0.667)
         got = o1[b, 0, (end - 64) * 256:end * 256].cpu().numpy()
-        want = o_ref[0, 0, (ctx - 64) * 256:].numpy()
+        want = o_ref[0, 0, (ctx - 64) * 256:ctx * 256].numpy()
         err = got - want
         rms, ref = float(np.sqrt((err ** 2).mean())), float(np.sqrt((want ** 2).mean()))
         assert rms <= 1e-3 and rms / ref <= 1e-4, (b, rms, rms / ref)
@@ -608,9 +617,9 @@ def test_c3_full_size_with_speaker_conditioning(M):
     assert torch.equal(o, dec(z * mc, g=gc))
     for b in (0, 4, 31):
         zb = flow(zpc[b:b + 1], mc[b:b + 1], g=gc[b:b + 1], reverse=True)
-        assert torch.equal(zb[0], z[b]), b
-        ob = dec(zb * mc[b:b + 1], g=gc[b:b + 1])
-        assert torch.equal(ob[0], o[b]), b
+        assert (zb[0] - z[b]).abs().max().item() <= 1e-5, b
+        ob = dec(z[b:b + 1] * mc[b:b + 1], g=gc[b:b + 1])
+        assert (ob[0] - o[b]).abs().max().item() <= BATCH_TOL, b
     sdt = sdT(sd)
     b = 4
     with torch.no_grad():

@@ -1,6 +1,6 @@
 """N>1 data path with the REAL model on one GPU: two ranks share device 0 and talk over gloo (the collective an 8-GPU
 node runs over RCCL/xGMI is the same scatter/gather in smart-vocoder_amd/parallel.py, with host staging only for gloo).
-Checks infer_sharded == single-process infer bit for bit, and that bench.py's --gpus 2 path runs end to end.
+Checks infer_sharded == single-process infer (to fp32 rounding: kernel variants depend on the launch size), and that bench.py's --gpus 2 path runs end to end.
 No scaling number is derived from this setup."""
 import json
 import os
@@ -42,7 +42,8 @@ def _worker(rank, world, port, B, T, q):
         o = parallel.infer_sharded(net, mel, ln, eps, noise_scale=0.667, src=0)
         if rank == 0:
             ref = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
-            ok = o.is_cuda and o.shape == ref.shape and torch.equal(o, ref)
+            # shards and the whole batch may take different kernel variants (chosen from the launch size): fp32 rounding
+            ok = o.is_cuda and o.shape == ref.shape and (o - ref).abs().max().item() <= 2e-6
         else:
             ok = o is None
     q.put((rank, bool(ok)))
