@@ -137,6 +137,7 @@ struct ResSink { float* y; long long bs; int ld; unsigned flags; float div; };
 struct ResBlock {
   int kind = 1, C = 0, K = 0, ND = 0;
   std::vector<std::unique_ptr<PackedConv>> c1, c2;
+  std::vector<std::unique_ptr<PackedWino>> w1, w2;   // Winograd form of the undilated convolutions (null where not applicable)
   DevBuf ws;
 
   int create(int kind_, int channels, int k, const int* dil, int nd, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
@@ -145,11 +146,22 @@ struct ResBlock {
     for (int i = 0; i < ND; ++i) {
       PackSpec sp{}; sp.Cin = C; sp.Cout = C; sp.K = K; sp.dil = dil[i];
       c1.emplace_back(new PackedConv());
-      SVOC_TRY(pack_conv_named(*c1.back(), sp, tab, prefix + (kind == 1 ? "convs1." : "convs.") + std::to_string(i), st));
+      const std::string n1 = prefix + (kind == 1 ? "convs1." : "convs.") + std::to_string(i);
+      SVOC_TRY(pack_conv_named(*c1.back(), sp, tab, n1, st));
+      w1.emplace_back(nullptr);
+      if (C >= 128 && wino_supported(C, C, K, dil[i])) {       // C = 32 / 64 run the fused kernel instead
+        w1.back().reset(new PackedWino());
+        SVOC_TRY(pack_wino_named(*w1.back(), C, C, K, tab, n1, st));
+      }
       if (kind == 1) {
         PackSpec s2{}; s2.Cin = C; s2.Cout = C; s2.K = K; s2.dil = 1;
         c2.emplace_back(new PackedConv());
         SVOC_TRY(pack_conv_named(*c2.back(), s2, tab, prefix + "convs2." + std::to_string(i), st));
+        w2.emplace_back(nullptr);
+        if (C >= 128 && wino_supported(C, C, K, 1)) {
+          w2.back().reset(new PackedWino());
+          SVOC_TRY(pack_wino_named(*w2.back(), C, C, K, tab, prefix + "convs2." + std::to_string(i), st));
+        }
       }
     }
     return SVOC_OK;
@@ -188,7 +200,9 @@ struct ResBlock {
         a.pre_slope = 0.1f; a.in_mask = mask; a.in_mask_bs = mask_bs;
         a.Ncols = L;
         set_out(a.out[0], scratch, bs, ld, C);
-        SVOC_TRY(launch_conv(*c1[i], a, B, st));
+        int rw = w1[i] ? launch_conv_wino(*w1[i], a, B, st) : 1;
+        if (rw < 0) return rw;
+        if (rw == 1) SVOC_TRY(launch_conv(*c1[i], a, B, st));
         cin = scratch; cin_bs = bs; cin_ld = ld;
       }
       ConvArgs a = mk_args();
@@ -204,7 +218,12 @@ struct ResBlock {
       }
       set_res(a.out[0], cur, cur_bs, cur_ld);
       if (last && wait_before_last) SVOC_HIP(hipStreamWaitEvent(st, wait_before_last, 0));
-      SVOC_TRY(launch_conv(kind == 1 ? *c2[i] : *c1[i], a, B, st));
+      {
+        const PackedWino* pw = kind == 1 ? w2[i].get() : w1[i].get();
+        int rw = pw ? launch_conv_wino(*pw, a, B, st) : 1;
+        if (rw < 0) return rw;
+        if (rw == 1) SVOC_TRY(launch_conv(kind == 1 ? *c2[i] : *c1[i], a, B, st));
+      }
       if (last && record_after_last) SVOC_HIP(hipEventRecord(record_after_last, st));
       cur = nxt; cur_bs = bs; cur_ld = ld;
     }
@@ -447,9 +466,21 @@ struct Generator {
     for (int it = 0; it < ND; ++it) {
       const bool last = it == ND - 1;
       const PackedConv* pcs[3];
+      const PackedWino* pws[3];
       ConvArgs as[3];
       float* scratch[3];
       float* nxt[3];
+      // one step of the three chains in one launch: the Winograd kernel where every member has that form (d = 1), else
+      // the direct grouped kernel, else one by one
+      auto launch3 = [&](bool wino) -> int {
+        int r = 1;
+        if (wino) r = launch_conv_wino_group(pws, as, nk, B, st);
+        if (r == 1) r = launch_conv_group(pcs, as, nk, B, st);
+        if (r < 0) return r;
+        if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
+        return SVOC_OK;
+      };
+      bool all_w = true;
       for (int q = 0; q < nk; ++q) {
         const int j = order[q];
         float* A = bufs[3 + 2 * j];
@@ -463,10 +494,11 @@ struct Generator {
         set_out(a.out[0], scratch[q], bs, ld, C);
         as[q] = a;
         pcs[q] = rbs[stage * nk + j]->c1[it].get();
+        pws[q] = rbs[stage * nk + j]->w1[it].get();
+        all_w = all_w && pws[q] != nullptr;
       }
-      int r = launch_conv_group(pcs, as, nk, B, st);
-      if (r < 0) return r;
-      if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
+      SVOC_TRY(launch3(all_w));
+      all_w = true;
       for (int q = 0; q < nk; ++q) {
         const int j = order[q];
         ConvArgs a = mk_args();
@@ -477,11 +509,11 @@ struct Generator {
         set_res(a.out[0], cur[j], bs, ld);
         as[q] = a;
         pcs[q] = rbs[stage * nk + j]->c2[it].get();
+        pws[q] = rbs[stage * nk + j]->w2[it].get();
+        all_w = all_w && pws[q] != nullptr;
       }
       if (!last) {
-        r = launch_conv_group(pcs, as, nk, B, st);
-        if (r < 0) return r;
-        if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
+        SVOC_TRY(launch3(all_w));
         for (int q = 0; q < nk; ++q) cur[order[q]] = nxt[q];
       } else {
         for (int j = 0; j < nk; ++j) {        // xs = sum_j ResBlock_j(x) / n, accumulated in chain order (models.py:149-155)
@@ -494,7 +526,9 @@ struct Generator {
           set_out(a.out[0], XS, bs, ld, C, fl);
           a.out[0].div = (float)nk;
           set_res(a.out[0], cur[j], bs, ld);
-          SVOC_TRY(launch_conv(*pcs[q], a, B, st));
+          int rw = pws[q] ? launch_conv_wino(*pws[q], a, B, st) : 1;
+          if (rw < 0) return rw;
+          if (rw == 1) SVOC_TRY(launch_conv(*pcs[q], a, B, st));
         }
       }
     }
@@ -1148,6 +1182,27 @@ int svoc_conv1d(void* stream, const float* x, const float* weight_v, const float
   if (residual) set_res(a.out[0], residual, (long long)Cout * L, L);
   SVOC_TRY(launch_conv(pc, a, B, st));
   SVOC_HIP(hipStreamSynchronize(st));   // packed weights are freed on return
+  return SVOC_OK;
+  SVOC_GUARD_END
+}
+int svoc_conv1d_winograd(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias,
+                         const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, float pre_slope) {
+  if (!x || !weight_v || !y || B <= 0 || L <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_conv1d_winograd: bad arguments");
+  if (!wino_supported(Cin, Cout, kernel_size, 1)) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "svoc_conv1d_winograd: kernel 3/7/11, channels multiples of 32, Cin >= 64");
+  SVOC_GUARD_BEGIN
+  hipStream_t st = as_stream(stream);
+  PackedWino pw;
+  SVOC_TRY(pack_wino(pw, Cin, Cout, kernel_size, weight_v, weight_g, bias, st));
+  ConvArgs a = mk_args();
+  set_in(a, x, (long long)Cin * L, L, L);
+  a.pre_slope = pre_slope;
+  a.Ncols = L;
+  set_out(a.out[0], y, (long long)Cout * L, L, Cout, residual ? (unsigned)F_RES : 0u);
+  if (residual) set_res(a.out[0], residual, (long long)Cout * L, L);
+  const int r = launch_conv_wino(pw, a, B, st, 0);
+  if (r == 1) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "svoc_conv1d_winograd: needs 16-byte aligned rows of even length (L %% 4 == 0)");
+  if (r < 0) return r;
+  SVOC_HIP(hipStreamSynchronize(st));   // transformed weights are freed on return
   return SVOC_OK;
   SVOC_GUARD_END
 }

@@ -19,6 +19,10 @@ rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d /tmp/pw --output-form
 python $R/tools/pmc_traffic.py /tmp/pr /tmp/pw $NK 2 > $O/${TAG}_pmc_hbm_traffic.json
 ( cd $R && python tools/profile_infer.py 16 512 3 ) > $O/${TAG}_per_layer_event_profile.txt 2>&1
 ( cd $R && python tools/latency_probe.py ) > $O/${TAG}_latency_by_shape.txt 2>&1
-( cd $R && tools/mfma_peak_probe ) > $O/${TAG}_mfma_peak_probe.txt 2>&1
-( cd $R && SVOC_STREAMS=0 python tools/clock_trace.py 16 512 3 ) > $O/${TAG}_shader_clock_trace.txt 2>&1
+
+
+ls -la $O
+( cd $R && SVOC_STREAMS=0 python tools/profile_infer.py 16 512 3 ) > $O/${TAG}_per_layer_event_profile_single_stream.txt 2>&1
+( cd $R && python tools/profile_infer.py 1 200 5 ) > $O/${TAG}_per_layer_event_profile_1x200.txt 2>&1
+( cd $R && BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 5 --warmup 2 ) > $O/${TAG}_bench_2ranks_gloo_one_gpu.json 2> $O/${TAG}_bench_2ranks_gloo_one_gpu.err
 ls -la $O
