@@ -104,8 +104,9 @@ def cpu_baseline(sd_np, seed):
 
 def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     """Per-launch duration of the dominant kernel, measured live with HIP events on the launch stream by the library's
-    event profiler (every GEMM-family launch bracketed by hipEventRecord): conv_group_kernel on the C=128 stage
-    (3 convolutions k=11/7/3 per launch, 40 % of the step).  Runs after the timed region."""
+    event profiler (every GEMM-family launch bracketed by hipEventRecord): the grouped launch of the C=128 stage's
+    three undilated convolutions k=11/7/3 (conv_wino_group_kernel<1>, Winograd F(2,3) form; conv_group_kernel when
+    SVOC_WINO=0).  Runs after the timed region."""
     from smart_vocoder_amd import _native
     _native.profile_enable(True)
     with torch.no_grad():
@@ -116,12 +117,12 @@ def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     _native.profile_enable(False)
     best = None
     for line in rep.splitlines():
-        if not line.startswith("group "):
+        if not (line.startswith("group ") or line.startswith("winoG ")):
             continue
         f = line.split()
         n, total_ms, mean_us, tfl = int(f[-4]), float(f[-3]), float(f[-2]), float(f[-1])
         if best is None or total_ms > best["total_ms"]:
-            best = dict(desc=" ".join(f[:-4]), n=n, total_ms=total_ms, mean_us=mean_us, tflops=tfl)
+            best = dict(desc=" ".join(f[:-4]), n=n, total_ms=total_ms, mean_us=mean_us, tflops=tfl, wino=line.startswith("winoG "))
     return best, rep
 
 
@@ -284,17 +285,24 @@ def main():
         # single kernel with the largest share, per-launch, measured live after the timed region.
         res["roofline"] = {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_mfma_kernel, conv_group_kernel, resblock_fused_kernel, wn_layer_fused(_ks)_kernel",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino(_group)_kernel (Winograd F(2,3)), conv_mfma_kernel, conv_group_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel",
+                           "note": "achieved = algorithmic direct-form 2*MAC of the convolutions (SURVEY.md 8d) / time; the Winograd kernels execute 2/3 - 8/11 of them as MFMAs",
                            "gemm_launches_per_step": stats["conv_launches"] / args.steps,
                            "convolutions_per_step": stats["convolutions"] / args.steps,
                            "small_kernel_launches_per_step": stats["other_launches"] / args.steps,
                            "flop_per_step": stats["conv_flops"] / args.steps,
                            "gpu_ms_per_step_rank0": gpu_ms / args.steps}
         if dom:
+            # Winograd form: the launch computes the same convolutions (same algorithmic 2*MAC) while
+            # issuing (8 + 5 + 2) / (11 + 7 + 3) of them as MFMAs, so `achieved` (algorithmic) may exceed the direct-form
+            # MFMA peak; `mfma_pipe_frac` prices the multiply-adds the matrix pipe really executed
+            executed = 15.0 / 21.0 if dom["wino"] else 1.0
             res["roofline"]["dominant_kernel"] = {
-                "name": "conv_group_kernel<2,2,2,2> " + dom["desc"], "launches_measured": dom["n"],
-                "avg_launch_us": dom["mean_us"], "flop_per_launch": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6,
+                "name": ("conv_wino_group_kernel<1> " if dom["wino"] else "conv_group_kernel<2,2,2,2> ") + dom["desc"],
+                "launches_measured": dom["n"], "avg_launch_us": dom["mean_us"],
+                "flop_per_launch": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6,
                 "achieved": dom["tflops"], "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "executed_mfma_flop_fraction": executed, "mfma_pipe_frac": dom["tflops"] * executed / FP32_MFMA_PEAK_TFLOPS,
                 "measured": "hipEventRecord around every launch on the launch stream (library event profiler), after the timed region"}
         # HBM traffic of the same workload from PMC counters: they cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 --pmc passes of THIS round's code (tools/pmc_traffic.py); older files are ignored.

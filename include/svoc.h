@@ -271,11 +271,11 @@ int svoc_fold_weight_norm(void* stream, const float* weight_v, const float* weig
 int svoc_conv1d(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias,
                 const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation,
                 float pre_slope);
-/* The same operation for dilation 1, kernel_size 3 / 7 / 11, Cin >= 64, channel counts multiples of 32 and L % 4 == 0,
- * computed in Winograd F(2,3) form (csrc/conv_wino.hip): what the decoder's C = 128 / 256 stages run for their
- * undilated convolutions.  Unit-test entry; returns SVOC_ERR_UNSUPPORTED for other shapes. */
+/* The same operation for kernel_size 3 / 7 / 11, dilation 1 / 3 / 5, Cin >= 64, channel counts multiples of 32 and
+ * L % 4 == 0, computed in Winograd F(2,3) form (csrc/conv_wino.hip): what the decoder's C = 128 / 256 stages run.
+ * Unit-test entry; returns SVOC_ERR_UNSUPPORTED for other shapes. */
 int svoc_conv1d_winograd(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias,
-                         const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size,
+                         const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation,
                          float pre_slope);
 /* F.leaky_relu -> weight-normed ConvTranspose1d(k, stride, padding=(k-stride)//2) (models.py:125-127, 147-148):
  * x [B,Cin,L], weight_v [Cin,Cout,k], weight_g [Cin,1,1] or NULL, y [B,Cout,L*stride] */

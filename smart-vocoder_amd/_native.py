@@ -102,7 +102,7 @@ SIGNATURES = {
     "svoc_flip_channels": (_I, [_P, _P, _P, _I, _I, _I]),
     "svoc_fold_weight_norm": (_I, [_P, _P, _P, _P, _L, _L]),
     "svoc_conv1d": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F]),
-    "svoc_conv1d_winograd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F]),
+    "svoc_conv1d_winograd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F]),
     "svoc_conv_transpose1d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F]),
 }
 

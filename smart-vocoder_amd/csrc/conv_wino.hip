@@ -41,21 +41,31 @@ struct WinoArgs {
 };
 struct WinoGroup { WinoArgs a[3]; int end[3]; int k[3]; };
 
-template <int K>
+// Dilation D (1, 3, 5) is handled through the polyphase view: a convolution with dilation D is D interleaved undilated
+// convolutions, so the pair of outputs that shares a group's four products is (n, n + D) instead of (n, n + 1).  A tile
+// holds PU = 64 - 64 % D pairs u = qq * D + phase (outputs n0 + 2 qq D + phase and that + D: contiguous blocks of 2 D
+// columns, tile width 2 PU = 128 / 126 / 120); group g then reads the V planes at column u + 2 g D and a direct tap
+// with q offset delta reads E / O at u + (delta + 1) D - everything else is unchanged.
+template <int K, int D>
 struct WinoGeo {
   static constexpr int G = (K + 1) / 4;                   // three-tap groups at tap offsets 0, 4, 8
   static constexpr int ND = G - 1;                        // left-over single taps (3, 7)
-  static constexpr int PAD = (K - 1) / 2;
+  static constexpr int PADT = (K - 1) / 2;                // padding in taps (columns: PADT * D)
   static constexpr int SLOTS = 4 * G + ND;                // weight slots per 32-channel chunk (a direct tap feeds E and O)
-  static constexpr int NQV = 64 + 2 * (G - 1);            // q' range of the V planes
-  static constexpr int NQE = 66;                          // q range of the E / O planes, origin q0 - 1
-  static constexpr int PQ = 72;                           // plane row stride (floats)
+  static constexpr int PU = (64 / D) * D;                 // output pairs per tile
+  static constexpr int W = 2 * PU;                        // output columns per tile
+  static constexpr int NUV = PU + 2 * (G - 1) * D;        // entries of a V plane row
+  static constexpr int NUE = PU + 2 * D;                  // entries of an E / O plane row (origin one q block before the tile)
+  static constexpr int PQV = (NUV + 3) & ~3;              // plane row strides (floats)
+  static constexpr int PQE = (NUE + 3) & ~3;
   static constexpr int NPL = ND > 0 ? 6 : 4;              // planes: V0..V3 (+ E, O)
-  static constexpr int XOFF = -8;                         // raw tile starts at n0 + XOFF
-  static constexpr int RAW = 144;                         // raw tile columns (multiple of 4)
+  static constexpr int XOFF = -((PADT * D + 3) & ~3);     // raw tile starts at n0 + XOFF (multiple of 4)
+  static constexpr int VMAX = (2 * (PU / D - 1 + 2 * (G - 1)) - PADT + 3) * D + D - 1;   // last position a V window reads
+  static constexpr int EMAX = ND > 0 ? 2 * PU + 2 * D - 1 : 0;                           // last position of the O plane
+  static constexpr int RAW = (((VMAX > EMAX ? VMAX : EMAX) + 1 - XOFF) + 3) & ~3;        // raw tile columns
   static constexpr int RAW_FLOATS = KC * RAW;
-  static constexpr int LDS_BYTES = (RAW_FLOATS + NPL * KC * PQ) * 4;
-  static constexpr int MFMA_PER_CHUNK = 16 * (4 * G + 2 * ND);
+  static constexpr int PL_FLOATS = 4 * KC * PQV + (ND > 0 ? 2 * KC * PQE : 0);
+  static constexpr int LDS_BYTES = (RAW_FLOATS + PL_FLOATS) * 4;
 };
 
 template <int OFF>
@@ -68,44 +78,60 @@ __device__ __forceinline__ float wino_lds_rd(unsigned addr) {
 __device__ __forceinline__ void wino_wait4(float (&b)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])); }
 __device__ __forceinline__ float wino_pick(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 
-// B fragments of one k-group (4 k-steps = channels 8*KG .. 8*KG+7) of plane PL at column offset COL: lane (l31, hi) reads
-// row 8*KG + 2*s + hi.  `baddr` = LDS byte address of planes + (hi * PQ + first q of the wave + l31) * 4.
-template <int PQ, int PL, int KG, int COL>
+// B fragments of one k-group (4 k-steps = channels 8*KG .. 8*KG+7) of a plane whose rows start BASE floats into the
+// plane area, row stride PQ, at column offset COL: lane (l31, hi) reads row 8*KG + 2*s + hi.
+// `baddr` = LDS byte address of the plane area + (hi * PQ + this lane's pair index u) * 4.
+template <int PQ, int BASE, int KG, int COL>
 __device__ __forceinline__ void wino_frag(float (&b)[4], unsigned baddr) {
-  constexpr int BASE = (PL * KC + 8 * KG) * PQ + COL;
-  b[0] = wino_lds_rd<(BASE) * 4>(baddr);
-  b[1] = wino_lds_rd<(BASE + 2 * PQ) * 4>(baddr);
-  b[2] = wino_lds_rd<(BASE + 4 * PQ) * 4>(baddr);
-  b[3] = wino_lds_rd<(BASE + 6 * PQ) * 4>(baddr);
+  constexpr int O = BASE + 8 * KG * PQ + COL;
+  b[0] = wino_lds_rd<(O) * 4>(baddr);
+  b[1] = wino_lds_rd<(O + 2 * PQ) * 4>(baddr);
+  b[2] = wino_lds_rd<(O + 4 * PQ) * 4>(baddr);
+  b[3] = wino_lds_rd<(O + 6 * PQ) * 4>(baddr);
 }
 
-template <int K>
+template <int T, int N, class F>
+__device__ __forceinline__ void wino_static_for(F&& f) {
+  if constexpr (T < N) {
+    f(std::integral_constant<int, T>{});
+    wino_static_for<T + 1, N>(f);
+  }
+}
+// step t of a chunk (see mfma_chunk): direct-tap steps request 8 fragment values (E and O), group steps 4
+template <int K> constexpr bool wino_step_direct(int t) { return t / 4 >= 4 * ((K + 1) / 4); }
+template <int K> constexpr int wino_step_reads(int t) {
+  return t >= 4 * (4 * ((K + 1) / 4) + (K + 1) / 4 - 1) ? 0 : (wino_step_direct<K>(t) ? 8 : 4);
+}
+
+template <int K, int D>
 __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const int by, const int bz) {
-  using Geo = WinoGeo<K>;
-  constexpr int G = Geo::G, ND = Geo::ND, PAD = Geo::PAD, PQ = Geo::PQ, RAW = Geo::RAW, SLOTS = Geo::SLOTS;
+  using Geo = WinoGeo<K, D>;
+  constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQV = Geo::PQV, PQE = Geo::PQE, RAW = Geo::RAW, SLOTS = Geo::SLOTS;
+  constexpr int PU = Geo::PU, XOFF = Geo::XOFF;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* const raw = wl;                                   // [KC][RAW]  lrelu(x), zero outside [0, L)
-  float* const pl = wl + Geo::RAW_FLOATS;                  // [NPL][KC][PQ]
+  float* const pl = wl + Geo::RAW_FLOATS;                  // V0..V3 [KC][PQV] each, then E, O [KC][PQE]
+  constexpr int EBASE = 4 * KC * PQV;                      // E plane offset inside the plane area (O follows)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int n0 = bx * 128;                                 // first output column of the workgroup
+  const int n0 = bx * Geo::W;                              // first output column of the workgroup
   const int mt = by * 2 + wm;                              // this wave's 32-row tile
   const bool row_ok = mt < p.mtiles;
   const int mtc = row_ok ? mt : p.mtiles - 1;
   const int L = p.L;
 
-  f32x16 M[4], D[2];
+  f32x16 M[4], Dd[2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { M[0][i] = 0.f; M[1][i] = 0.f; M[2][i] = 0.f; M[3][i] = 0.f; D[0][i] = 0.f; D[1][i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { M[0][i] = 0.f; M[1][i] = 0.f; M[2][i] = 0.f; M[3][i] = 0.f; Dd[0][i] = 0.f; Dd[1][i] = 0.f; }
 
-  // ---- raw staging: 32 channels x RAW columns = 36 float4 per channel, 1152 per chunk, 4.5 per thread
+  // ---- raw staging: 32 channels x RAW columns
   constexpr int R4 = RAW / 4, SU = (KC * R4 + 255) / 256;
   const float* xb = p.x + (long long)bz * p.x_bs;
-  const int xs_start = n0 + Geo::XOFF;
+  const int xs_start = n0 + XOFF;
   const float slope = p.pre_slope;
   float4 v[SU];
   auto issue = [&](int ch) {
@@ -141,122 +167,134 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
       }
     }
   };
-  // ---- transform pass: raw -> V0..V3 (q' = q0 + i, window raw[2i + 8 - PAD .. +3]) and E / O (q = q0 - 1 + i: raw[2i + 6], [2i + 7])
+  // ---- transform pass: raw -> V0..V3 and E / O.  V entry u' = q' D + phase: window d_j = raw[(2 q' - PADT + j) D + phase - XOFF];
+  // E / O entry e = (q + 1) D + phase: raw[2 q D + phase - XOFF], raw[(2 q + 1) D + phase - XOFF].
   auto transform = [&]() {
-    constexpr int NV2 = Geo::NQV / 2;                      // pairs of q' per channel
-    for (int it = tid; it < KC * NV2; it += 256) {
-      const int c = it / NV2, i = 2 * (it - c * NV2);
-      const float* r = raw + c * RAW + 2 * i + 8 - PAD;
-      const float d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4], d5 = r[5];
-      float* o = pl + c * PQ + i;
-      *reinterpret_cast<float2*>(o) = make_float2(d0 - d2, d2 - d4);
-      *reinterpret_cast<float2*>(o + KC * PQ) = make_float2(d1 + d2, d3 + d4);
-      *reinterpret_cast<float2*>(o + 2 * KC * PQ) = make_float2(d2 - d1, d4 - d3);
-      *reinterpret_cast<float2*>(o + 3 * KC * PQ) = make_float2(d1 - d3, d3 - d5);
-    }
-    if constexpr (ND > 0) {
-      constexpr int NE2 = Geo::NQE / 2;
-      for (int it = tid; it < KC * NE2; it += 256) {
-        const int c = it / NE2, i = 2 * (it - c * NE2);
-        const float* r = raw + c * RAW + 2 * i + 6;
-        const float2 a = *reinterpret_cast<const float2*>(r), b = *reinterpret_cast<const float2*>(r + 2);
-        float* o = pl + 4 * KC * PQ + c * PQ + i;
-        *reinterpret_cast<float2*>(o) = make_float2(a.x, b.x);
-        *reinterpret_cast<float2*>(o + KC * PQ) = make_float2(a.y, b.y);
+    if constexpr (D == 1) {
+      constexpr int NV2 = Geo::NUV / 2;                    // pairs of q' per channel (NUV is even)
+      for (int it = tid; it < KC * NV2; it += 256) {
+        const int c = it / NV2, i = 2 * (it - c * NV2);
+        const float* r = raw + c * RAW + 2 * i - PADT - XOFF;
+        const float d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4], d5 = r[5];
+        float* o = pl + c * PQV + i;
+        *reinterpret_cast<float2*>(o) = make_float2(d0 - d2, d2 - d4);
+        *reinterpret_cast<float2*>(o + KC * PQV) = make_float2(d1 + d2, d3 + d4);
+        *reinterpret_cast<float2*>(o + 2 * KC * PQV) = make_float2(d2 - d1, d4 - d3);
+        *reinterpret_cast<float2*>(o + 3 * KC * PQV) = make_float2(d1 - d3, d3 - d5);
+      }
+      if constexpr (ND > 0) {
+        constexpr int NE2 = Geo::NUE / 2;
+        for (int it = tid; it < KC * NE2; it += 256) {
+          const int c = it / NE2, i = 2 * (it - c * NE2);
+          const float* r = raw + c * RAW + 2 * (i - 1) - XOFF;
+          const float2 a = *reinterpret_cast<const float2*>(r), b = *reinterpret_cast<const float2*>(r + 2);
+          float* o = pl + EBASE + c * PQE + i;
+          *reinterpret_cast<float2*>(o) = make_float2(a.x, b.x);
+          *reinterpret_cast<float2*>(o + KC * PQE) = make_float2(a.y, b.y);
+        }
+      }
+    } else {
+      // two q' of one phase per item (they share two of their window samples)
+      constexpr int NQ = Geo::NUV / D, NQ2 = (NQ + 1) / 2;
+      for (int it = tid; it < KC * NQ2 * D; it += 256) {
+        const int c = it / (NQ2 * D), rem = it - c * (NQ2 * D);
+        const int q2 = rem / D, ph = rem - q2 * D;
+        const int qp = 2 * q2;
+        const float* r = raw + c * RAW + (2 * qp - PADT) * D + ph - XOFF;
+        const float d0 = r[0], d1 = r[D], d2 = r[2 * D], d3 = r[3 * D];
+        float* o = pl + c * PQV + qp * D + ph;
+        o[0] = d0 - d2; o[KC * PQV] = d1 + d2; o[2 * KC * PQV] = d2 - d1; o[3 * KC * PQV] = d1 - d3;
+        if (qp + 1 < NQ) {
+          const float d4 = r[4 * D], d5 = r[5 * D];
+          o[D] = d2 - d4; o[KC * PQV + D] = d3 + d4; o[2 * KC * PQV + D] = d4 - d3; o[3 * KC * PQV + D] = d3 - d5;
+        }
+      }
+      if constexpr (ND > 0) {
+        constexpr int NQE = Geo::NUE / D;
+        for (int it = tid; it < KC * NQE * D; it += 256) {
+          const int c = it / (NQE * D), rem = it - c * (NQE * D);
+          const int qe = rem / D, ph = rem - qe * D;       // q = qe - 1
+          const float* r = raw + c * RAW + 2 * (qe - 1) * D + ph - XOFF;
+          float* o = pl + EBASE + c * PQE + qe * D + ph;
+          o[0] = r[0]; o[KC * PQE] = r[D];
+        }
       }
     }
   };
 
   // ---- MFMA phase of one chunk.  Weight slots (pack_wino order): sigma = 4 g + p for the groups, then the direct taps.
   // All four weight fragments (16 k-steps) of slot sigma + 1 are requested while slot sigma computes.
-  const unsigned baddr = (unsigned)(size_t)pl + (unsigned)(hi * PQ + wn * 32 + l31) * 4u;
+  const int uu = wn * 32 + l31;                            // this lane's pair index (>= PU: idle lane of a dilated tile)
+  const unsigned pbase = (unsigned)(size_t)pl;
+  const unsigned baddrV = pbase + (unsigned)(hi * PQV + uu) * 4u;
+  const unsigned baddrE = pbase + (unsigned)(hi * PQE + uu) * 4u;
   const char* const wrow = reinterpret_cast<const char*>(p.wp) + (size_t)mtc * p.nchunks * SLOTS * 4096 + (size_t)lane * 16;
+  // The chunk is a static list of NS = 4 * SLOTS steps; step t = (slot t / 4, k-group t % 4) issues 4 MFMAs (group slot:
+  // plane P at column 2 g D into M[P]) or 8 (direct tap: E and O at column DQ * D into Dd[0], Dd[1]).  Fragment reads run
+  // TWO steps ahead in two register sets: step t waits for its own reads only (lgkmcnt = size of step t + 1's request),
+  // issues its MFMAs, then requests step t + 2 into the set it has just consumed - an LDS round trip is never exposed.
   auto mfma_chunk = [&](int ch) {
+    constexpr int NS = 4 * SLOTS;
     const char* wa = wrow + (size_t)ch * SLOTS * 4096;
-    float4 a0[4], a1[4];
+    float4 a[2][4];
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) a0[kg] = *reinterpret_cast<const float4*>(wa + kg * 1024);
-    // one group slot: 16 MFMAs into M[P]; fragments one k-group ahead
-    auto vslot = [&](auto gc, auto pc, float4(&ac)[4], float4(&an)[4], bool more) {
-      constexpr int GG = decltype(gc)::value, P = decltype(pc)::value;
-      wa += 4096;
-      if (more) {
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) an[kg] = *reinterpret_cast<const float4*>(wa + kg * 1024);
-      }
-      float b0[4], b1[4];
-      wino_frag<PQ, P, 0, 2 * GG>(b0, baddr);
-      wino_frag<PQ, P, 1, 2 * GG>(b1, baddr);
-      wino_wait4(b0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) M[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[0], s), b0[s], M[P], 0, 0, 0);
-      wino_frag<PQ, P, 2, 2 * GG>(b0, baddr);
-      wino_wait4(b1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) M[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[1], s), b1[s], M[P], 0, 0, 0);
-      wino_frag<PQ, P, 3, 2 * GG>(b1, baddr);
-      wino_wait4(b0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) M[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[2], s), b0[s], M[P], 0, 0, 0);
-      wino_wait4(b1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) M[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[3], s), b1[s], M[P], 0, 0, 0);
-    };
-    // one direct tap: the same weights feed E -> D[0] (even outputs) and O -> D[1] (odd outputs); COL = 1 + (tap - PAD) / 2
-    auto dslot = [&](auto colc, float4(&ac)[4], float4(&an)[4], bool more) {
-      constexpr int COL = decltype(colc)::value;
-      wa += 4096;
-      if (more) {
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) an[kg] = *reinterpret_cast<const float4*>(wa + kg * 1024);
-      }
-      float e0[4], o0[4], e1[4], o1[4];
-      wino_frag<PQ, 4, 0, COL>(e0, baddr); wino_frag<PQ, 5, 0, COL>(o0, baddr);
-      wino_frag<PQ, 4, 1, COL>(e1, baddr); wino_frag<PQ, 5, 1, COL>(o1, baddr);
-      wino_wait4(e0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        D[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[0], s), e0[s], D[0], 0, 0, 0);
-        D[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[0], s), o0[s], D[1], 0, 0, 0);
-      }
-      wino_frag<PQ, 4, 2, COL>(e0, baddr); wino_frag<PQ, 5, 2, COL>(o0, baddr);
-      wino_wait4(e1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        D[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[1], s), e1[s], D[0], 0, 0, 0);
-        D[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[1], s), o1[s], D[1], 0, 0, 0);
-      }
-      wino_frag<PQ, 4, 3, COL>(e1, baddr); wino_frag<PQ, 5, 3, COL>(o1, baddr);
-      wino_wait4(e0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        D[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[2], s), e0[s], D[0], 0, 0, 0);
-        D[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[2], s), o0[s], D[1], 0, 0, 0);
-      }
-      wino_wait4(e1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        D[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[3], s), e1[s], D[0], 0, 0, 0);
-        D[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(ac[3], s), o1[s], D[1], 0, 0, 0);
+    for (int kg = 0; kg < 4; ++kg) a[0][kg] = *reinterpret_cast<const float4*>(wa + kg * 1024);
+    float fb[2][4], fo[2][4];
+    auto request = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      if constexpr (T < NS) {
+        constexpr int SG = T / 4, KG = T % 4;
+        if constexpr (SG < 4 * G) {
+          constexpr int GG = SG / 4, P = SG % 4;
+          wino_frag<PQV, P * KC * PQV, KG, 2 * GG * D>(fb[T & 1], baddrV);
+        } else {
+          constexpr int DI = SG - 4 * G;
+          constexpr int DQ = (G == 2) ? 1 : (DI == 0 ? 0 : 2);              // 1 + (tap - PADT) / 2 for taps 3, 7
+          wino_frag<PQE, EBASE, KG, DQ * D>(fb[T & 1], baddrE);
+          wino_frag<PQE, EBASE + KC * PQE, KG, DQ * D>(fo[T & 1], baddrE);
+        }
       }
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    // SLOTS is odd for K = 7 (9) and K = 3 has 4: the ping-pong of (a0, a1) is written out per K
-    vslot(I0{}, I0{}, a0, a1, true); vslot(I0{}, I1{}, a1, a0, true); vslot(I0{}, I2{}, a0, a1, true);
-    if constexpr (G == 1) {
-      vslot(I0{}, I3{}, a1, a0, false);
-    } else {
-      vslot(I0{}, I3{}, a1, a0, true);
-      vslot(I1{}, I0{}, a0, a1, true); vslot(I1{}, I1{}, a1, a0, true); vslot(I1{}, I2{}, a0, a1, true); vslot(I1{}, I3{}, a1, a0, true);
-      if constexpr (G == 2) {
-        dslot(I1{}, a0, a1, false);                                   // tap 3, pad 3: q offset 0 -> column 1
+    auto wait_for = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      constexpr int N = wino_step_reads<K>(T + 1);                          // requests younger than step T's
+      float(&b)[4] = fb[T & 1];
+      if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      if constexpr (wino_step_direct<K>(T)) {
+        float(&o)[4] = fo[T & 1];
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));   // same wait covers the O fragments
+      }
+    };
+    auto step = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      constexpr int SG = T / 4, KG = T % 4;
+      if constexpr (KG == 0 && SG + 1 < SLOTS) {                              // next slot's weights: a whole slot ahead
+        const char* wn_ = wa + (SG + 1) * 4096;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) a[(SG + 1) & 1][kg] = *reinterpret_cast<const float4*>(wn_ + kg * 1024);
+      }
+      wait_for(tc);
+      const float4 av = a[SG & 1][KG];
+      if constexpr (SG < 4 * G) {
+        constexpr int P = SG % 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) M[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[P], 0, 0, 0);
       } else {
-        vslot(I2{}, I0{}, a0, a1, true); vslot(I2{}, I1{}, a1, a0, true); vslot(I2{}, I2{}, a0, a1, true); vslot(I2{}, I3{}, a1, a0, true);
-        dslot(I0{}, a0, a1, true);                                    // tap 3, pad 5: q offset -1 -> column 0
-        dslot(I2{}, a1, a0, false);                                   // tap 7: q offset +1 -> column 2
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          Dd[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], Dd[0], 0, 0, 0);
+          Dd[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fo[T & 1][s], Dd[1], 0, 0, 0);
+        }
       }
-    }
+      __builtin_amdgcn_sched_barrier(0);
+      request(std::integral_constant<int, T + 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    request(std::integral_constant<int, 0>{});
+    request(std::integral_constant<int, 1>{});
+    wino_static_for<0, NS>(step);
   };
 
   issue(0);
@@ -268,34 +306,40 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
     __syncthreads();
     if (row_ok) mfma_chunk(ch);
   }
-  if (!row_ok) return;
+  if (!row_ok || uu >= PU) return;
 
-  // ---- output transform + epilogue: lane owns y[row][2q], y[row][2q+1] for its 16 rows
-  const int col = n0 + 2 * (wn * 32 + l31);
-  if (col >= L) return;
+  // ---- output transform + epilogue: lane owns y[row][ne] and y[row][ne + D] for its 16 rows
+  const int ne = n0 + 2 * (uu / D) * D + (uu % D);
+  if (ne >= L) return;
+  const bool odd_ok = ne + D < L;
   const float* bias = p.bias + mt * 32 + 4 * hi;
-  const long long yrow0 = (long long)bz * p.y_bs + (long long)(mt * 32 + 4 * hi) * p.y_ld + col;
+  const long long yrow0 = (long long)bz * p.y_bs + (long long)(mt * 32 + 4 * hi) * p.y_ld + ne;
   float2 vo[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float bv = bias[(r & 3) + 8 * (r >> 2)];
     float ye = (M[0][r] + M[1][r]) + M[2][r];
     float yo = (M[1][r] - M[2][r]) - M[3][r];
-    if constexpr (ND > 0) { ye += D[0][r]; yo += D[1][r]; }
+    if constexpr (ND > 0) { ye += Dd[0][r]; yo += Dd[1][r]; }
     vo[r] = make_float2(ye + bv, yo + bv);
   }
+  // D == 1 with an even L: the pair is one aligned 8-byte access; otherwise two 4-byte accesses D columns apart
+  auto ld2 = [&](const float* q) -> float2 {
+    if constexpr (D == 1) { if (odd_ok) return *reinterpret_cast<const float2*>(q); return make_float2(q[0], 0.f); }
+    else return make_float2(q[0], odd_ok ? q[D] : 0.f);
+  };
   if (p.flags & F_RES) {
-    const float* rb = p.res + (long long)bz * p.res_bs + (long long)(mt * 32 + 4 * hi) * p.res_ld + col;
+    const float* rb = p.res + (long long)bz * p.res_bs + (long long)(mt * 32 + 4 * hi) * p.res_ld + ne;
     float2 rv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rv[r] = *reinterpret_cast<const float2*>(rb + (long long)((r & 3) + 8 * (r >> 2)) * p.res_ld);
+    for (int r = 0; r < 16; ++r) rv[r] = ld2(rb + (long long)((r & 3) + 8 * (r >> 2)) * p.res_ld);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; }
   }
   if (p.flags & F_ACC) {
     float2 yv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) yv[r] = *reinterpret_cast<const float2*>(p.y + yrow0 + (long long)((r & 3) + 8 * (r >> 2)) * p.y_ld);
+    for (int r = 0; r < 16; ++r) yv[r] = ld2(p.y + yrow0 + (long long)((r & 3) + 8 * (r >> 2)) * p.y_ld);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { vo[r].x = yv[r].x + vo[r].x; vo[r].y = yv[r].y + vo[r].y; }
   }
@@ -305,20 +349,28 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
     for (int r = 0; r < 16; ++r) { vo[r].x = vo[r].x / p.div; vo[r].y = vo[r].y / p.div; }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) *reinterpret_cast<float2*>(p.y + yrow0 + (long long)((r & 3) + 8 * (r >> 2)) * p.y_ld) = vo[r];
+  for (int r = 0; r < 16; ++r) {
+    float* q = p.y + yrow0 + (long long)((r & 3) + 8 * (r >> 2)) * p.y_ld;
+    if constexpr (D == 1) {
+      if (odd_ok) *reinterpret_cast<float2*>(q) = vo[r]; else q[0] = vo[r].x;
+    } else {
+      q[0] = vo[r].x;
+      if (odd_ok) q[D] = vo[r].y;
+    }
+  }
 }
 
-template <int K>
+template <int K, int D>
 __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs p) {
   const int lin = blockIdx.x;
-  const int total = gridDim.x;
-  const int tl = xcd_linear(lin, total, p.xcd);
+  const int tl = xcd_linear(lin, gridDim.x, p.xcd);
   const int t = tl / p.ntn;
   const int bz = t / p.gy;
-  wino_tile<K>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  wino_tile<K, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
 }
 
-// up to three problems (the MRF chains' convolutions of one step, k = 11 / 7 / 3) in one launch, longest first
+// up to three problems of one dilation (the MRF chains' convolutions of one step, k = 11 / 7 / 3) in one launch, longest first
+template <int D>
 __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup g) {
   const int lin = blockIdx.x;
   int pi = 0;
@@ -330,9 +382,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup
   const int t = tl / p.ntn;
   const int bz = t / p.gy;
   const int k = g.k[pi];
-  if (k == 11) wino_tile<11>(p, tl - t * p.ntn, t - bz * p.gy, bz);
-  else if (k == 7) wino_tile<7>(p, tl - t * p.ntn, t - bz * p.gy, bz);
-  else wino_tile<3>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  if (k == 11) wino_tile<11, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  else if (k == 7) wino_tile<7, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  else wino_tile<3, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
 }
 
 // ------------------------------------------------------------------ weight transform + packing
@@ -387,7 +439,7 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
-  return on && dil == 1 && (K == 3 || K == 7 || K == 11) && Cin >= 64 && (Cin % KC) == 0 && (Cout % 32) == 0;
+  return on && (dil == 1 || dil == 3 || dil == 5) && (K == 3 || K == 7 || K == 11) && Cin >= 64 && (Cin % KC) == 0 && (Cout % 32) == 0;
 }
 
 int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, const float* g, const float* bias, hipStream_t st) {
@@ -427,11 +479,12 @@ int pack_wino_named(PackedWino& pw, int Cin, int Cout, int K, const TensorTable&
 }
 
 // ------------------------------------------------------------------ launches
-static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, WinoArgs& w) {
-  // the decoder's plain epilogue only: out[0], flags within RES | ACC | DIV, full rows, 8-byte aligned even-length rows
+static int wino_tile_w(int D) { return 2 * ((64 / D) * D); }
+static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, int D, WinoArgs& w) {
+  // the decoder's plain epilogue only: out[0], flags within RES | ACC | DIV, full rows, 8-byte aligned rows
   const EpiOut& o = a.out[0];
   if (a.mode != EPI_PLAIN || a.in_mask || a.mask || a.gadd || (o.flags & ~(unsigned)(F_RES | F_ACC | F_DIV)) || a.split_row < pw.mtiles * 32) return false;
-  if (o.nrows < pw.Cout || a.Ncols != a.Lin || (a.Ncols & 1)) return false;
+  if (!(D == 1 || D == 3 || D == 5) || o.nrows < pw.Cout || a.Ncols != a.Lin || a.Ncols < 4) return false;
   if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.x_ld & 3) || (a.x_bs & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(o.y) & 7) || (o.y_ld & 1) || (o.y_bs & 1)) return false;
   if ((o.flags & F_RES) && ((reinterpret_cast<uintptr_t>(o.res) & 7) || (o.res_ld & 1) || (o.res_bs & 1))) return false;
@@ -440,16 +493,30 @@ static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, WinoArgs& 
   w.y = o.y; w.y_bs = o.y_bs; w.y_ld = o.y_ld;
   w.res = o.res; w.res_bs = o.res_bs; w.res_ld = o.res_ld;
   w.flags = o.flags; w.div = o.div;
-  w.ntn = (a.Ncols + 127) / 128; w.gy = (pw.mtiles + 1) / 2; w.xcd = xcd_mapping_enabled();
+  const int W = wino_tile_w(D);
+  w.ntn = (a.Ncols + W - 1) / W; w.gy = (pw.mtiles + 1) / 2; w.xcd = xcd_mapping_enabled();
   (void)B;
   return true;
 }
-template <int K> static size_t wino_lds() { return (size_t)WinoGeo<K>::LDS_BYTES; }
+template <int K, int D>
+static int wino_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
+  using Geo = WinoGeo<K, D>;
+  static_assert(Geo::LDS_BYTES <= 160 * 1024, "tile does not fit");
+  auto kern = conv_wino_kernel<K, D>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const size_t lds = (size_t)Geo::LDS_BYTES;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, w);
+  return SVOC_OK;
+}
+template <int D>
+static size_t wino_lds(int K) {
+  return K == 11 ? (size_t)WinoGeo<11, D>::LDS_BYTES : (K == 7 ? (size_t)WinoGeo<7, D>::LDS_BYTES : (size_t)WinoGeo<3, D>::LDS_BYTES);
+}
 
 // 1 = not eligible (caller uses the direct kernel)
-int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, hipStream_t st, long long min_tiles) {
+int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles) {
   WinoArgs w;
-  if (B <= 0 || !wino_args(pw, a, B, w)) return 1;
+  if (B <= 0 || !wino_args(pw, a, B, dil, w)) return 1;
   const long long total = (long long)w.ntn * w.gy * B;
   if (min_tiles < 0) min_tiles = 2LL * device_cu_count();
   if (total < min_tiles || total > 0x7fffffffLL) return 1;    // short inputs: the direct / K-split kernels
@@ -458,31 +525,33 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, hipStream_t
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "wino  Ci%-4d Co%-4d k%-2d d1  N%-7d B%-3d", pw.Cin, pw.Cout, pw.K, a.Ncols, B);
+    snprintf(d, sizeof(d), "wino  Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d", pw.Cin, pw.Cout, pw.K, dil, a.Ncols, B);
     prof_idx = prof_begin(st, d, flops);
   }
-  if (pw.K == 11) { auto k = conv_wino_kernel<11>; SVOC_TRY(ensure_max_dyn_lds((const void*)k)); hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(256), wino_lds<11>(), st, w); }
-  else if (pw.K == 7) { auto k = conv_wino_kernel<7>; SVOC_TRY(ensure_max_dyn_lds((const void*)k)); hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(256), wino_lds<7>(), st, w); }
-  else { auto k = conv_wino_kernel<3>; SVOC_TRY(ensure_max_dyn_lds((const void*)k)); hipLaunchKernelGGL(k, dim3((unsigned)total), dim3(256), wino_lds<3>(), st, w); }
+  int rc = SVOC_OK;
+#define SVOC_W(KK, DD) if (pw.K == KK && dil == DD) rc = wino_launch_one<KK, DD>(w, total, st);
+  SVOC_W(3, 1) SVOC_W(7, 1) SVOC_W(11, 1) SVOC_W(3, 3) SVOC_W(7, 3) SVOC_W(11, 3) SVOC_W(3, 5) SVOC_W(7, 5) SVOC_W(11, 5)
+#undef SVOC_W
   prof_end(st, prof_idx);
+  if (rc != SVOC_OK) return rc;
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;
 }
 
-int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, hipStream_t st) {
+int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st) {
   if (n < 2 || n > 3 || B <= 0) return 1;
   WinoGroup g{};
   long long total = 0;
   double flops = 0;
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
-    if (!wino_args(*pws[i], as[i], B, g.a[i])) return 1;
+    if (!wino_args(*pws[i], as[i], B, dil, g.a[i])) return 1;
     total += (long long)g.a[i].ntn * g.a[i].gy * B;
     if (total > 0x7fffffffLL) return 1;
     g.end[i] = (int)total;
     g.k[i] = pws[i]->K;
     flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
-    lds = std::max(lds, pws[i]->K == 11 ? wino_lds<11>() : (pws[i]->K == 7 ? wino_lds<7>() : wino_lds<3>()));
+    lds = std::max(lds, dil == 1 ? wino_lds<1>(pws[i]->K) : (dil == 3 ? wino_lds<3>(pws[i]->K) : wino_lds<5>(pws[i]->K)));
   }
   if (total < 2LL * device_cu_count()) return 1;
   for (int i = n; i < 3; ++i) { g.end[i] = 0x7fffffff; g.k[i] = 3; }
@@ -490,12 +559,14 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "winoG Ci%-4d Co%-4d k%d/%d/%d N%-7d B%-3d", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, as[0].Ncols, B);
+    snprintf(d, sizeof(d), "winoG Ci%-4d Co%-4d k%d/%d/%d d%d N%-7d B%-3d", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, dil, as[0].Ncols, B);
     prof_idx = prof_begin(st, d, flops);
   }
-  auto kern = conv_wino_group_kernel;
-  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, g);
+  const void* kern = dil == 1 ? (const void*)conv_wino_group_kernel<1> : (dil == 3 ? (const void*)conv_wino_group_kernel<3> : (const void*)conv_wino_group_kernel<5>);
+  SVOC_TRY(ensure_max_dyn_lds(kern));
+  if (dil == 1) hipLaunchKernelGGL(conv_wino_group_kernel<1>, dim3((unsigned)total), dim3(256), lds, st, g);
+  else if (dil == 3) hipLaunchKernelGGL(conv_wino_group_kernel<3>, dim3((unsigned)total), dim3(256), lds, st, g);
+  else hipLaunchKernelGGL(conv_wino_group_kernel<5>, dim3((unsigned)total), dim3(256), lds, st, g);
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;

@@ -154,7 +154,7 @@ int ensure_max_dyn_lds(const void* kernel);  // hipFuncSetAttribute(MaxDynamicSh
 struct ConvGroup { ConvArgs a[3]; int end[3]; };     // conv_group_kernel: end[i] = first workgroup id after problem i
 int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, int B, hipStream_t st);   // 1 = not eligible
 
-// conv_wino.hip: Winograd F(2,3) form of the big undilated convolutions (k = 3 / 7 / 11, C >= 64): 1/3 fewer MFMAs
+// conv_wino.hip: Winograd F(2,3) form of the big convolutions (k = 3 / 7 / 11, dilation 1 / 3 / 5, C >= 64): 1/3 fewer MFMAs
 struct PackedWino {
   DevBuf wp, bias;
   int Cin = 0, Cout = 0, K = 0, nchunks = 0, mtiles = 0, slots = 0;
@@ -165,8 +165,8 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
 int pack_wino_named(PackedWino& pw, int Cin, int Cout, int K, const TensorTable& tab, const std::string& prefix, hipStream_t st);
 // `a`: x / pre_slope / Ncols / out[0] as for launch_conv (plain epilogue, flags within F_RES | F_ACC | F_DIV); 1 = not
 // eligible (alignment, odd length, masks, or fewer than min_tiles workgroups; min_tiles < 0: twice the CU count)
-int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, hipStream_t st, long long min_tiles = -1);
-int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, hipStream_t st);
+int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles = -1);
+int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st);
 
 // resblock_fused.hip: one ResBlock1 iteration (c1 -> lrelu -> c2 -> + x) in one kernel; returns 1 when not eligible
 void set_debug_stamp_buffer(long long* p);

@@ -89,30 +89,33 @@ def test_conv1d(M, C, k, d, L, B, res):
     check(f"conv1d C{C} k{k} d{d}", y, ref)
 
 
-@pytest.mark.parametrize("C,co,k,L,B,res", [(128, 128, 3, 4096, 2, True), (128, 128, 7, 1000, 3, True), (128, 128, 11, 4100, 1, False),
-                                             (256, 256, 11, 516, 2, True), (64, 96, 7, 260, 2, False), (256, 256, 3, 128, 1, True),
-                                             (128, 128, 11, 12, 1, True)])
-def test_conv1d_winograd(M, C, co, k, L, B, res):
-    """lrelu -> Conv1d(k, d=1) [+ residual] in Winograd F(2,3) form (conv_wino.hip: three-tap groups at tap offsets 0/4/8 on
-    shared transformed planes + direct taps 3/7 on de-interleaved planes) against torch's direct convolution: every kernel
-    size, ragged last tiles (L not a multiple of 128), tiles shorter than the halo, odd row-block counts (Cout = 96)."""
+@pytest.mark.parametrize("C,co,k,d,L,B,res", [(128, 128, 3, 1, 4096, 2, True), (128, 128, 7, 1, 1000, 3, True), (128, 128, 11, 1, 4100, 1, False),
+                                               (256, 256, 11, 1, 516, 2, True), (64, 96, 7, 1, 260, 2, False), (256, 256, 3, 1, 128, 1, True),
+                                               (128, 128, 11, 1, 12, 1, True), (128, 128, 3, 3, 1000, 2, True), (128, 128, 7, 3, 4096, 1, True),
+                                               (128, 128, 11, 3, 756, 2, True), (256, 256, 3, 5, 1204, 1, False), (128, 128, 7, 5, 4100, 2, True),
+                                               (128, 128, 11, 5, 2400, 2, True), (64, 96, 11, 5, 40, 1, False), (128, 128, 11, 3, 8, 1, True)])
+def test_conv1d_winograd(M, C, co, k, d, L, B, res):
+    """lrelu -> Conv1d(k, dilation d) [+ residual] in Winograd F(2,3) form (conv_wino.hip: three-tap groups at tap offsets
+    0/4/8 on shared transformed planes + direct taps 3/7 on de-interleaved planes; dilation through the polyphase pairing
+    (n, n + d)) against torch's direct convolution: every (k, d) of the model, ragged last tiles (L not a multiple of the
+    128/126/120-column tiles), inputs shorter than the halo, odd row-block counts (Cout = 96)."""
     import ctypes
-    seed = 300 + C + 7 * k + L
+    seed = 300 + C + 7 * k + L + 1000 * d
     v = T(cases.rnd(seed, "v", (co, C, k), 1.0 / np.sqrt(C * k)))
     g = T((0.5 + sw.uniform01(seed, "g", co)).astype(np.float32)).reshape(co, 1, 1)
     bias = T(cases.rnd(seed, "b", (co,), 0.1))
     x = T(cases.rnd(seed, "x", (B, C, L), 1.0))
     w = O.fold_weight_norm(v, g)
-    ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x, 0.1), w, bias, padding=(k - 1) // 2)
+    ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x, 0.1), w, bias, dilation=d, padding=(k - 1) * d // 2)
     if res:
         ref = ref + x
     N = M.native
     xc, vc, gc, bc = x.cuda(), v.cuda(), g.cuda(), bias.cuda()
     y = torch.full((B, co, L), float("nan"), device="cuda")
     N.check(N.lib().svoc_conv1d_winograd(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), N.ptr(xc) if res else None,
-                                         N.ptr(y), B, C, co, L, k, ctypes.c_float(0.1)))
-    check(f"winograd C{C} k{k} L{L}", y, ref)
-    rc = N.lib().svoc_conv1d_winograd(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), None, N.ptr(y), B, C, co, L, 5, ctypes.c_float(0.1))
+                                         N.ptr(y), B, C, co, L, k, d, ctypes.c_float(0.1)))
+    check(f"winograd C{C} k{k} d{d} L{L}", y, ref)
+    rc = N.lib().svoc_conv1d_winograd(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), None, N.ptr(y), B, C, co, L, 5, 1, ctypes.c_float(0.1))
     assert rc == -5
 
 
