@@ -46,13 +46,16 @@ struct WinoGroup { WinoArgs a[3]; int end[3]; int k[3]; };
 // holds PU = 64 - 64 % D pairs u = qq * D + phase (outputs n0 + 2 qq D + phase and that + D: contiguous blocks of 2 D
 // columns, tile width 2 PU = 128 / 126 / 120); group g then reads the V planes at column u + 2 g D and a direct tap
 // with q offset delta reads E / O at u + (delta + 1) D - everything else is unchanged.
-template <int K, int D>
+// WM = row tiles per workgroup (waves along the rows): 4 x 1 (128 rows x 32 pairs) where the convolution has at least
+// four row tiles - the staged / transformed input is then shared by twice as many MFMAs - else 2 x 2 (64 rows x 64 pairs).
+template <int K, int D, int WM>
 struct WinoGeo {
   static constexpr int G = (K + 1) / 4;                   // three-tap groups at tap offsets 0, 4, 8
   static constexpr int ND = G - 1;                        // left-over single taps (3, 7)
   static constexpr int PADT = (K - 1) / 2;                // padding in taps (columns: PADT * D)
   static constexpr int SLOTS = 4 * G + ND;                // weight slots per 32-channel chunk (a direct tap feeds E and O)
-  static constexpr int PU = (64 / D) * D;                 // output pairs per tile
+  static constexpr int WN = 4 / WM;                       // waves along the pairs
+  static constexpr int PU = ((32 * WN) / D) * D;          // output pairs per tile
   static constexpr int W = 2 * PU;                        // output columns per tile
   static constexpr int NUV = PU + 2 * (G - 1) * D;        // entries of a V plane row
   static constexpr int NUE = PU + 2 * D;                  // entries of an E / O plane row (origin one q block before the tile)
@@ -103,9 +106,9 @@ template <int K> constexpr int wino_step_reads(int t) {
   return t >= 4 * (4 * ((K + 1) / 4) + (K + 1) / 4 - 1) ? 0 : (wino_step_direct<K>(t) ? 8 : 4);
 }
 
-template <int K, int D>
+template <int K, int D, int WM>
 __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const int by, const int bz) {
-  using Geo = WinoGeo<K, D>;
+  using Geo = WinoGeo<K, D, WM>;
   constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQV = Geo::PQV, PQE = Geo::PQE, RAW = Geo::RAW, SLOTS = Geo::SLOTS;
   constexpr int PU = Geo::PU, XOFF = Geo::XOFF;
   extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -116,10 +119,10 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WM == 4 ? wave : wave >> 1, wn = WM == 4 ? 0 : wave & 1;
   const int l31 = lane & 31, hi = lane >> 5;
   const int n0 = bx * Geo::W;                              // first output column of the workgroup
-  const int mt = by * 2 + wm;                              // this wave's 32-row tile
+  const int mt = by * WM + wm;                             // this wave's 32-row tile
   const bool row_ok = mt < p.mtiles;
   const int mtc = row_ok ? mt : p.mtiles - 1;
   const int L = p.L;
@@ -128,95 +131,107 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
 #pragma unroll
   for (int i = 0; i < 16; ++i) { M[0][i] = 0.f; M[1][i] = 0.f; M[2][i] = 0.f; M[3][i] = 0.f; Dd[0][i] = 0.f; Dd[1][i] = 0.f; }
 
-  // ---- raw staging: 32 channels x RAW columns
-  constexpr int R4 = RAW / 4, SU = (KC * R4 + 255) / 256;
-  const float* xb = p.x + (long long)bz * p.x_bs;
+  // ---- raw staging: 32 channels x RAW columns.  Thread (r0, g4) of the first RPP * R4 threads owns float4 group g4 of rows
+  // r0, r0 + RPP, ...: one per-thread offset + a wave-uniform base per pass on the global side, one per-thread LDS address +
+  // an immediate per pass on the LDS side - no per-slot index arithmetic (every vector instruction of these phases takes
+  // matrix-pipe time from the other workgroup's MFMA phase).
+  constexpr int R4 = RAW / 4, RPP = 256 / R4, NPASS = (KC + RPP - 1) / RPP;
+  const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
+  const long long ldb = (long long)p.x_ld * 4;
   const int xs_start = n0 + XOFF;
   const float slope = p.pre_slope;
-  float4 v[SU];
+  const int r0 = tid / R4, g4 = tid - r0 * R4;
+  const bool mine = tid < RPP * R4;
+  const int tg = xs_start + 4 * g4;                        // first column of this thread's groups
+  const bool inside = tg >= 0 && tg + 3 < L;               // else: a group that straddles an end of the sequence
+  const unsigned goff = (unsigned)((mine ? r0 : 0) * p.x_ld + (inside ? tg : 0)) * 4u;
+  float4 v[NPASS];
   auto issue = [&](int ch) {
+    const char* cb = xb + (long long)ch * KC * ldb;
 #pragma unroll
-    for (int u = 0; u < SU; ++u) {
-      const int idx = tid + u * 256;
-      const int c = min(idx / R4, KC - 1), g4 = idx - (idx / R4) * R4;
-      const int gc = min(ch * KC + c, p.Cin - 1);
-      int t = xs_start + 4 * g4;
-      t = (t >= 0 && t + 3 < L) ? t : 0;                   // clamped address; edges are fixed up in publish()
-      v[u] = *reinterpret_cast<const float4*>(xb + (long long)gc * p.x_ld + t);
+    for (int u = 0; u < NPASS; ++u) {
+      if (u * RPP + RPP - 1 < KC) {                        // compile time: every row of this pass exists
+        v[u] = *reinterpret_cast<const float4*>(cb + (long long)(u * RPP) * ldb + goff);
+      } else {                                             // last, partial pass: rows beyond the chunk re-read its last row (not written)
+        const int c = min((mine ? r0 : 0) + u * RPP, KC - 1);
+        v[u] = *reinterpret_cast<const float4*>(cb + (long long)c * ldb + (long long)(inside ? tg : 0) * 4);
+      }
     }
   };
+  float* const rdst = raw + r0 * RAW + 4 * g4;
   auto publish = [&](int ch) {
 #pragma unroll
-    for (int u = 0; u < SU; ++u) {
-      const int idx = tid + u * 256;
-      if (idx < KC * R4) {
-        const int c = idx / R4, g4 = idx - c * R4;
-        const int t = xs_start + 4 * g4;
+    for (int u = 0; u < NPASS; ++u) {
+      if (mine && (u * RPP + RPP - 1 < KC || r0 + u * RPP < KC)) {
         float4 q = v[u];
-        if (!(t >= 0 && t + 3 < L)) {                      // a group that straddles an end (rare): element-wise
-          const float* row = xb + (long long)min(ch * KC + c, p.Cin - 1) * p.x_ld;
-          q.x = (t >= 0 && t < L) ? row[t] : 0.f;
-          q.y = (t + 1 >= 0 && t + 1 < L) ? row[t + 1] : 0.f;
-          q.z = (t + 2 >= 0 && t + 2 < L) ? row[t + 2] : 0.f;
-          q.w = (t + 3 >= 0 && t + 3 < L) ? row[t + 3] : 0.f;
+        if (!inside) {                                     // rare: element-wise with zero padding
+          const float* row = reinterpret_cast<const float*>(xb + (long long)(ch * KC + r0 + u * RPP) * ldb);
+          q.x = (tg >= 0 && tg < L) ? row[tg] : 0.f;
+          q.y = (tg + 1 >= 0 && tg + 1 < L) ? row[tg + 1] : 0.f;
+          q.z = (tg + 2 >= 0 && tg + 2 < L) ? row[tg + 2] : 0.f;
+          q.w = (tg + 3 >= 0 && tg + 3 < L) ? row[tg + 3] : 0.f;
         }
-        if (ch * KC + c >= p.Cin) q = make_float4(0.f, 0.f, 0.f, 0.f);
         q.x = fmaxf(q.x, q.x * slope); q.y = fmaxf(q.y, q.y * slope);
         q.z = fmaxf(q.z, q.z * slope); q.w = fmaxf(q.w, q.w * slope);
-        *reinterpret_cast<float4*>(raw + c * RAW + 4 * g4) = q;
+        *reinterpret_cast<float4*>(rdst + u * RPP * RAW) = q;
       }
     }
   };
   // ---- transform pass: raw -> V0..V3 and E / O.  V entry u' = q' D + phase: window d_j = raw[(2 q' - PADT + j) D + phase - XOFF];
-  // E / O entry e = (q + 1) D + phase: raw[2 q D + phase - XOFF], raw[(2 q + 1) D + phase - XOFF].
+  // E / O entry e = (q + 1) D + phase: raw[2 q D + phase - XOFF], raw[(2 q + 1) D + phase - XOFF].  Same regular mapping:
+  // an item (two q' of one phase: they share two window samples) per thread and pass, rows TPP apart.
+  constexpr int NQ = Geo::NUV / D, NQ2 = (NQ + 1) / 2, IPR = NQ2 * D;   // q' per phase, pairs of q', items per row
+  constexpr int TPP = 256 / IPR, TPASS = (KC + TPP - 1) / TPP;
+  const int tr0 = tid / IPR, trem = tid - tr0 * IPR;
+  const int tq2 = trem / D, tph = trem - tq2 * D;
+  const bool tmine = tid < TPP * IPR;
+  const bool tsecond = 2 * tq2 + 1 < NQ;                   // the item's second q' exists (NQ may be odd)
+  const float* const tsrc = raw + tr0 * RAW + (4 * tq2 - PADT) * D + tph - XOFF;
+  float* const tdst = pl + tr0 * PQV + 2 * tq2 * D + tph;
+  constexpr int NQE = Geo::NUE / D, EIPR = ((NQE + 1) / 2) * D;         // E / O: pairs of q per phase
+  constexpr int EPP = 256 / EIPR, EPASS = (KC + EPP - 1) / EPP;
+  const int er0 = tid / EIPR, erem = tid - er0 * EIPR;
+  const int eq2 = erem / D, eph = erem - eq2 * D;
+  const bool emine = tid < EPP * EIPR;
+  const bool esecond = 2 * eq2 + 1 < NQE;
+  const float* const esrc = raw + er0 * RAW + (4 * eq2 - 2) * D + eph - XOFF;
+  float* const edst = pl + EBASE + er0 * PQE + 2 * eq2 * D + eph;
   auto transform = [&]() {
-    if constexpr (D == 1) {
-      constexpr int NV2 = Geo::NUV / 2;                    // pairs of q' per channel (NUV is even)
-      for (int it = tid; it < KC * NV2; it += 256) {
-        const int c = it / NV2, i = 2 * (it - c * NV2);
-        const float* r = raw + c * RAW + 2 * i - PADT - XOFF;
-        const float d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4], d5 = r[5];
-        float* o = pl + c * PQV + i;
-        *reinterpret_cast<float2*>(o) = make_float2(d0 - d2, d2 - d4);
-        *reinterpret_cast<float2*>(o + KC * PQV) = make_float2(d1 + d2, d3 + d4);
-        *reinterpret_cast<float2*>(o + 2 * KC * PQV) = make_float2(d2 - d1, d4 - d3);
-        *reinterpret_cast<float2*>(o + 3 * KC * PQV) = make_float2(d1 - d3, d3 - d5);
-      }
-      if constexpr (ND > 0) {
-        constexpr int NE2 = Geo::NUE / 2;
-        for (int it = tid; it < KC * NE2; it += 256) {
-          const int c = it / NE2, i = 2 * (it - c * NE2);
-          const float* r = raw + c * RAW + 2 * (i - 1) - XOFF;
-          const float2 a = *reinterpret_cast<const float2*>(r), b = *reinterpret_cast<const float2*>(r + 2);
-          float* o = pl + EBASE + c * PQE + i;
-          *reinterpret_cast<float2*>(o) = make_float2(a.x, b.x);
-          *reinterpret_cast<float2*>(o + KC * PQE) = make_float2(a.y, b.y);
-        }
-      }
-    } else {
-      // two q' of one phase per item (they share two of their window samples)
-      constexpr int NQ = Geo::NUV / D, NQ2 = (NQ + 1) / 2;
-      for (int it = tid; it < KC * NQ2 * D; it += 256) {
-        const int c = it / (NQ2 * D), rem = it - c * (NQ2 * D);
-        const int q2 = rem / D, ph = rem - q2 * D;
-        const int qp = 2 * q2;
-        const float* r = raw + c * RAW + (2 * qp - PADT) * D + ph - XOFF;
+#pragma unroll
+    for (int u = 0; u < TPASS; ++u) {
+      if (tmine && (u * TPP + TPP - 1 < KC || tr0 + u * TPP < KC)) {
+        const float* r = tsrc + u * TPP * RAW;
+        float* o = tdst + u * TPP * PQV;
         const float d0 = r[0], d1 = r[D], d2 = r[2 * D], d3 = r[3 * D];
-        float* o = pl + c * PQV + qp * D + ph;
-        o[0] = d0 - d2; o[KC * PQV] = d1 + d2; o[2 * KC * PQV] = d2 - d1; o[3 * KC * PQV] = d1 - d3;
-        if (qp + 1 < NQ) {
-          const float d4 = r[4 * D], d5 = r[5 * D];
-          o[D] = d2 - d4; o[KC * PQV + D] = d3 + d4; o[2 * KC * PQV + D] = d4 - d3; o[3 * KC * PQV + D] = d3 - d5;
+        if constexpr (D == 1) {                            // the two q' are neighbours in the plane: 8-byte stores
+          const float d4 = r[4], d5 = r[5];                // (NUV is even for D = 1)
+          *reinterpret_cast<float2*>(o) = make_float2(d0 - d2, d2 - d4);
+          *reinterpret_cast<float2*>(o + KC * PQV) = make_float2(d1 + d2, d3 + d4);
+          *reinterpret_cast<float2*>(o + 2 * KC * PQV) = make_float2(d2 - d1, d4 - d3);
+          *reinterpret_cast<float2*>(o + 3 * KC * PQV) = make_float2(d1 - d3, d3 - d5);
+        } else {
+          o[0] = d0 - d2; o[KC * PQV] = d1 + d2; o[2 * KC * PQV] = d2 - d1; o[3 * KC * PQV] = d1 - d3;
+          if (tsecond) {
+            const float d4 = r[4 * D], d5 = r[5 * D];
+            o[D] = d2 - d4; o[KC * PQV + D] = d3 + d4; o[2 * KC * PQV + D] = d4 - d3; o[3 * KC * PQV + D] = d3 - d5;
+          }
         }
       }
-      if constexpr (ND > 0) {
-        constexpr int NQE = Geo::NUE / D;
-        for (int it = tid; it < KC * NQE * D; it += 256) {
-          const int c = it / (NQE * D), rem = it - c * (NQE * D);
-          const int qe = rem / D, ph = rem - qe * D;       // q = qe - 1
-          const float* r = raw + c * RAW + 2 * (qe - 1) * D + ph - XOFF;
-          float* o = pl + EBASE + c * PQE + qe * D + ph;
-          o[0] = r[0]; o[KC * PQE] = r[D];
+    }
+    if constexpr (ND > 0) {
+#pragma unroll
+      for (int u = 0; u < EPASS; ++u) {
+        if (emine && (u * EPP + EPP - 1 < KC || er0 + u * EPP < KC)) {
+          const float* r = esrc + u * EPP * RAW;           // q = 2 eq2 - 1: E = r[0], O = r[D]; q + 1: r[2 D], r[3 D]
+          float* o = edst + u * EPP * PQE;
+          if constexpr (D == 1) {
+            const float2 a = *reinterpret_cast<const float2*>(r), b = *reinterpret_cast<const float2*>(r + 2);
+            *reinterpret_cast<float2*>(o) = make_float2(a.x, b.x);
+            *reinterpret_cast<float2*>(o + KC * PQE) = make_float2(a.y, b.y);
+          } else {
+            o[0] = r[0]; o[KC * PQE] = r[D];
+            if (esecond) { o[D] = r[2 * D]; o[KC * PQE + D] = r[3 * D]; }
+          }
         }
       }
     }
@@ -360,17 +375,17 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
   }
 }
 
-template <int K, int D>
+template <int K, int D, int WM>
 __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs p) {
   const int lin = blockIdx.x;
   const int tl = xcd_linear(lin, gridDim.x, p.xcd);
   const int t = tl / p.ntn;
   const int bz = t / p.gy;
-  wino_tile<K, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  wino_tile<K, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
 }
 
 // up to three problems of one dilation (the MRF chains' convolutions of one step, k = 11 / 7 / 3) in one launch, longest first
-template <int D>
+template <int D, int WM>
 __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup g) {
   const int lin = blockIdx.x;
   int pi = 0;
@@ -382,9 +397,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup
   const int t = tl / p.ntn;
   const int bz = t / p.gy;
   const int k = g.k[pi];
-  if (k == 11) wino_tile<11, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
-  else if (k == 7) wino_tile<7, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
-  else wino_tile<3, D>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  if (k == 11) wino_tile<11, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  else if (k == 7) wino_tile<7, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  else wino_tile<3, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
 }
 
 // ------------------------------------------------------------------ weight transform + packing
@@ -479,13 +494,19 @@ int pack_wino_named(PackedWino& pw, int Cin, int Cout, int K, const TensorTable&
 }
 
 // ------------------------------------------------------------------ launches
-static int wino_tile_w(int D) { return 2 * ((64 / D) * D); }
-static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, int D, WinoArgs& w) {
+static int wino_wm(const PackedWino& pw) {
+  static const int force = getenv("SVOC_WINO_WM") ? atoi(getenv("SVOC_WINO_WM")) : 0;
+  if (force == 2 || force == 4) return force;
+  return pw.mtiles >= 4 && pw.mtiles % 4 == 0 ? 4 : 2;
+}
+static int wino_tile_w(int D, int WM) { return 2 * (((32 * (4 / WM)) / D) * D); }
+static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, int D, int WM, WinoArgs& w) {
   // the decoder's plain epilogue only: out[0], flags within RES | ACC | DIV, full rows, 8-byte aligned rows
   const EpiOut& o = a.out[0];
   if (a.mode != EPI_PLAIN || a.in_mask || a.mask || a.gadd || (o.flags & ~(unsigned)(F_RES | F_ACC | F_DIV)) || a.split_row < pw.mtiles * 32) return false;
   if (!(D == 1 || D == 3 || D == 5) || o.nrows < pw.Cout || a.Ncols != a.Lin || a.Ncols < 4) return false;
   if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.x_ld & 3) || (a.x_bs & 3)) return false;
+  if ((long long)KC * a.x_ld * 4 >= (1LL << 31)) return false;                   // 32-bit per-thread offsets within a chunk
   if ((reinterpret_cast<uintptr_t>(o.y) & 7) || (o.y_ld & 1) || (o.y_bs & 1)) return false;
   if ((o.flags & F_RES) && ((reinterpret_cast<uintptr_t>(o.res) & 7) || (o.res_ld & 1) || (o.res_bs & 1))) return false;
   w.x = a.x; w.x_bs = a.x_bs; w.x_ld = a.x_ld; w.Cin = pw.Cin; w.L = a.Lin; w.pre_slope = a.pre_slope;
@@ -493,30 +514,38 @@ static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, int D, Win
   w.y = o.y; w.y_bs = o.y_bs; w.y_ld = o.y_ld;
   w.res = o.res; w.res_bs = o.res_bs; w.res_ld = o.res_ld;
   w.flags = o.flags; w.div = o.div;
-  const int W = wino_tile_w(D);
-  w.ntn = (a.Ncols + W - 1) / W; w.gy = (pw.mtiles + 1) / 2; w.xcd = xcd_mapping_enabled();
+  const int W = wino_tile_w(D, WM);
+  w.ntn = (a.Ncols + W - 1) / W; w.gy = (pw.mtiles + WM - 1) / WM; w.xcd = xcd_mapping_enabled();
   (void)B;
   return true;
 }
-template <int K, int D>
+template <int K, int D, int WM>
 static int wino_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
-  using Geo = WinoGeo<K, D>;
+  using Geo = WinoGeo<K, D, WM>;
   static_assert(Geo::LDS_BYTES <= 160 * 1024, "tile does not fit");
-  auto kern = conv_wino_kernel<K, D>;
+  auto kern = conv_wino_kernel<K, D, WM>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const size_t lds = (size_t)Geo::LDS_BYTES;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, w);
   return SVOC_OK;
 }
-template <int D>
+template <int D, int WM>
 static size_t wino_lds(int K) {
-  return K == 11 ? (size_t)WinoGeo<11, D>::LDS_BYTES : (K == 7 ? (size_t)WinoGeo<7, D>::LDS_BYTES : (size_t)WinoGeo<3, D>::LDS_BYTES);
+  return K == 11 ? (size_t)WinoGeo<11, D, WM>::LDS_BYTES : (K == 7 ? (size_t)WinoGeo<7, D, WM>::LDS_BYTES : (size_t)WinoGeo<3, D, WM>::LDS_BYTES);
+}
+template <int D, int WM>
+static int wino_launch_group(const WinoGroup& g, long long total, size_t lds, hipStream_t st) {
+  auto kern = conv_wino_group_kernel<D, WM>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, g);
+  return SVOC_OK;
 }
 
 // 1 = not eligible (caller uses the direct kernel)
 int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles) {
   WinoArgs w;
-  if (B <= 0 || !wino_args(pw, a, B, dil, w)) return 1;
+  const int WM = wino_wm(pw);
+  if (B <= 0 || !wino_args(pw, a, B, dil, WM, w)) return 1;
   const long long total = (long long)w.ntn * w.gy * B;
   if (min_tiles < 0) min_tiles = 2LL * device_cu_count();
   if (total < min_tiles || total > 0x7fffffffLL) return 1;    // short inputs: the direct / K-split kernels
@@ -525,11 +554,11 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "wino  Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d", pw.Cin, pw.Cout, pw.K, dil, a.Ncols, B);
+    snprintf(d, sizeof(d), "wino  Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%d", pw.Cin, pw.Cout, pw.K, dil, a.Ncols, B, WM, 4 / WM);
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
-#define SVOC_W(KK, DD) if (pw.K == KK && dil == DD) rc = wino_launch_one<KK, DD>(w, total, st);
+#define SVOC_W(KK, DD) if (pw.K == KK && dil == DD) rc = WM == 4 ? wino_launch_one<KK, DD, 4>(w, total, st) : wino_launch_one<KK, DD, 2>(w, total, st);
   SVOC_W(3, 1) SVOC_W(7, 1) SVOC_W(11, 1) SVOC_W(3, 3) SVOC_W(7, 3) SVOC_W(11, 3) SVOC_W(3, 5) SVOC_W(7, 5) SVOC_W(11, 5)
 #undef SVOC_W
   prof_end(st, prof_idx);
@@ -544,14 +573,19 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   long long total = 0;
   double flops = 0;
   size_t lds = 0;
+  const int WM = wino_wm(*pws[0]);
   for (int i = 0; i < n; ++i) {
-    if (!wino_args(*pws[i], as[i], B, dil, g.a[i])) return 1;
+    if (wino_wm(*pws[i]) != WM || !wino_args(*pws[i], as[i], B, dil, WM, g.a[i])) return 1;
     total += (long long)g.a[i].ntn * g.a[i].gy * B;
     if (total > 0x7fffffffLL) return 1;
     g.end[i] = (int)total;
     g.k[i] = pws[i]->K;
     flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
-    lds = std::max(lds, dil == 1 ? wino_lds<1>(pws[i]->K) : (dil == 3 ? wino_lds<3>(pws[i]->K) : wino_lds<5>(pws[i]->K)));
+    const int K = pws[i]->K;
+    size_t l = 0;
+    if (WM == 4) l = dil == 1 ? wino_lds<1, 4>(K) : (dil == 3 ? wino_lds<3, 4>(K) : wino_lds<5, 4>(K));
+    else l = dil == 1 ? wino_lds<1, 2>(K) : (dil == 3 ? wino_lds<3, 2>(K) : wino_lds<5, 2>(K));
+    lds = std::max(lds, l);
   }
   if (total < 2LL * device_cu_count()) return 1;
   for (int i = n; i < 3; ++i) { g.end[i] = 0x7fffffff; g.k[i] = 3; }
@@ -559,15 +593,15 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "winoG Ci%-4d Co%-4d k%d/%d/%d d%d N%-7d B%-3d", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, dil, as[0].Ncols, B);
+    snprintf(d, sizeof(d), "winoG Ci%-4d Co%-4d k%d/%d/%d d%d N%-7d B%-3d %dx%d", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, dil,
+             as[0].Ncols, B, WM, 4 / WM);
     prof_idx = prof_begin(st, d, flops);
   }
-  const void* kern = dil == 1 ? (const void*)conv_wino_group_kernel<1> : (dil == 3 ? (const void*)conv_wino_group_kernel<3> : (const void*)conv_wino_group_kernel<5>);
-  SVOC_TRY(ensure_max_dyn_lds(kern));
-  if (dil == 1) hipLaunchKernelGGL(conv_wino_group_kernel<1>, dim3((unsigned)total), dim3(256), lds, st, g);
-  else if (dil == 3) hipLaunchKernelGGL(conv_wino_group_kernel<3>, dim3((unsigned)total), dim3(256), lds, st, g);
-  else hipLaunchKernelGGL(conv_wino_group_kernel<5>, dim3((unsigned)total), dim3(256), lds, st, g);
+  int rc = SVOC_OK;
+  if (WM == 4) rc = dil == 1 ? wino_launch_group<1, 4>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 4>(g, total, lds, st) : wino_launch_group<5, 4>(g, total, lds, st));
+  else rc = dil == 1 ? wino_launch_group<1, 2>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 2>(g, total, lds, st) : wino_launch_group<5, 2>(g, total, lds, st));
   prof_end(st, prof_idx);
+  if (rc != SVOC_OK) return rc;
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;
 }
