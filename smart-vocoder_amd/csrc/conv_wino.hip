@@ -38,6 +38,7 @@ struct WinoArgs {
   const float* res; long long res_bs; int res_ld;                   // F_RES
   unsigned flags; float div;                                        // F_RES | F_ACC | F_DIV
   int ntn; int gy; int xcd;                                         // column tiles per row, row blocks, XCD-aware order
+  long long* dbg; int dbg_base;                                     // optional [workgroups][16] stamps (svoc_debug_set_stamp_buffer)
 };
 struct WinoGroup { WinoArgs a[3]; int end[3]; int k[3]; };
 
@@ -57,16 +58,31 @@ struct WinoGeo {
   static constexpr int WN = 4 / WM;                       // waves along the pairs
   static constexpr int PU = ((32 * WN) / D) * D;          // output pairs per tile
   static constexpr int W = 2 * PU;                        // output columns per tile
-  static constexpr int NUV = PU + 2 * (G - 1) * D;        // entries of a V plane row
-  static constexpr int NUE = PU + 2 * D;                  // entries of an E / O plane row (origin one q block before the tile)
-  static constexpr int PQV = (NUV + 3) & ~3;              // plane row strides (floats)
-  static constexpr int PQE = (NUE + 3) & ~3;
-  static constexpr int NPL = ND > 0 ? 6 : 4;              // planes: V0..V3 (+ E, O)
   static constexpr int XOFF = -((PADT * D + 3) & ~3);     // raw tile starts at n0 + XOFF (multiple of 4)
-  static constexpr int VMAX = (2 * (PU / D - 1 + 2 * (G - 1)) - PADT + 3) * D + D - 1;   // last position a V window reads
-  static constexpr int EMAX = ND > 0 ? 2 * PU + 2 * D - 1 : 0;                           // last position of the O plane
-  static constexpr int RAW = (((VMAX > EMAX ? VMAX : EMAX) + 1 - XOFF) + 3) & ~3;        // raw tile columns
+  static constexpr int NQ = PU / D + 2 * (G - 1);         // windows q' per phase and row
+  // D = 1: an item of the transform pass is a pair of windows (q'a, q'a + 1) whose six samples sit at f[1..6] of two aligned
+  // float4 of the raw row; S shifts the pairing (items start at q' = -S) so that this holds for every k.
+  static constexpr int S = (D == 1 && ((-PADT - XOFF) & 3) == 3) ? 1 : 0;
+  static constexpr int NT = (NQ + S + 1) / 2;             // D = 1: items per row
+  // planes V0, V1, V2, V3' (+ E, O), one geometry: entry (q' + S) * D + phase.  E / O hold d1 / d2 of the same window, i.e.
+  // E[q], O[q] with q = q' - (PADT - 1) / 2.
+  static constexpr int EO0 = S + (PADT - 1) / 2;          // E / O entry of q in the V geometry: (q + EO0) * D + phase
+  static constexpr int NUV = D == 1 ? 2 * NT : (NQ + S) * D;
+  static constexpr int PQV = (NUV + 3) & ~3;              // plane row stride (floats)
+  static constexpr int NPL = ND > 0 ? 6 : 4;
+  static constexpr int VMAX = (2 * (NQ - 1) - PADT + 3) * D + D - 1;                     // last position a window reads (from n0)
+  static constexpr int RAW0 = (VMAX + 1 - XOFF + 3) & ~3;
+  static constexpr int RAW = D == 1 ? (RAW0 > 4 * NT + 4 ? RAW0 : 4 * NT + 4) : RAW0;    // raw tile columns
   static constexpr int RAW_FLOATS = KC * RAW;
+  // E / O share the V geometry (same entry index, written by the same transform item) unless that costs the second
+  // workgroup per CU (k = 11, D = 5, 64-pair tiles: 82 KB): then they are stored one q block lower with their own row
+  // stride, and the transform skips the entries that fall outside.
+  static constexpr bool ESHIFT = D > 1 && ND > 0 && (RAW_FLOATS + 6 * KC * PQV) * 4 > 80 * 1024;
+  static constexpr int ESH = ESHIFT ? 1 : 0;
+  static constexpr int EO = EO0 - ESH;
+  static constexpr int DQMAX = G == 2 ? 1 : 2;
+  static constexpr int NUE = ESHIFT ? PU + (DQMAX - 1 + EO) * D : NUV;
+  static constexpr int PQE = ESHIFT ? ((NUE + 3) & ~3) : PQV;
   static constexpr int PL_FLOATS = 4 * KC * PQV + (ND > 0 ? 2 * KC * PQE : 0);
   static constexpr int LDS_BYTES = (RAW_FLOATS + PL_FLOATS) * 4;
 };
@@ -106,15 +122,31 @@ template <int K> constexpr int wino_step_reads(int t) {
   return t >= 4 * (4 * ((K + 1) / 4) + (K + 1) / 4 - 1) ? 0 : (wino_step_direct<K>(t) ? 8 : 4);
 }
 
-template <int K, int D, int WM>
-__device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const int by, const int bz) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// leaky relu of four values in 6 instructions (2 packed multiplies + 4 max; fmaxf() costs a canonicalising max more each)
+__device__ __forceinline__ void wino_lrelu4(float4& q, const float slope) {
+  const f32x2 s2 = {slope, slope};
+  const f32x2 a = (f32x2){q.x, q.y} * s2, b = (f32x2){q.z, q.w} * s2;
+  asm("v_max_f32 %0, %1, %2" : "=v"(q.x) : "v"(q.x), "v"(a.x));
+  asm("v_max_f32 %0, %1, %2" : "=v"(q.y) : "v"(q.y), "v"(a.y));
+  asm("v_max_f32 %0, %1, %2" : "=v"(q.z) : "v"(q.z), "v"(b.x));
+  asm("v_max_f32 %0, %1, %2" : "=v"(q.w) : "v"(q.w), "v"(b.y));
+}
+
+// Instruction budget: measured with per-workgroup stamps (tools/wino_timeline.py), the SIMD time of a workgroup is
+// 64 cycles per MFMA plus ~20 cycles per OTHER vector / memory instruction its waves issue outside the MFMA stream (the
+// partner wave's MFMAs do not hide them) - so staging, transform and epilogue are written for instruction count: aligned
+// 16-byte LDS reads, merged E / O writes, branch-free interior tiles, uniform row bases, bias and direct taps folded into
+// the transform-domain accumulators.
+template <int K, int D, int WM, bool DBG = false>
+__device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const int by, const int bz, const int dbg_lin = 0) {
   using Geo = WinoGeo<K, D, WM>;
-  constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQV = Geo::PQV, PQE = Geo::PQE, RAW = Geo::RAW, SLOTS = Geo::SLOTS;
-  constexpr int PU = Geo::PU, XOFF = Geo::XOFF;
+  constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQV = Geo::PQV, RAW = Geo::RAW, SLOTS = Geo::SLOTS;
+  constexpr int PU = Geo::PU, XOFF = Geo::XOFF, S = Geo::S, EO = Geo::EO, NQ = Geo::NQ;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* const raw = wl;                                   // [KC][RAW]  lrelu(x), zero outside [0, L)
-  float* const pl = wl + Geo::RAW_FLOATS;                  // V0..V3 [KC][PQV] each, then E, O [KC][PQE]
-  constexpr int EBASE = 4 * KC * PQV;                      // E plane offset inside the plane area (O follows)
+  float* const pl = wl + Geo::RAW_FLOATS;                  // V0, V1, V2, V3' (, E, O): [KC][PQV] each
+  constexpr int PLANE = KC * PQV;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -127,110 +159,150 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
   const int mtc = row_ok ? mt : p.mtiles - 1;
   const int L = p.L;
 
-  f32x16 M[4], Dd[2];
+  // transform-domain accumulators: y[even] = M0 + M1 + M2, y[odd] = M1 - M2 + M3' (M3' = -M3: its plane holds d3 - d1).
+  // The bias starts in M1 (part of both outputs); a direct tap adds w * E to M0 (even outputs only) and w * O to M3'.
+  f32x16 M[4];
+  {
+    const float* bias = p.bias + mtc * 32 + 4 * hi;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { M[0][i] = 0.f; M[1][i] = 0.f; M[2][i] = 0.f; M[3][i] = 0.f; Dd[0][i] = 0.f; Dd[1][i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { M[0][i] = 0.f; M[1][i] = bias[(i & 3) + 8 * (i >> 2)]; M[2][i] = 0.f; M[3][i] = 0.f; }
+  }
 
-  // ---- raw staging: 32 channels x RAW columns.  Thread (r0, g4) of the first RPP * R4 threads owns float4 group g4 of rows
-  // r0, r0 + RPP, ...: one per-thread offset + a wave-uniform base per pass on the global side, one per-thread LDS address +
-  // an immediate per pass on the LDS side - no per-slot index arithmetic (every vector instruction of these phases takes
-  // matrix-pipe time from the other workgroup's MFMA phase).
-  constexpr int R4 = RAW / 4, RPP = 256 / R4, NPASS = (KC + RPP - 1) / RPP;
+  // ---- raw staging: 32 channels x RAW columns = NG float4 groups.  Two item -> thread mappings:
+  // LINEAR (4 x 1 tiles, few passes): group g = row * R4 + g4 goes to thread g % 256 in pass g / 256 - the last pass is partial
+  // and whole waves skip it; the LDS tile is contiguous in g, the global side keeps one per-thread offset per pass.
+  // Regular (2 x 2 tiles, five or six passes): thread (r0, g4) owns group g4 of rows r0, r0 + RPP, ...: one per-thread offset
+  // and a uniform base / an immediate per pass, no per-pass registers (and no scalar masks to spill).
+  constexpr bool LINEAR = WM == 4;
+  constexpr int R4 = RAW / 4, NG = KC * R4, RPP = 256 / R4;
+  constexpr int NPASS = LINEAR ? (NG + 255) / 256 : (KC + RPP - 1) / RPP;
   const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
   const long long ldb = (long long)p.x_ld * 4;
   const int xs_start = n0 + XOFF;
+  const bool interior = xs_start >= 0 && xs_start + RAW <= L;      // workgroup-uniform: no zero padding anywhere in the tile
   const float slope = p.pre_slope;
-  const int r0 = tid / R4, g4 = tid - r0 * R4;
-  const bool mine = tid < RPP * R4;
-  const int tg = xs_start + 4 * g4;                        // first column of this thread's groups
-  const bool inside = tg >= 0 && tg + 3 < L;               // else: a group that straddles an end of the sequence
-  const unsigned goff = (unsigned)((mine ? r0 : 0) * p.x_ld + (inside ? tg : 0)) * 4u;
+  const int r0 = tid / R4, g40 = tid - r0 * R4;
+  auto st_row = [&](int u) { return LINEAR ? (tid + 256 * u) / R4 : r0 + u * RPP; };
+  auto st_g4 = [&](int u) { return LINEAR ? (tid + 256 * u) % R4 : g40; };
+  auto st_valid = [&](int u) -> bool {
+    if constexpr (LINEAR) return 256 * (u + 1) <= NG || tid < NG - 256 * u;
+    else return tid < RPP * R4 && (u * RPP + RPP - 1 < KC || r0 + u * RPP < KC);
+  };
+  unsigned goff[LINEAR ? NPASS : 1];                       // byte offset of the pass's group inside the chunk (clamped into the tile)
+#pragma unroll
+  for (int u = 0; u < (LINEAR ? NPASS : 1); ++u) {
+    const int row = LINEAR ? min(st_row(u), KC - 1) : (tid < RPP * R4 ? r0 : 0), tg = xs_start + 4 * st_g4(u);
+    goff[u] = (unsigned)(row * p.x_ld + ((tg >= 0 && tg + 3 < L) ? tg : 0)) * 4u;
+  }
   float4 v[NPASS];
   auto issue = [&](int ch) {
     const char* cb = xb + (long long)ch * KC * ldb;
 #pragma unroll
     for (int u = 0; u < NPASS; ++u) {
-      if (u * RPP + RPP - 1 < KC) {                        // compile time: every row of this pass exists
-        v[u] = *reinterpret_cast<const float4*>(cb + (long long)(u * RPP) * ldb + goff);
-      } else {                                             // last, partial pass: rows beyond the chunk re-read its last row (not written)
-        const int c = min((mine ? r0 : 0) + u * RPP, KC - 1);
-        v[u] = *reinterpret_cast<const float4*>(cb + (long long)c * ldb + (long long)(inside ? tg : 0) * 4);
+      if constexpr (LINEAR) v[u] = *reinterpret_cast<const float4*>(cb + goff[u]);
+      else if (u * RPP + RPP - 1 < KC) v[u] = *reinterpret_cast<const float4*>(cb + (long long)(u * RPP) * ldb + goff[0]);
+      else {                                               // last, partial pass: rows beyond the chunk re-read its last row (not written)
+        const int c = min((tid < RPP * R4 ? r0 : 0) + u * RPP, KC - 1), tg = xs_start + 4 * g40;
+        v[u] = *reinterpret_cast<const float4*>(cb + (long long)c * ldb + (long long)((tg >= 0 && tg + 3 < L) ? tg : 0) * 4);
       }
     }
   };
-  float* const rdst = raw + r0 * RAW + 4 * g4;
+  float* const rdst = LINEAR ? raw + 4 * tid : raw + r0 * RAW + 4 * g40;
+  constexpr int RSTEP = LINEAR ? 1024 : RPP * RAW;         // LDS floats between a thread's groups of consecutive passes
   auto publish = [&](int ch) {
+    if (interior) {
 #pragma unroll
-    for (int u = 0; u < NPASS; ++u) {
-      if (mine && (u * RPP + RPP - 1 < KC || r0 + u * RPP < KC)) {
-        float4 q = v[u];
-        if (!inside) {                                     // rare: element-wise with zero padding
-          const float* row = reinterpret_cast<const float*>(xb + (long long)(ch * KC + r0 + u * RPP) * ldb);
-          q.x = (tg >= 0 && tg < L) ? row[tg] : 0.f;
-          q.y = (tg + 1 >= 0 && tg + 1 < L) ? row[tg + 1] : 0.f;
-          q.z = (tg + 2 >= 0 && tg + 2 < L) ? row[tg + 2] : 0.f;
-          q.w = (tg + 3 >= 0 && tg + 3 < L) ? row[tg + 3] : 0.f;
+      for (int u = 0; u < NPASS; ++u) {
+        if (st_valid(u)) {
+          float4 q = v[u];
+          wino_lrelu4(q, slope);
+          *reinterpret_cast<float4*>(rdst + RSTEP * u) = q;
         }
-        q.x = fmaxf(q.x, q.x * slope); q.y = fmaxf(q.y, q.y * slope);
-        q.z = fmaxf(q.z, q.z * slope); q.w = fmaxf(q.w, q.w * slope);
-        *reinterpret_cast<float4*>(rdst + u * RPP * RAW) = q;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u) {
+        if (st_valid(u)) {
+          const int row = st_row(u), tg = xs_start + 4 * st_g4(u);
+          float4 q = v[u];
+          if (!(tg >= 0 && tg + 3 < L)) {                  // a group that straddles an end of the sequence: element-wise, zero padding
+            const float* xr = reinterpret_cast<const float*>(xb + (long long)(ch * KC + row) * ldb);
+            q.x = (tg >= 0 && tg < L) ? xr[tg] : 0.f;
+            q.y = (tg + 1 >= 0 && tg + 1 < L) ? xr[tg + 1] : 0.f;
+            q.z = (tg + 2 >= 0 && tg + 2 < L) ? xr[tg + 2] : 0.f;
+            q.w = (tg + 3 >= 0 && tg + 3 < L) ? xr[tg + 3] : 0.f;
+          }
+          wino_lrelu4(q, slope);
+          *reinterpret_cast<float4*>(rdst + RSTEP * u) = q;
+        }
       }
     }
   };
-  // ---- transform pass: raw -> V0..V3 and E / O.  V entry u' = q' D + phase: window d_j = raw[(2 q' - PADT + j) D + phase - XOFF];
-  // E / O entry e = (q + 1) D + phase: raw[2 q D + phase - XOFF], raw[(2 q + 1) D + phase - XOFF].  Same regular mapping:
-  // an item (two q' of one phase: they share two window samples) per thread and pass, rows TPP apart.
-  constexpr int NQ = Geo::NUV / D, NQ2 = (NQ + 1) / 2, IPR = NQ2 * D;   // q' per phase, pairs of q', items per row
-  constexpr int TPP = 256 / IPR, TPASS = (KC + TPP - 1) / TPP;
-  const int tr0 = tid / IPR, trem = tid - tr0 * IPR;
-  const int tq2 = trem / D, tph = trem - tq2 * D;
-  const bool tmine = tid < TPP * IPR;
-  const bool tsecond = 2 * tq2 + 1 < NQ;                   // the item's second q' exists (NQ may be odd)
-  const float* const tsrc = raw + tr0 * RAW + (4 * tq2 - PADT) * D + tph - XOFF;
-  float* const tdst = pl + tr0 * PQV + 2 * tq2 * D + tph;
-  constexpr int NQE = Geo::NUE / D, EIPR = ((NQE + 1) / 2) * D;         // E / O: pairs of q per phase
-  constexpr int EPP = 256 / EIPR, EPASS = (KC + EPP - 1) / EPP;
-  const int er0 = tid / EIPR, erem = tid - er0 * EIPR;
-  const int eq2 = erem / D, eph = erem - eq2 * D;
-  const bool emine = tid < EPP * EIPR;
-  const bool esecond = 2 * eq2 + 1 < NQE;
-  const float* const esrc = raw + er0 * RAW + (4 * eq2 - 2) * D + eph - XOFF;
-  float* const edst = pl + EBASE + er0 * PQE + 2 * eq2 * D + eph;
+  // ---- transform pass: raw -> planes.  Window q' of phase ph: d_j = raw[(2 q' - PADT + j) D + ph - XOFF], j = 0..3;
+  // plane entry (q' + S) D + ph:  V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3' = d3 - d1, E = d1, O = d2.
+  // An item is two consecutive windows of one phase (they share two samples), IPR items per row; same two mappings
+  // (LINEAR: LDS addresses per pass computed once per workgroup; regular: rows TPP apart, immediates).
+  constexpr int NQ2 = D == 1 ? Geo::NT : (NQ + 1) / 2, IPR = NQ2 * D;      // items per row
+  constexpr int NI = KC * IPR, TPP = 256 / IPR;
+  constexpr int TPASS = LINEAR ? (NI + 255) / 256 : (KC + TPP - 1) / TPP;
+  constexpr int TN = LINEAR ? TPASS : 1;                   // per-pass address sets kept in registers
+  constexpr int PQE = Geo::PQE, ESH = Geo::ESH;
+  constexpr int EBASE = 4 * PLANE;                         // E plane offset inside the plane area (O follows, KC * PQE further)
+  const float* tsrc[TN];                                   // LDS addresses of the item's samples / V0 entry / E entry
+  float* tdst[TN];
+  float* tedst[TN];
+  unsigned tflags = 0;                                     // per set: bit 3u = second window exists, 3u+1 / 3u+2 = E/O of window 1 / 2 stored
+  const int tr0 = tid / IPR;
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int it = LINEAR ? min(tid + 256 * u, NI - 1) : tid;
+    const int row = LINEAR ? it / IPR : tr0, rem = it - row * IPR;
+    const int tq2 = rem / D, tph = rem - tq2 * D;
+    // D = 1: item t covers q' = 2 t - S, 2 t - S + 1; its samples are f[1..6] of raw[4 t .. 4 t + 7] (see WinoGeo::S)
+    tsrc[u] = D == 1 ? raw + row * RAW + 4 * tq2 : raw + row * RAW + (4 * tq2 - PADT) * D + tph - XOFF;
+    tdst[u] = pl + row * PQV + 2 * tq2 * D + tph;
+    const int e1 = (2 * tq2 - ESH) * D + tph;              // E / O entry of the first window (second: + D)
+    tedst[u] = pl + EBASE + row * PQE + e1;
+    const bool second = D == 1 || 2 * tq2 + 1 < NQ;
+    if (second) tflags |= 1u << (3 * u);
+    if (e1 >= 0 && e1 < Geo::NUE) tflags |= 2u << (3 * u);
+    if (second && e1 + D < Geo::NUE) tflags |= 4u << (3 * u);
+  }
+  auto tr_valid = [&](int u) -> bool {
+    if constexpr (LINEAR) return 256 * (u + 1) <= NI || tid < NI - 256 * u;
+    else return tid < TPP * IPR && (u * TPP + TPP - 1 < KC || tr0 + u * TPP < KC);
+  };
   auto transform = [&]() {
 #pragma unroll
     for (int u = 0; u < TPASS; ++u) {
-      if (tmine && (u * TPP + TPP - 1 < KC || tr0 + u * TPP < KC)) {
-        const float* r = tsrc + u * TPP * RAW;
-        float* o = tdst + u * TPP * PQV;
-        const float d0 = r[0], d1 = r[D], d2 = r[2 * D], d3 = r[3 * D];
-        if constexpr (D == 1) {                            // the two q' are neighbours in the plane: 8-byte stores
-          const float d4 = r[4], d5 = r[5];                // (NUV is even for D = 1)
+      if (tr_valid(u)) {
+        constexpr int FS = LINEAR ? 3 : 0;                 // flag set of pass u: 3 u (LINEAR) or the one shared set
+        const float* r = LINEAR ? tsrc[LINEAR ? u : 0] : tsrc[0] + u * TPP * RAW;
+        float* o = LINEAR ? tdst[LINEAR ? u : 0] : tdst[0] + u * TPP * PQV;
+        if constexpr (D == 1) {
+          const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
+          const float d0 = fa.y, d1 = fa.z, d2 = fa.w, d3 = fb.x, d4 = fb.y, d5 = fb.z;
           *reinterpret_cast<float2*>(o) = make_float2(d0 - d2, d2 - d4);
-          *reinterpret_cast<float2*>(o + KC * PQV) = make_float2(d1 + d2, d3 + d4);
-          *reinterpret_cast<float2*>(o + 2 * KC * PQV) = make_float2(d2 - d1, d4 - d3);
-          *reinterpret_cast<float2*>(o + 3 * KC * PQV) = make_float2(d1 - d3, d3 - d5);
-        } else {
-          o[0] = d0 - d2; o[KC * PQV] = d1 + d2; o[2 * KC * PQV] = d2 - d1; o[3 * KC * PQV] = d1 - d3;
-          if (tsecond) {
-            const float d4 = r[4 * D], d5 = r[5 * D];
-            o[D] = d2 - d4; o[KC * PQV + D] = d3 + d4; o[2 * KC * PQV + D] = d4 - d3; o[3 * KC * PQV + D] = d3 - d5;
+          *reinterpret_cast<float2*>(o + PLANE) = make_float2(d1 + d2, d3 + d4);
+          *reinterpret_cast<float2*>(o + 2 * PLANE) = make_float2(d2 - d1, d4 - d3);
+          *reinterpret_cast<float2*>(o + 3 * PLANE) = make_float2(d3 - d1, d5 - d3);
+          if constexpr (ND > 0) {
+            *reinterpret_cast<float2*>(o + 4 * PLANE) = make_float2(d1, d3);
+            *reinterpret_cast<float2*>(o + 5 * PLANE) = make_float2(d2, d4);
           }
-        }
-      }
-    }
-    if constexpr (ND > 0) {
-#pragma unroll
-      for (int u = 0; u < EPASS; ++u) {
-        if (emine && (u * EPP + EPP - 1 < KC || er0 + u * EPP < KC)) {
-          const float* r = esrc + u * EPP * RAW;           // q = 2 eq2 - 1: E = r[0], O = r[D]; q + 1: r[2 D], r[3 D]
-          float* o = edst + u * EPP * PQE;
-          if constexpr (D == 1) {
-            const float2 a = *reinterpret_cast<const float2*>(r), b = *reinterpret_cast<const float2*>(r + 2);
-            *reinterpret_cast<float2*>(o) = make_float2(a.x, b.x);
-            *reinterpret_cast<float2*>(o + KC * PQE) = make_float2(a.y, b.y);
-          } else {
-            o[0] = r[0]; o[KC * PQE] = r[D];
-            if (esecond) { o[D] = r[2 * D]; o[KC * PQE + D] = r[3 * D]; }
+        } else {
+          const float d0 = r[0], d1 = r[D], d2 = r[2 * D], d3 = r[3 * D];
+          o[0] = d0 - d2; o[PLANE] = d1 + d2; o[2 * PLANE] = d2 - d1; o[3 * PLANE] = d3 - d1;
+          float* oe = LINEAR ? tedst[LINEAR ? u : 0] : tedst[0] + u * TPP * PQE;
+          if constexpr (ND > 0) {
+            if (!Geo::ESHIFT || (tflags & (2u << (FS * u)))) { oe[0] = d1; oe[KC * PQE] = d2; }
+          }
+          if ((NQ & 1) == 0 || (tflags & (1u << (FS * u)))) {
+            const float d4 = r[4 * D], d5 = r[5 * D];
+            o[D] = d2 - d4; o[PLANE + D] = d3 + d4; o[2 * PLANE + D] = d4 - d3; o[3 * PLANE + D] = d5 - d3;
+            if constexpr (ND > 0) {
+              if (!Geo::ESHIFT || (tflags & (4u << (FS * u)))) { oe[D] = d3; oe[KC * PQE + D] = d4; }
+            }
           }
         }
       }
@@ -238,22 +310,25 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
   };
 
   // ---- MFMA phase of one chunk.  Weight slots (pack_wino order): sigma = 4 g + p for the groups, then the direct taps.
-  // All four weight fragments (16 k-steps) of slot sigma + 1 are requested while slot sigma computes.
   const int uu = wn * 32 + l31;                            // this lane's pair index (>= PU: idle lane of a dilated tile)
   const unsigned pbase = (unsigned)(size_t)pl;
-  const unsigned baddrV = pbase + (unsigned)(hi * PQV + uu) * 4u;
+  const unsigned baddr = pbase + (unsigned)(hi * PQV + uu) * 4u;
   const unsigned baddrE = pbase + (unsigned)(hi * PQE + uu) * 4u;
   const char* const wrow = reinterpret_cast<const char*>(p.wp) + (size_t)mtc * p.nchunks * SLOTS * 4096 + (size_t)lane * 16;
   // The chunk is a static list of NS = 4 * SLOTS steps; step t = (slot t / 4, k-group t % 4) issues 4 MFMAs (group slot:
-  // plane P at column 2 g D into M[P]) or 8 (direct tap: E and O at column DQ * D into Dd[0], Dd[1]).  Fragment reads run
-  // TWO steps ahead in two register sets: step t waits for its own reads only (lgkmcnt = size of step t + 1's request),
-  // issues its MFMAs, then requests step t + 2 into the set it has just consumed - an LDS round trip is never exposed.
-  auto mfma_chunk = [&](int ch) {
+  // plane P at column (2 g + S) D into M[P]) or 8 (direct tap: E and O at column (DQ - 1 + EO) D into M[0], M[3]).  Fragment
+  // reads run TWO steps ahead in two register sets: step t waits for its own reads only (lgkmcnt = size of step t + 1's
+  // request), issues its MFMAs, then requests step t + 2 into the set it has just consumed.
+  // Weight registers: two sets of four float4 (16 k-steps of one slot each); slot sigma of chunk ch lives in set
+  // (PAR + sigma) & 1 where PAR is the chunk's starting set.  The slot-ahead request runs across chunk boundaries, and the
+  // next chunk's raw-tile loads are issued before the transform pass (vmcnt retires in order: a weight wait in the MFMA
+  // phase must not sit behind a fresh HBM request).  Both measured neutral, kept for the simpler wait pattern.
+  float4 a[2][4];
+  auto mfma_chunk = [&](int ch, auto par) {
+    constexpr int PAR = decltype(par)::value;
     constexpr int NS = 4 * SLOTS;
     const char* wa = wrow + (size_t)ch * SLOTS * 4096;
-    float4 a[2][4];
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) a[0][kg] = *reinterpret_cast<const float4*>(wa + kg * 1024);
+    const bool more = ch + 1 < p.nchunks;
     float fb[2][4], fo[2][4];
     auto request = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
@@ -261,12 +336,12 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
         constexpr int SG = T / 4, KG = T % 4;
         if constexpr (SG < 4 * G) {
           constexpr int GG = SG / 4, P = SG % 4;
-          wino_frag<PQV, P * KC * PQV, KG, 2 * GG * D>(fb[T & 1], baddrV);
+          wino_frag<PQV, P * PLANE, KG, (2 * GG + S) * D>(fb[T & 1], baddr);
         } else {
           constexpr int DI = SG - 4 * G;
           constexpr int DQ = (G == 2) ? 1 : (DI == 0 ? 0 : 2);              // 1 + (tap - PADT) / 2 for taps 3, 7
-          wino_frag<PQE, EBASE, KG, DQ * D>(fb[T & 1], baddrE);
-          wino_frag<PQE, EBASE + KC * PQE, KG, DQ * D>(fo[T & 1], baddrE);
+          wino_frag<PQE, EBASE, KG, (DQ - 1 + EO) * D>(fb[T & 1], baddrE);
+          wino_frag<PQE, EBASE + KC * PQE, KG, (DQ - 1 + EO) * D>(fo[T & 1], baddrE);
         }
       }
     };
@@ -285,15 +360,17 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
     auto step = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
       constexpr int SG = T / 4, KG = T % 4;
-      // next slot's weights a whole slot ahead (two sets of four registers).  Measured alternative: one float4 per step two
-      // steps ahead in a ring of three - 40 registers fewer, three waves per SIMD - is 9 % SLOWER (k=11: 1101 -> 1205 us)
-      if constexpr (KG == 0 && SG + 1 < SLOTS) {
-        const char* wn_ = wa + (SG + 1) * 4096;
+      // next slot's weights a whole slot ahead.  Measured alternative: one float4 per step two steps ahead in a ring of
+      // three - 40 registers fewer - is 9 % SLOWER (k=11: 1101 -> 1205 us)
+      if constexpr (KG == 0) {
+        if (SG + 1 < SLOTS || more) {                      // slot SLOTS of this chunk = slot 0 of the next one
+          const char* wn_ = wa + (SG + 1) * 4096;
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) a[(SG + 1) & 1][kg] = *reinterpret_cast<const float4*>(wn_ + kg * 1024);
+          for (int kg = 0; kg < 4; ++kg) a[(PAR + SG + 1) & 1][kg] = *reinterpret_cast<const float4*>(wn_ + kg * 1024);
+        }
       }
       wait_for(tc);
-      const float4 av = a[SG & 1][KG];
+      const float4 av = a[(PAR + SG) & 1][KG];
       if constexpr (SG < 4 * G) {
         constexpr int P = SG % 4;
 #pragma unroll
@@ -301,8 +378,8 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
       } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          Dd[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], Dd[0], 0, 0, 0);
-          Dd[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fo[T & 1][s], Dd[1], 0, 0, 0);
+          M[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[0], 0, 0, 0);
+          M[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fo[T & 1][s], M[3], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -314,76 +391,122 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
     wino_static_for<0, NS>(step);
   };
 
+  // diagnostics (tools/wino_timeline.py): wall-clock start / end of the workgroup, shader cycles wave 0 spent inside MFMA
+  // phases and in the parts of the staging / transform section of the chunk loop
+  long long ts_start = 0, cyc_mfma = 0, cyc_prep = 0, cyc_pub = 0, cyc_b1 = 0, cyc_tr = 0;
+  if constexpr (DBG) ts_start = (long long)wall_clock64();
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) a[0][kg] = *reinterpret_cast<const float4*>(wrow + kg * 1024);
   issue(0);
-  for (int ch = 0; ch < p.nchunks; ++ch) {
+  auto chunk = [&](int ch, auto par) {
+    long long c0 = 0, c1 = 0, q0 = 0, q1 = 0, q2 = 0;
+    if constexpr (DBG) c0 = (long long)__builtin_readcyclecounter();
     publish(ch);
+    if (ch + 1 < p.nchunks) issue(ch + 1);                 // in flight under the transform pass and the MFMA phase
+    if constexpr (DBG) q0 = (long long)__builtin_readcyclecounter();
     __syncthreads();                                       // raw complete; every wave has left the previous chunk's MFMA phase
+    if constexpr (DBG) q1 = (long long)__builtin_readcyclecounter();
     transform();
-    if (ch + 1 < p.nchunks) issue(ch + 1);                 // in flight under the MFMA phase
+    if constexpr (DBG) { q2 = (long long)__builtin_readcyclecounter(); cyc_pub += q0 - c0; cyc_b1 += q1 - q0; cyc_tr += q2 - q1; }
     __syncthreads();
-    if (row_ok) mfma_chunk(ch);
+    if constexpr (DBG) c1 = (long long)__builtin_readcyclecounter();
+    if (row_ok) mfma_chunk(ch, par);
+    if constexpr (DBG) { cyc_prep += c1 - c0; cyc_mfma += (long long)__builtin_readcyclecounter() - c1; }
+  };
+  if constexpr ((SLOTS & 1) == 0) {
+    for (int ch = 0; ch < p.nchunks; ++ch) chunk(ch, std::integral_constant<int, 0>{});
+  } else {                                                 // odd slot count: the starting register set alternates
+    for (int ch = 0; ch < p.nchunks; ch += 2) {
+      chunk(ch, std::integral_constant<int, 0>{});
+      if (ch + 1 < p.nchunks) chunk(ch + 1, std::integral_constant<int, 1>{});
+    }
   }
-  if (!row_ok || uu >= PU) return;
+  long long c_epi = 0;
+  if constexpr (DBG) c_epi = (long long)__builtin_readcyclecounter();
+  auto dbg_out = [&]() {
+    if constexpr (DBG) if (tid == 0) {
+      long long* d = p.dbg + 16 * (long long)(p.dbg_base + dbg_lin);
+      d[8] = cyc_pub; d[9] = cyc_b1; d[10] = cyc_tr;
+      d[0] = ts_start; d[1] = (long long)wall_clock64(); d[2] = cyc_mfma; d[3] = cyc_prep;
+      d[4] = (long long)__builtin_readcyclecounter() - c_epi; d[5] = 1;
+      d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_ID: wave, simd, cu, sh, se
+      d[7] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);      // XCC_ID
+    }
+  };
 
-  // ---- output transform + epilogue: lane owns y[row][ne] and y[row][ne + D] for its 16 rows
+  // ---- output transform + epilogue: lane owns y[row][ne] and y[row][ne + D] for its 16 rows.  Row r of the lane is at
+  // (uniform base of row (r & 3) + 8 (r >> 2)) + (per-lane byte offset): no per-row vector address arithmetic.
   const int ne = n0 + 2 * (uu / D) * D + (uu % D);
-  if (ne >= L) return;
+  if (!row_ok || uu >= PU || ne >= L) { dbg_out(); return; }
   const bool odd_ok = ne + D < L;
-  const float* bias = p.bias + mt * 32 + 4 * hi;
-  const long long yrow0 = (long long)bz * p.y_bs + (long long)(mt * 32 + 4 * hi) * p.y_ld + ne;
   float2 vo[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float bv = bias[(r & 3) + 8 * (r >> 2)];
-    float ye = (M[0][r] + M[1][r]) + M[2][r];
-    float yo = (M[1][r] - M[2][r]) - M[3][r];
-    if constexpr (ND > 0) { ye += Dd[0][r]; yo += Dd[1][r]; }
-    vo[r] = make_float2(ye + bv, yo + bv);
+    const float t1 = M[1][r] + M[2][r], t2 = M[1][r] - M[2][r];
+    vo[r] = make_float2(M[0][r] + t1, M[3][r] + t2);
   }
-  // D == 1 with an even L: the pair is one aligned 8-byte access; otherwise two 4-byte accesses D columns apart
-  auto ld2 = [&](const float* q) -> float2 {
-    if constexpr (D == 1) { if (odd_ok) return *reinterpret_cast<const float2*>(q); return make_float2(q[0], 0.f); }
-    else return make_float2(q[0], odd_ok ? q[D] : 0.f);
-  };
-  if (p.flags & F_RES) {
-    const float* rb = p.res + (long long)bz * p.res_bs + (long long)(mt * 32 + 4 * hi) * p.res_ld + ne;
-    float2 rv[16];
+  // address of row r = (uniform base of row block r >> 2) + (per-lane offset of row r & 3): 4 + 4 registers, no per-row math
+  const unsigned ylb = (unsigned)p.y_ld * 4u, rlb = (unsigned)p.res_ld * 4u;
+  unsigned yo4[4], ro4[4];
+  char* yb4[4];
+  const char* rb4[4];
+  {
+    const unsigned yoff = (unsigned)(4 * hi * p.y_ld + ne) * 4u, roff = (unsigned)(4 * hi * p.res_ld + ne) * 4u;
+    char* const ybase = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld);
+    const char* const rbase = reinterpret_cast<const char*>(p.res + (long long)bz * p.res_bs + (long long)(mt * 32) * p.res_ld);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rv[r] = ld2(rb + (long long)((r & 3) + 8 * (r >> 2)) * p.res_ld);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; }
-  }
-  if (p.flags & F_ACC) {
-    float2 yv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) yv[r] = ld2(p.y + yrow0 + (long long)((r & 3) + 8 * (r >> 2)) * p.y_ld);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { vo[r].x = yv[r].x + vo[r].x; vo[r].y = yv[r].y + vo[r].y; }
-  }
-  if (p.flags & F_DIV) {
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { vo[r].x = vo[r].x / p.div; vo[r].y = vo[r].y / p.div; }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float* q = p.y + yrow0 + (long long)((r & 3) + 8 * (r >> 2)) * p.y_ld;
-    if constexpr (D == 1) {
-      if (odd_ok) *reinterpret_cast<float2*>(q) = vo[r]; else q[0] = vo[r].x;
-    } else {
-      q[0] = vo[r].x;
-      if (odd_ok) q[D] = vo[r].y;
+    for (int i = 0; i < 4; ++i) {
+      yo4[i] = yoff + i * ylb; ro4[i] = roff + i * rlb;
+      yb4[i] = ybase + (size_t)(8 * i) * ylb; rb4[i] = rbase + (size_t)(8 * i) * rlb;
     }
   }
+  auto finish = [&](auto pair_c) {
+    constexpr bool PAIR = decltype(pair_c)::value;         // the lane's second output exists
+    auto ld2 = [&](const char* q) -> float2 {
+      if constexpr (D == 1 && PAIR) return *reinterpret_cast<const float2*>(q);
+      else if constexpr (PAIR) return make_float2(*reinterpret_cast<const float*>(q), *reinterpret_cast<const float*>(q + 4 * D));
+      else return make_float2(*reinterpret_cast<const float*>(q), 0.f);
+    };
+    if (p.flags & F_RES) {
+      float2 rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = ld2(rb4[r >> 2] + ro4[r & 3]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; }
+    }
+    if (p.flags & F_ACC) {
+      float2 yv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yv[r] = ld2(yb4[r >> 2] + yo4[r & 3]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { vo[r].x = yv[r].x + vo[r].x; vo[r].y = yv[r].y + vo[r].y; }
+    }
+    if (p.flags & F_DIV) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { vo[r].x = vo[r].x / p.div; vo[r].y = vo[r].y / p.div; }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      char* q = yb4[r >> 2] + yo4[r & 3];
+      if constexpr (D == 1 && PAIR) *reinterpret_cast<float2*>(q) = vo[r];
+      else {
+        *reinterpret_cast<float*>(q) = vo[r].x;
+        if constexpr (PAIR) *reinterpret_cast<float*>(q + 4 * D) = vo[r].y;
+      }
+    }
+  };
+  if (odd_ok) finish(std::true_type{}); else finish(std::false_type{});
+  dbg_out();
 }
 
-template <int K, int D, int WM>
+template <int K, int D, int WM, bool DBG>
 __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs p) {
   const int lin = blockIdx.x;
   const int tl = xcd_linear(lin, gridDim.x, p.xcd);
   const int t = tl / p.ntn;
   const int bz = t / p.gy;
-  wino_tile<K, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  wino_tile<K, D, WM, DBG>(p, tl - t * p.ntn, t - bz * p.gy, bz, lin);
 }
 
 // up to three problems of one dilation (the MRF chains' convolutions of one step, k = 11 / 7 / 3) in one launch, longest first
@@ -399,9 +522,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup
   const int t = tl / p.ntn;
   const int bz = t / p.gy;
   const int k = g.k[pi];
-  if (k == 11) wino_tile<11, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
-  else if (k == 7) wino_tile<7, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
-  else wino_tile<3, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz);
+  if (k == 11) wino_tile<11, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz, lin);
+  else if (k == 7) wino_tile<7, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz, lin);
+  else wino_tile<3, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz, lin);
 }
 
 // ------------------------------------------------------------------ weight transform + packing
@@ -518,6 +641,7 @@ static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, int D, int
   w.flags = o.flags; w.div = o.div;
   const int W = wino_tile_w(D, WM);
   w.ntn = (a.Ncols + W - 1) / W; w.gy = (pw.mtiles + WM - 1) / WM; w.xcd = xcd_mapping_enabled();
+  w.dbg = debug_stamp_buffer(); w.dbg_base = 0;
   (void)B;
   return true;
 }
@@ -525,10 +649,16 @@ template <int K, int D, int WM>
 static int wino_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
   using Geo = WinoGeo<K, D, WM>;
   static_assert(Geo::LDS_BYTES <= 160 * 1024, "tile does not fit");
-  auto kern = conv_wino_kernel<K, D, WM>;
-  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const size_t lds = (size_t)Geo::LDS_BYTES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, w);
+  if (w.dbg) {                                             // stamped build of the same kernel (tools/wino_timeline.py)
+    auto kern = conv_wino_kernel<K, D, WM, true>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, w);
+  } else {
+    auto kern = conv_wino_kernel<K, D, WM, false>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, w);
+  }
   return SVOC_OK;
 }
 template <int D, int WM>
