@@ -133,6 +133,10 @@ __device__ __forceinline__ void wino_lrelu4(float4& q, const float slope) {
   asm("v_max_f32 %0, %1, %2" : "=v"(q.w) : "v"(q.w), "v"(b.y));
 }
 
+// Persistent workgroups (one per CU slot walking a strided list of tiles, tile-independent set-up done once, next tile's
+// first raw loads requested before the epilogue) were measured too: k = 7 / 11 -1..3 %, k = 3 +7 % (the longer live ranges
+// cost the third workgroup per CU), 16 x 512 step 37.15 -> 37.5 ms - not kept.  Lesson kept: loop-invariant work of the rare
+// edge-tile paths must not be hoistable (it cost 80 registers there).
 // Instruction budget: measured with per-workgroup stamps (tools/wino_timeline.py), the SIMD time of a workgroup is
 // 64 cycles per MFMA plus ~20 cycles per OTHER vector / memory instruction its waves issue outside the MFMA stream (the
 // partner wave's MFMAs do not hide them) - so staging, transform and epilogue are written for instruction count: aligned
@@ -481,10 +485,14 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) { vo[r].x = yv[r].x + vo[r].x; vo[r].y = yv[r].y + vo[r].y; }
     }
-    if (p.flags & F_DIV) {
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { vo[r].x = vo[r].x / p.div; vo[r].y = vo[r].y / p.div; }
+    if (p.flags & F_DIV) {                                 // x / div as x * (1 / div) with one residual correction: 3 instructions
+      const float dv = p.div, rc = 1.0f / dv;              // per value instead of the ~10 of the IEEE sequence (same result up to
+#pragma unroll                                             // rare last-bit differences in halfway cases)
+      for (int r = 0; r < 16; ++r) {
+        const float qx = vo[r].x * rc, qy = vo[r].y * rc;
+        vo[r].x = __builtin_fmaf(__builtin_fmaf(-qx, dv, vo[r].x), rc, qx);
+        vo[r].y = __builtin_fmaf(__builtin_fmaf(-qy, dv, vo[r].y), rc, qy);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

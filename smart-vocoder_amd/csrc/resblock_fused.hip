@@ -377,6 +377,14 @@ __device__ __forceinline__ void gemm_ct(f32x16 (&acc)[NR], const char* __restric
   if constexpr (NCH > 1) chunk(std::integral_constant<int, 1>{});
 }
 
+typedef float rb_f32x2 __attribute__((ext_vector_type(2)));
+// leaky relu without fmaxf's canonicalising extra max: 1 packed multiply per two values + 1 max per value
+__device__ __forceinline__ void rb_lrelu2(float& a, float& b, const float slope) {
+  const rb_f32x2 m = (rb_f32x2){a, b} * (rb_f32x2){slope, slope};
+  asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(m.x));
+  asm("v_max_f32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(m.y));
+}
+
 template <int C, int K, int D, int NRT>
 __global__ void __launch_bounds__(256, 2) resblock_fused_ct_kernel(const FusedArgs p) {
   using G = RbGeo<C, K, D, NRT>;
@@ -449,10 +457,8 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_ct_kernel(const FusedAr
       const bool full = u * RPP + RPP - 1 < C;            // compile time: every row of this pass exists
       if (mine && (full || r0 + u * RPP < C)) {
         float4 q = v[u];
-        q.x = fmaxf(q.x, q.x * slope);
-        q.y = fmaxf(q.y, q.y * slope);
-        q.z = fmaxf(q.z, q.z * slope);
-        q.w = fmaxf(q.w, q.w * slope);
+        rb_lrelu2(q.x, q.y, slope);
+        rb_lrelu2(q.z, q.w, slope);
         *reinterpret_cast<float4*>(dst + u * RPP * XROW) = q;
       }
     }
@@ -479,7 +485,8 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_ct_kernel(const FusedAr
   gemm_ct<NR, XROW, G::NCH, K, D>(acc, w1, voff, lds0 + (unsigned)(hi * XROW + (ncol0 + l31 - G::PAD2 - G::PAD1 - G::XOFF0)) * 4u);
   if (p.dbg) ts[2] = (long long)wall_clock64();
   // The x tile is now only needed for the residual: pull this wave's values into registers, then (after a barrier) the
-  // same LDS region is overwritten with lrelu(c1(.)) as c2's B operand.
+  // same LDS region is overwritten with lrelu(c1(.)) as c2's B operand.  (Re-reading x from global memory instead - 32 loads
+  // for 32 LDS reads + 64 vector instructions - is 4..8 % SLOWER: tools/rb_bench.py.)
   const float inv_slope = 1.0f / slope;
   float resv[NR][16];
 #pragma unroll
@@ -487,9 +494,12 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_ct_kernel(const FusedAr
     const int cidx = min(ncol0 + nr * 32 + l31 - G::XOFF0, XROW - 1);
     const float* rbase = XT + (mt * 32 + 4 * hi) * XROW + cidx;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = rbase[((r & 3) + 8 * (r >> 2)) * XROW];
-      resv[nr][r] = fminf(v, v * inv_slope);               // x from lrelu(x) (see the generic kernel)
+    for (int r = 0; r < 16; r += 2) {
+      float v0 = rbase[((r & 3) + 8 * (r >> 2)) * XROW], v1 = rbase[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * XROW];
+      const rb_f32x2 m = (rb_f32x2){v0, v1} * (rb_f32x2){inv_slope, inv_slope};      // x from lrelu(x): min(v, v / slope)
+      asm("v_min_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "v"(m.x));
+      asm("v_min_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "v"(m.y));
+      resv[nr][r] = v0; resv[nr][r + 1] = v1;
     }
   }
   __syncthreads();
@@ -500,9 +510,11 @@ __global__ void __launch_bounds__(256, 2) resblock_fused_ct_kernel(const FusedAr
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[nr][r];
-          ybase[((r & 3) + 8 * (r >> 2)) * YROW + nr * 32] = fmaxf(v, v * slope);
+        for (int r = 0; r < 16; r += 2) {
+          float v0 = acc[nr][r], v1 = acc[nr][r + 1];
+          rb_lrelu2(v0, v1, slope);
+          ybase[((r & 3) + 8 * (r >> 2)) * YROW + nr * 32] = v0;
+          ybase[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * YROW + nr * 32] = v1;
         }
     } else {
 #pragma unroll
