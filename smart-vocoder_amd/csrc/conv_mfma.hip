@@ -36,7 +36,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr unsigned F_VECST = 1u << 16;   // internal: float4 stores legal for EPI_UPS
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float pick4(const float4& v, int s) {
   return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
@@ -480,7 +479,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
               vA += gaddb[(long long)chn * p.gadd_ld + (long long)col * p.gadd_ts];
               vB += gaddb[(long long)(H + chn) * p.gadd_ld + (long long)col * p.gadd_ts];
             }
-            o.y[yo] = tanhf(vA) * sigmoidf_(vB);
+            o.y[yo] = gate_tanh_sigmoid(vA, vB);
           } else if (p.mode == EPI_MAG) {
             o.y[yo] = sqrtf(vA * vA + vB * vB + p.mag_eps);
           } else if (p.mode == EPI_PROJ) {

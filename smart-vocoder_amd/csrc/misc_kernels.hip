@@ -151,7 +151,7 @@ __global__ void gate_kernel(const float* __restrict__ a, const float* __restrict
   const long long b = i / (T * H);
   const long long ia = (b * 2 * H + c) * T + t, ib = (b * 2 * H + H + c) * T + t;
   const float u = a[ia] + g[ia], v = a[ib] + g[ib];
-  y[i] = tanhf(u) * (1.0f / (1.0f + expf(-v)));
+  y[i] = gate_tanh_sigmoid(u, v);
 }
 int k_gate(hipStream_t st, const float* a, const float* b, float* y, int B, int H, int T) {
   const long long total = (long long)B * H * T;

@@ -138,6 +138,15 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st);
 // contiguous range [start(c), start(c+1)): neighbours are issued back to back on the same L2.  Bijective for any
 // total.  on = 0 keeps the natural order (SVOC_XCD=0, for A/B runs).
 #if defined(__HIPCC__)
+// Gate of a WN layer (reference commons.py:100-107): tanh(a) * sigmoid(b) from the hardware exp2 / rcp (1 ulp each) - 9
+// instructions where tanhf + expf + an IEEE division take ~60, and the gate runs on eight accumulator registers per lane
+// and layer between two MFMA phases.  tanh(a) = 1 - 2 / (1 + e^{2a}): absolute error <= ~2e-7, saturates correctly.
+__device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
+  const float ea = __builtin_amdgcn_exp2f(a * 2.885390082f);      // e^{2a}
+  const float eb = __builtin_amdgcn_exp2f(b * -1.442695041f);     // e^{-b}
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + ea);
+  return t * __builtin_amdgcn_rcpf(1.0f + eb);
+}
 __device__ __forceinline__ int xcd_linear(int lin, int total, int on) {
   if (!on) return lin;
   const int c = lin & 7, i = lin >> 3;

@@ -33,7 +33,6 @@ struct WnArgs {
 };
 
 __device__ __forceinline__ float wn_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
-__device__ __forceinline__ float wn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // acc[2][NR] += W[two 32-row tiles][K] * B with B fragments from an LDS tile ([channels][row_len]); NT2 = number of
 // row tiles actually used (1 on the last layer's res_skip).
@@ -190,7 +189,7 @@ __global__ void __launch_bounds__(512) wn_layer_fused_kernel(const WnArgs p) {
           vA += gb[(long long)chn * p.gadd_ld + (long long)t * p.gadd_ts];
           vB += gb[(long long)(H + chn) * p.gadd_ld + (long long)t * p.gadd_ts];
         }
-        AT[chn * p.arow + m] = tanhf(vA) * wn_sigmoid(vB);
+        AT[chn * p.arow + m] = gate_tanh_sigmoid(vA, vB);
       }
     }
   }
@@ -361,7 +360,7 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
         vA += gb[(long long)chn * p.gadd_ld + (long long)t * p.gadd_ts];
         vB += gb[(long long)(H + chn) * p.gadd_ld + (long long)t * p.gadd_ts];
       }
-      AT[chn * p.arow + m] = tanhf(vA) * wn_sigmoid(vB);
+      AT[chn * p.arow + m] = gate_tanh_sigmoid(vA, vB);
     }
   }
   // ---- phase B: res_skip 1x1 on the acts tile; tile pi = x part, tile npairs + pi = skip part (last layer: tile pi only)
