@@ -437,6 +437,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
               if (n + 2 >= 0 && n + 2 < p.Lout) yp[2] = v.z;
               if (n + 3 >= 0 && n + 3 < p.Lout) yp[3] = v.w;
             }
+          } else if (s == 2 && row0 + 3 < o.nrows) {   // the four rows are two consecutive samples of two channels
+            const int oc = row0 >> 1;
+            const int n = col * 2 - p.ups_pad;
+            float* yp = yb + (long long)oc * o.y_ld + n;
+            if (n >= 0 && n + 1 < p.Lout) {
+              yp[0] = acc[mr][nr][4 * q + 0]; yp[1] = acc[mr][nr][4 * q + 1];
+              yp[o.y_ld] = acc[mr][nr][4 * q + 2]; yp[o.y_ld + 1] = acc[mr][nr][4 * q + 3];
+            } else {
+              if (n >= 0 && n < p.Lout) { yp[0] = acc[mr][nr][4 * q + 0]; yp[o.y_ld] = acc[mr][nr][4 * q + 2]; }
+              if (n + 1 >= 0 && n + 1 < p.Lout) { yp[1] = acc[mr][nr][4 * q + 1]; yp[o.y_ld + 1] = acc[mr][nr][4 * q + 3]; }
+            }
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
