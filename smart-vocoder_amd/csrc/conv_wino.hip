@@ -1,24 +1,25 @@
-// Winograd F(2,3) implicit-GEMM convolution for the decoder's big undilated convolutions
-// (reference modules.py:190-207: convs2 and the d = 1 member of convs1, C = 128 / 256, k = 3 / 7 / 11).
+// Winograd F(2,3) implicit-GEMM convolution for the ResBlock convolutions of the decoder's C >= 64 stages
+// (reference modules.py:190-207: convs1 with dilation 1 / 3 / 5 and convs2, k = 3 / 7 / 11).
 //
 // The fp32 matrix pipe is the roofline of this path (157.3 TFLOP/s, no TF32 on gfx950) and the direct kernels sit at
 // 82 % of it, so the remaining lever is to issue fewer MFMAs.  A k-tap convolution is split into groups of three taps
 // at tap offsets 0, 4, 8 (k = 3: one group; 7: two + tap 3; 11: three + taps 3 and 7).  Each group is a minimal
 // F(2,3) filtering: two outputs y[2q], y[2q+1] from the four inputs d_j = x[2q - pad + 4g + j] with four products
 // instead of six,
-//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3          (input transform, additions only)
+//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3' = d3 - d1         (input transform, additions only)
 //     U0 = w0        U1 = (w0+w1+w2)/2   U2 = (w0-w1+w2)/2   U3 = w2    (weight transform, at load time)
-//     y[2q] = M0 + M1 + M2     y[2q+1] = M1 - M2 - M3      M_p = sum_c U_p[c] * V_p[c]
+//     y[2q] = M0 + M1 + M2     y[2q+1] = M1 - M2 + M3'     M_p = sum_c U_p[c] * V_p[c]
 // Because the tap offsets of the groups are multiples of four and pad is odd, every group reads the SAME transformed
 // planes V_p[c][q'] (q' = q + 2g), so all groups accumulate into one set of four transform-domain accumulators; the
 // channel reduction M_p is the GEMM the MFMAs do.  The left-over taps (3, 7) are ordinary taps on the de-interleaved
-// planes E[q] = x[2q], O[q] = x[2q+1] with two more accumulators (their tap offset minus pad is even, so y[2q] reads
-// only E and y[2q+1] only O).  MFMAs per output and channel pair: k=3: 2 (direct 3), k=7: 5 (7), k=11: 8 (11).
+// planes E[q] = x[2q], O[q] = x[2q+1] (their tap offset minus pad is even, so y[2q] reads only E and y[2q+1] only O);
+// they accumulate into M0 (part of y[2q] only) and M3' (part of y[2q+1] only), the bias starts in M1.
+// MFMAs per output and channel pair: k=3: 2 (direct 3), k=7: 5 (7), k=11: 8 (11).
 // fp32 throughout; the additions of the transforms round once more than the direct form (measured <= 1e-6 relative).
 //
-// One workgroup = 4 waves = 64 rows x 64 q (128 output columns); a wave owns 32 rows x 32 q: four M tiles + two
-// direct tiles (96 accumulator registers).  Per 32-channel chunk: raw tile (leaky-relu'd, zero padded) -> LDS ->
-// transform pass -> six planes in LDS -> 16 * (4 G + 2 ND) MFMAs per wave with fragment reads at immediate offsets.
+// One workgroup = 4 waves = 128 rows x 32 pairs (C >= 128) or 64 rows x 64 pairs; a wave owns 32 rows x 32 pairs = four
+// accumulator tiles.  Per 32-channel chunk: raw tile (leaky-relu'd, zero padded) -> LDS -> transform pass -> six planes
+// in LDS -> 16 * (4 G + 2 ND) MFMAs per wave with fragment reads at immediate offsets.
 #include "svoc_internal.h"
 
 #include <algorithm>
