@@ -93,12 +93,15 @@ def test_conv1d(M, C, k, d, L, B, res):
                                                (256, 256, 11, 1, 516, 2, True), (64, 96, 7, 1, 260, 2, False), (256, 256, 3, 1, 128, 1, True),
                                                (128, 128, 11, 1, 12, 1, True), (128, 128, 3, 3, 1000, 2, True), (128, 128, 7, 3, 4096, 1, True),
                                                (128, 128, 11, 3, 756, 2, True), (256, 256, 3, 5, 1204, 1, False), (128, 128, 7, 5, 4100, 2, True),
-                                               (128, 128, 11, 5, 2400, 2, True), (64, 96, 11, 5, 40, 1, False), (128, 128, 11, 3, 8, 1, True)])
+                                               (128, 128, 11, 5, 2400, 2, True), (64, 96, 11, 5, 40, 1, False), (128, 128, 11, 3, 8, 1, True),
+                                               (64, 64, 11, 5, 1000, 2, True), (64, 64, 7, 3, 700, 1, True), (64, 64, 3, 1, 332, 2, True),
+                                               (128, 128, 7, 1, 1004, 1, True), (64, 64, 11, 1, 2048, 1, False)])
 def test_conv1d_winograd(M, C, co, k, d, L, B, res):
     """lrelu -> Conv1d(k, dilation d) [+ residual] in Winograd F(2,3) form (conv_wino.hip: three-tap groups at tap offsets
     0/4/8 on shared transformed planes + direct taps 3/7 on de-interleaved planes; dilation through the polyphase pairing
     (n, n + d)) against torch's direct convolution: every (k, d) of the model, ragged last tiles (L not a multiple of the
-    128/126/120-column tiles), inputs shorter than the halo, odd row-block counts (Cout = 96)."""
+    128/126/120-column tiles), inputs shorter than the halo, odd row-block counts (Cout = 96), lanes whose second
+    output falls beyond the end (dilated tiles), the 64-pair tiles of C = 64 incl. the k = 11 / d = 5 variant that stores E / O with its own geometry."""
     import ctypes
     seed = 300 + C + 7 * k + L + 1000 * d
     v = T(cases.rnd(seed, "v", (co, C, k), 1.0 / np.sqrt(C * k)))
