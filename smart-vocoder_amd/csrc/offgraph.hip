@@ -6,6 +6,7 @@
 #include "svoc_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace svoc {
@@ -99,6 +100,132 @@ __global__ void __launch_bounds__(256) dds_ln_gelu_kernel(const float* __restric
   }
 }
 
+// ---- vectorised form of the three modes (rows 16-byte aligned, C <= 256): a block owns 64 time steps x all C channels;
+// thread (tq, cg) = (tid & 15, tid >> 4) holds the float4 of time steps t0 + 4 tq .. + 3 for channels cg, cg + 16, ... in
+// REGISTERS between the passes (twelve independent 16-byte loads in flight per thread at C = 192), so the only LDS traffic
+// is the 16-way channel reduction of the LayerNorm sums - and, for MODE 0, the dilated receptive field: (x * mask) with its
+// halo [t0 - pad, t0 + 64 + pad) is staged through LDS once with coalesced 16-byte row reads and every tap of the depthwise
+// convolution is an LDS read.  Measured at [16,192,4096] (tools/offgraph_bench.py): see profiles/r02_offgraph_kernels.txt.
+template <int MODE>
+__global__ void __launch_bounds__(256) dds_ln_v2_kernel(const float* __restrict__ src, long long s_bs, int s_ld,
+                                                        const float* __restrict__ mask, long long mask_bs,
+                                                        const float* __restrict__ dw_w, const float* __restrict__ dw_b, int K, int dil,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ dst, long long d_bs, int d_ld, int C, int T, int last) {
+  constexpr int TT = 64, MAXI = 16;
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  float4* red = reinterpret_cast<float4*>(tile);           // [2][16 cg][16 tq]
+  float* xt = tile + 2 * 256 * 4;                          // MODE 0: [C][XW] x * mask with halo
+  const int tid = threadIdx.x;
+  const int tq = tid & 15, cg = tid >> 4;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const int t4 = t0 + 4 * tq;
+  const bool tv = t4 < T;
+  const float* sb = src + (long long)b * s_bs;
+  const float* mb = MODE == 2 ? nullptr : mask + (long long)b * mask_bs;
+  const int ni = (C - cg + 15) >> 4;
+  float4 vals[MAXI];
+  if constexpr (MODE == 0) {
+    const int pad = (K * dil - dil) / 2, pad4 = (pad + 3) & ~3;
+    const int XW = TT + 2 * pad4, XQ = XW >> 2;
+    for (int idx = tid; idx < C * XQ; idx += 256) {        // 16-byte groups, rows contiguous in time
+      const int c = idx / XQ, q = idx - c * XQ;
+      const int t = t0 - pad4 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* row = sb + (long long)c * s_ld;
+      if (t >= 0 && t + 3 < T) {
+        v = *reinterpret_cast<const float4*>(row + t);
+        v.x *= mb[t]; v.y *= mb[t + 1]; v.z *= mb[t + 2]; v.w *= mb[t + 3];
+      } else {
+        if (t >= 0 && t < T) v.x = row[t] * mb[t];
+        if (t + 1 >= 0 && t + 1 < T) v.y = row[t + 1] * mb[t + 1];
+        if (t + 2 >= 0 && t + 2 < T) v.z = row[t + 2] * mb[t + 2];
+        if (t + 3 >= 0 && t + 3 < T) v.w = row[t + 3] * mb[t + 3];
+      }
+      *reinterpret_cast<float4*>(xt + (size_t)c * XW + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      if (i < ni) {
+        const int c = cg + 16 * i;
+        const float bv = dw_b[c];
+        float4 v = make_float4(bv, bv, bv, bv);
+        const float* xr = xt + (size_t)c * XW + pad4 - pad + 4 * tq;
+        for (int j = 0; j < K; ++j) {
+          const float w = dw_w[c * K + j];
+          const float* xp = xr + j * dil;
+          v.x = fmaf(w, xp[0], v.x); v.y = fmaf(w, xp[1], v.y); v.z = fmaf(w, xp[2], v.z); v.w = fmaf(w, xp[3], v.w);
+        }
+        vals[i] = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (i < ni) vals[i] = tv ? *reinterpret_cast<const float4*>(sb + (long long)(cg + 16 * i) * s_ld + t4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // LayerNorm over channels: per-thread partial sums over its channels, 16-way combine through LDS (fixed order)
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+    if (i < ni) { s1.x += vals[i].x; s1.y += vals[i].y; s1.z += vals[i].z; s1.w += vals[i].w; }
+  red[cg * 16 + tq] = s1;
+  __syncthreads();
+  float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const float4 r = red[q * 16 + tq]; mean.x += r.x; mean.y += r.y; mean.z += r.z; mean.w += r.w; }
+  const float invC = 1.0f / (float)C;
+  mean.x *= invC; mean.y *= invC; mean.z *= invC; mean.w *= invC;
+  float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+    if (i < ni) {
+      const float dx = vals[i].x - mean.x, dy = vals[i].y - mean.y, dz = vals[i].z - mean.z, dw = vals[i].w - mean.w;
+      s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+    }
+  red[256 + cg * 16 + tq] = s2;
+  __syncthreads();
+  float4 var = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const float4 r = red[256 + q * 16 + tq]; var.x += r.x; var.y += r.y; var.z += r.z; var.w += r.w; }
+  const float4 rstd = make_float4(1.0f / sqrtf(var.x * invC + eps), 1.0f / sqrtf(var.y * invC + eps), 1.0f / sqrtf(var.z * invC + eps),
+                                  1.0f / sqrtf(var.w * invC + eps));
+  if (!tv) return;
+  float* db = dst + (long long)b * d_bs;
+  float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (MODE == 1 && last) {
+    mk.x = mb[t4];
+    mk.y = t4 + 1 < T ? mb[t4 + 1] : 0.f; mk.z = t4 + 2 < T ? mb[t4 + 2] : 0.f; mk.w = t4 + 3 < T ? mb[t4 + 3] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    if (i < ni) {
+      const int c = cg + 16 * i;
+      const float ga = gamma[c], be = beta[c];
+      float4 o;
+      o.x = (vals[i].x - mean.x) * rstd.x * ga + be; o.y = (vals[i].y - mean.y) * rstd.y * ga + be;
+      o.z = (vals[i].z - mean.z) * rstd.z * ga + be; o.w = (vals[i].w - mean.w) * rstd.w * ga + be;
+      if (MODE != 2) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
+      float4* dp = reinterpret_cast<float4*>(db + (long long)c * d_ld + t4);
+      if (MODE == 1) {
+        const float4 r = *dp;
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        if (last) { o.x *= mk.x; o.y *= mk.y; o.z *= mk.z; o.w *= mk.w; }
+      }
+      *dp = o;
+    }
+  }
+}
+// eligibility of the vectorised kernels: 16-byte aligned rows with room for whole float4 groups, at most 256 channels
+static bool ln_v2_ok(const void* src, long long s_bs, int s_ld, const void* dst, long long d_bs, int d_ld, int C, int T) {
+  static const bool on = !(getenv("SVOC_LN_V2") && atoi(getenv("SVOC_LN_V2")) == 0);
+  const int T4 = (T + 3) & ~3;
+  return on && C <= 256 && s_ld >= T4 && d_ld >= T4 && (s_ld & 3) == 0 && (d_ld & 3) == 0 && (s_bs & 3) == 0 && (d_bs & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+}
+
 // dst = a (+ g): a [B][rows][a_ld] strided, g NULL or [B][rows][g_T] contiguous with g_T == T or 1 (broadcast over time,
 // the speaker-embedding case of DDSConv's `x = x + g`, modules.py:97-98)
 __global__ void add2d_kernel(const float* __restrict__ a, long long a_bs, int a_ld, const float* __restrict__ g, int g_T,
@@ -175,16 +302,34 @@ struct DDS {
       const float* dw_w = P; const float* dw_b = dw_w + (size_t)C * K;
       const float* g1 = dw_b + C; const float* b1 = g1 + C; const float* g2 = b1 + C; const float* b2 = g2 + C;
       dim3 grid((T + TT - 1) / TT, B);
-      hipLaunchKernelGGL(dds_ln_gelu_kernel<0>, grid, dim3(256), lds, st, xw, per, Tp, mask, mask_bs, dw_w, dw_b, K, d, g1, b1, 1e-5f,
-                         y1, per, Tp, C, T, TT, 0);
+      const bool v2 = ln_v2_ok(xw, per, Tp, y1, per, Tp, C, T);
+      if (v2) {   // depthwise conv (halo staged through LDS) + LayerNorm + GELU, values in registers
+        const int pad4 = (((K * d - d) / 2) + 3) & ~3;
+        const size_t lds0 = ((size_t)2 * 256 * 4 + (size_t)C * (64 + 2 * pad4)) * sizeof(float);
+        if (lds0 <= 160 * 1024) {
+          SVOC_TRY(ensure_max_dyn_lds((const void*)dds_ln_v2_kernel<0>));
+          hipLaunchKernelGGL(dds_ln_v2_kernel<0>, dim3((T + 63) / 64, B), dim3(256), lds0, st, xw, per, Tp, mask, mask_bs, dw_w, dw_b, K, d, g1, b1,
+                             1e-5f, y1, per, Tp, C, T, 0);
+        } else {
+          hipLaunchKernelGGL(dds_ln_gelu_kernel<0>, grid, dim3(256), lds, st, xw, per, Tp, mask, mask_bs, dw_w, dw_b, K, d, g1, b1, 1e-5f,
+                             y1, per, Tp, C, T, TT, 0);
+        }
+      } else {
+        hipLaunchKernelGGL(dds_ln_gelu_kernel<0>, grid, dim3(256), lds, st, xw, per, Tp, mask, mask_bs, dw_w, dw_b, K, d, g1, b1, 1e-5f,
+                           y1, per, Tp, C, T, TT, 0);
+      }
       SVOC_HIP(hipGetLastError());
       stats_add_other();
       ConvArgs a = mk_args2();
       a.x = y1; a.x_bs = per; a.x_ld = Tp; a.Lin = T; a.Ncols = T;
       a.out[0].y = y2; a.out[0].y_bs = per; a.out[0].y_ld = Tp; a.out[0].nrows = C;
       SVOC_TRY(launch_conv(*c1x1[i], a, B, st));
-      hipLaunchKernelGGL(dds_ln_gelu_kernel<1>, grid, dim3(256), lds, st, y2, per, Tp, mask, mask_bs, nullptr, nullptr, K, d, g2, b2,
-                         1e-5f, xw, per, Tp, C, T, TT, i == NL - 1 ? 1 : 0);
+      if (v2)
+        hipLaunchKernelGGL(dds_ln_v2_kernel<1>, dim3((T + 63) / 64, B), dim3(256), (size_t)2 * 256 * 4 * sizeof(float), st, y2, per, Tp, mask, mask_bs,
+                           nullptr, nullptr, K, d, g2, b2, 1e-5f, xw, per, Tp, C, T, i == NL - 1 ? 1 : 0);
+      else
+        hipLaunchKernelGGL(dds_ln_gelu_kernel<1>, grid, dim3(256), lds, st, y2, per, Tp, mask, mask_bs, nullptr, nullptr, K, d, g2, b2,
+                           1e-5f, xw, per, Tp, C, T, TT, i == NL - 1 ? 1 : 0);
       SVOC_HIP(hipGetLastError());
       stats_add_other();
       d *= K;
@@ -449,8 +594,12 @@ int svoc_layer_norm(void* stream, const float* x, const float* gamma, const floa
   const size_t lds = ((size_t)C * TT + 512) * sizeof(float);
   if (lds > 64 * 1024) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "LayerNorm: %d channels do not fit the tile", C);
   const long long bs = (long long)C * T;
-  hipLaunchKernelGGL(dds_ln_gelu_kernel<2>, dim3((T + TT - 1) / TT, B), dim3(256), lds, as_stream(stream), x, bs, T, nullptr, 0,
-                     nullptr, nullptr, 1, 1, gamma, beta, eps, y, bs, T, C, T, TT, 0);
+  if ((T & 3) == 0 && ln_v2_ok(x, bs, T, y, bs, T, C, T))
+    hipLaunchKernelGGL(dds_ln_v2_kernel<2>, dim3((T + 63) / 64, B), dim3(256), (size_t)2 * 256 * 4 * sizeof(float), as_stream(stream), x, bs, T,
+                       nullptr, 0, nullptr, nullptr, 1, 1, gamma, beta, eps, y, bs, T, C, T, 0);
+  else
+    hipLaunchKernelGGL(dds_ln_gelu_kernel<2>, dim3((T + TT - 1) / TT, B), dim3(256), lds, as_stream(stream), x, bs, T, nullptr, 0,
+                       nullptr, nullptr, 1, 1, gamma, beta, eps, y, bs, T, C, T, TT, 0);
   SVOC_HIP(hipGetLastError());
   stats_add_other();
   return SVOC_OK;
