@@ -588,7 +588,17 @@ struct Generator {
         SVOC_TRY(launch_conv(*ups[i], a, B, st));
       }
       const long long bs = (long long)cho * ldo;
-      if (use_streams && mrf_grouped(i, cho)) {
+      // Short inputs: when the three chains' convolutions are too small for the grouped Winograd launches (fewer than two
+      // workgroups per CU in total) they would run one by one as K-split launches; the chains are independent until the
+      // final accumulate, so they go to the three chain streams instead and their latencies overlap.
+      bool small_stage = false;
+      {
+        static const bool on = !(getenv("SVOC_MRF_SMALL") && atoi(getenv("SVOC_MRF_SMALL")) == 0);
+        const int mtl = cho / 32, wm = (mtl >= 4 && mtl % 4 == 0) ? 4 : 2;
+        const long long tiles = (long long)cfg.n_kernels * B * ((Lo + (wm == 4 ? 63 : 127)) / (wm == 4 ? 64 : 128)) * ((mtl + wm - 1) / wm);
+        small_stage = on && tiles < 2LL * device_cu_count();
+      }
+      if (use_streams && !small_stage && mrf_grouped(i, cho)) {
         // MRF with the chains' step-i convolutions grouped into single launches (conv_group_kernel)
         SVOC_TRY(run_mrf_grouped(st, i, X, XS, bufs, bs, ldo, cho, B, Lo));
         r ^= 1;
