@@ -663,7 +663,8 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
     const long long nbk = (long long)((a.Ncols + 31) / 32) * ((mt + mrk - 1) / mrk) * B;
     const int groups = a.nchunks * pc.ktaps;             // per wave: groups of 4 k-steps
     // (measured: extending this to "fewer than two workgroups per CU" is neutral at 1 x 200 and 7 % slower at 4 x 512)
-    if (ks_on && best < (long long)ncu && nbk > best && groups >= 2 && a.mode != EPI_UPS && a.mode != EPI_MAG) {
+    static const int ks_pct = getenv("SVOC_KS_PCT") ? atoi(getenv("SVOC_KS_PCT")) : 100;      // diagnostics: threshold in % of the CU count
+    if (ks_on && best * 100 < (long long)ncu * ks_pct && nbk > best && groups >= 2 && a.mode != EPI_UPS && a.mode != EPI_MAG) {
       c = TileCfg{1, 1, mrk, 1, 1};
     }
   }
