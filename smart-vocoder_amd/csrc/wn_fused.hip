@@ -434,7 +434,8 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
 // group list as in conv_wino.hip - measured 73.8 us per layer against 72.1 us for this one: the layer is not bound by the
 // instructions around its MFMAs but by the serial phases of the ONE workgroup a CU holds: staging, two exchanges, gate,
 // epilogue and the launch / drain between dependent layers add ~26 us to 46 us of matrix-pipe time.  What did help: the
-// gate from hardware exp2 / rcp (79 -> 72 us).)
+// gate from hardware exp2 / rcp (79 -> 72 us).  Requesting the first weight group of each GEMM, the res_skip bias and the
+// epilogue's operands (residual / skip accumulator / mask) ahead of the phases that precede their use: 72 -> 76 us, dropped.)
 // Returns 1 when the fused layer does not apply (caller runs in_layer and res_skip as two convolutions).
 int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H, const float* x, long long x_bs, int x_ld,
                           float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs, int out_ld, const float* mask,
