@@ -60,6 +60,12 @@ def test_sequence_mask_and_gate_and_flip(M):
     a = T(cases.rnd(1, "a", (2, 128, 37), 2.0)); b = T(cases.rnd(1, "b", (2, 128, 37), 1.0))
     y = M.commons.fused_add_tanh_sigmoid_multiply(a.cuda(), b.cuda(), torch.IntTensor([64]))
     check("gate", y, O.gate(a, b, 64), 2e-6, 0)
+    # the gate uses the hardware exp2 / rcp: saturation, zeros and large arguments must stay finite and within 2e-6
+    ext = torch.tensor([-200.0, -90.0, -20.0, -1e-3, 0.0, 1e-3, 20.0, 90.0, 200.0])
+    a2 = ext.repeat(128, 1).reshape(1, 128, 9).contiguous(); b2 = torch.flip(a2, [2]).contiguous() * 0.5
+    y2 = M.commons.fused_add_tanh_sigmoid_multiply(a2.cuda(), b2.cuda(), torch.IntTensor([64]))
+    assert torch.isfinite(y2).all()
+    check("gate extremes", y2, O.gate(a2, b2, 64), 2e-6, 0)
     x = T(cases.rnd(2, "x", (2, 6, 11)))
     y, ld = M.modules.Flip()(x.cuda())
     assert torch.equal(y.cpu(), torch.flip(x, [1])) and float(ld.abs().sum()) == 0
