@@ -69,7 +69,7 @@ struct WinoGeo {
   // E[q], O[q] with q = q' - (PADT - 1) / 2.
   static constexpr int EO0 = S + (PADT - 1) / 2;          // E / O entry of q in the V geometry: (q + EO0) * D + phase
   static constexpr int NUV = D == 1 ? 2 * NT : (NQ + S) * D;
-  static constexpr int PQV = (NUV + 3) & ~3;              // plane row stride (floats)
+  static constexpr int PQV = D == 5 ? NUV : ((NUV + 3) & ~3);  // plane row stride (floats); D = 5: unpadded, so that three workgroups fit a CU (53.2 KB each)
   static constexpr int NPL = ND > 0 ? 6 : 4;
   static constexpr int VMAX = (2 * (NQ - 1) - PADT + 3) * D + D - 1;                     // last position a window reads (from n0)
   static constexpr int RAW0 = (VMAX + 1 - XOFF + 3) & ~3;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int bx, const
   // and whole waves skip it; the LDS tile is contiguous in g, the global side keeps one per-thread offset per pass.
   // Regular (2 x 2 tiles, five or six passes): thread (r0, g4) owns group g4 of rows r0, r0 + RPP, ...: one per-thread offset
   // and a uniform base / an immediate per pass, no per-pass registers (and no scalar masks to spill).
-  constexpr bool LINEAR = WM == 4;
+  constexpr bool LINEAR = WM == 4 && D < 5;                // D = 5: the per-pass registers would cost the third workgroup per CU
   constexpr int R4 = RAW / 4, NG = KC * R4, RPP = 256 / R4;
   constexpr int NPASS = LINEAR ? (NG + 255) / 256 : (KC + RPP - 1) / RPP;
   const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
