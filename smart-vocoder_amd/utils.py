@@ -167,6 +167,12 @@ def load_wav_to_torch(full_path):
     return torch.FloatTensor(data.astype(np.float32)), sampling_rate
 
 
+def load_filepaths(filename):
+    """One stripped line per entry of a file list (reference utils.py:138-141; used to enumerate the wavs / mels to synthesise)."""
+    with open(filename, encoding="utf-8") as f:
+        return [line.strip() for line in f]
+
+
 def save_wav(path, sampling_rate, audio):
     """The notebook's (commented-out) last line, ``write('./generated_files/'+f_name, 22050, audio_)`` (inference.ipynb
     cell 4), for tensors straight out of ``infer``: `audio` is [samples], [1, samples] or [1, 1, samples] (any device)
