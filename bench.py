@@ -105,7 +105,7 @@ def cpu_baseline(sd_np, seed):
 def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     """Per-launch duration of the dominant kernel, measured live with HIP events on the launch stream by the library's
     event profiler (every GEMM-family launch bracketed by hipEventRecord): the grouped launch of the C=128 stage's
-    three undilated convolutions k=11/7/3 (conv_wino_group_kernel<1>, Winograd F(2,3) form; conv_group_kernel when
+    three undilated convolutions k=11/7/3 (conv_wino_ws_group_kernel<1>, Winograd F(2,3) form; conv_group_kernel when
     SVOC_WINO=0).  Runs after the timed region."""
     from smart_vocoder_amd import _native
     _native.profile_enable(True)
@@ -285,7 +285,7 @@ def main():
         # single kernel with the largest share, per-launch, measured live after the timed region.
         res["roofline"] = {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino(_group)_kernel (Winograd F(2,3)), conv_mfma_kernel, conv_group_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino(_ws)(_group)_kernel (Winograd F(2,3)), conv_mfma_kernel, conv_group_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel",
                            "note": "achieved = algorithmic direct-form 2*MAC of the convolutions (SURVEY.md 8d) / time; the Winograd kernels execute 2/3 - 8/11 of them as MFMAs",
                            "gemm_launches_per_step": stats["conv_launches"] / args.steps,
                            "convolutions_per_step": stats["convolutions"] / args.steps,
@@ -298,7 +298,8 @@ def main():
             # MFMA peak; `mfma_pipe_frac` prices the multiply-adds the matrix pipe really executed
             executed = 15.0 / 21.0 if dom["wino"] else 1.0
             res["roofline"]["dominant_kernel"] = {
-                "name": ("conv_wino_group_kernel<1> " if dom["wino"] else "conv_group_kernel<2,2,2,2> ") + dom["desc"],
+                "name": (("conv_wino_group_kernel<1> " if os.environ.get("SVOC_WINO_WS") == "0" else "conv_wino_ws_group_kernel<1> ")
+                         if dom["wino"] else "conv_group_kernel<2,2,2,2> ") + dom["desc"],
                 "launches_measured": dom["n"], "avg_launch_us": dom["mean_us"],
                 "flop_per_launch": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6,
                 "achieved": dom["tflops"], "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
