@@ -547,7 +547,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup
 // by the consumers after consuming stage s - 1.  Workgroups are persistent (a stage = (tile, chunk); the producers run
 // ahead across tile boundaries), two per CU.  Measured against the kernel above in one run (C = 128, us): k=3 375 / 410,
 // k=7 743 / 750, k=11 1020 / 1031 (d = 3: 430 / 440, 794 / 810, 1125 / 1138); 16 x 512 step -0.1 .. -0.2 ms.  The matrix pipe is
-// ~86 % busy: the producers' ~100 vector / LDS instructions per stage still issue on the consumers' SIMDs.
+// ~86 % busy: the producers' ~100 vector / LDS instructions per stage still issue on the consumers' SIMDs.  (Handing stages over
+// through two LDS counters instead of the barrier - consumers then never wait for their siblings - measured no faster.)
 template <int K, int D>
 __device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
   constexpr int WM = 4;
