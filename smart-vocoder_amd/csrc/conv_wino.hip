@@ -547,8 +547,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup
 // by the consumers after consuming stage s - 1.  Workgroups are persistent (a stage = (tile, chunk); the producers run
 // ahead across tile boundaries), two per CU.  Measured against the kernel above in one run (C = 128, us): k=3 375 / 410,
 // k=7 743 / 750, k=11 1020 / 1031 (d = 3: 430 / 440, 794 / 810, 1125 / 1138); 16 x 512 step -0.1 .. -0.2 ms.  The matrix pipe is
-// ~86 % busy: the producers' ~100 vector / LDS instructions per stage still issue on the consumers' SIMDs.  (Handing stages over
-// through two LDS counters instead of the barrier - consumers then never wait for their siblings - measured no faster.)
+// ~86 % busy.  Timing with work removed (profiles/r02_winograd_ws_phase_removal.txt): idle producers buy 1-8 %, no epilogue 2-13 %,
+// and the bare consumer streams still reach only 70 / 79 / 89 % of the pipe (k = 3 / 7 / 11): 0.7-1.2 us per stage go at the stage
+// boundaries.  Handing stages over through two LDS counters instead of the barrier (consumers then never wait for their
+// siblings) and serving the per-tile bias from LDS instead of global memory both measured no faster.
 template <int K, int D>
 __device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
   constexpr int WM = 4;
