@@ -550,8 +550,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup
 // ~86 % busy.  Timing with work removed (profiles/r02_winograd_ws_phase_removal.txt): idle producers buy 1-8 %, no epilogue 2-13 %,
 // and the bare consumer streams still reach only 70 / 79 / 89 % of the pipe (k = 3 / 7 / 11): 0.7-1.2 us per stage go at the stage
 // boundaries.  Handing stages over through two LDS counters instead of the barrier (consumers then never wait for their
-// siblings) and serving the per-tile bias from LDS instead of global memory both measured no faster.
-template <int K, int D>
+// siblings) and serving the per-tile bias from LDS instead of global memory both measured no faster.  Per-workgroup stamps
+// (tools/wino_ws_timeline.py): the two workgroups of a CU finish 17 % apart (821 - 986 us at k = 11) although both have 16 tiles;
+// handing tiles out dynamically (device-wide counter) makes them finish together - at the LATE end (1011 us): the early one was
+// fast at the other's expense, the CU's throughput does not change (kernel 1052 against 1020 us).
+template <int K, int D, bool DBG = false>
 __device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
   constexpr int WM = 4;
   using Geo = WinoGeo<K, D, WM>;
@@ -801,6 +804,8 @@ __device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0,
     yo4[i] = (unsigned)((4 * hi + i) * p.y_ld + lpart) * 4u;
     ro4[i] = (unsigned)((4 * hi + i) * p.res_ld + lpart) * 4u;
   }
+  long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0;     // diagnostics (stamped build): consumer wave 0 of each workgroup
+  if constexpr (DBG) cyc_all0 = (long long)__builtin_readcyclecounter();
   for (int ti = 0; ti < my_tiles; ++ti) {
     int n0, bz, by;
     locate(v0 + ti * stride, n0, bz, by);
@@ -827,11 +832,15 @@ __device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0,
     }
     auto stage = [&](int ch, auto par) {
       const int s_ = ti * nch + ch;
+      long long c0 = 0, c1 = 0;
+      if constexpr (DBG) c0 = (long long)__builtin_readcyclecounter();
       __syncthreads();                                     // B_s: plane set s & 1 is complete, set (s - 1) & 1 may be overwritten
+      if constexpr (DBG) c1 = (long long)__builtin_readcyclecounter();
       const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
       const char* wa = wt + (size_t)ch * SLOTS * 4096;
       const char* wnext = ch + 1 < nch ? wa + (size_t)SLOTS * 4096 : wnext_tile;
       mfma_chunk(baddr0 + off, baddrE0 + off, wa, wnext, par);
+      if constexpr (DBG) { cyc_bar += c1 - c0; cyc_mf += (long long)__builtin_readcyclecounter() - c1; }
     };
     if constexpr ((SLOTS & 1) == 0) {
       for (int ch = 0; ch < nch; ++ch) stage(ch, std::integral_constant<int, 0>{});
@@ -842,6 +851,8 @@ __device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0,
       }
     }
     // ---- epilogue
+    long long ce0 = 0;
+    if constexpr (DBG) ce0 = (long long)__builtin_readcyclecounter();
     const int ne = n0 + lpart;
     if (row_ok && uu < PU && ne < L) {
       const bool odd_ok = ne + D < L;
@@ -906,12 +917,19 @@ __device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0,
       if (odd_ok) { finish(std::true_type{}, std::integral_constant<int, 0>{}); finish(std::true_type{}, std::integral_constant<int, 1>{}); }
       else { finish(std::false_type{}, std::integral_constant<int, 0>{}); finish(std::false_type{}, std::integral_constant<int, 1>{}); }
     }
+    if constexpr (DBG) cyc_epi += (long long)__builtin_readcyclecounter() - ce0;
+  }
+  if constexpr (DBG) if (tid == 0) {      // [workgroup][16]: 0 tiles, 1 total cycles, 2 barrier waits, 3 MFMA streams, 4 epilogues, 5 marker, 6 HW_ID, 7 XCC_ID
+    long long* d = p.dbg + 16 * (long long)(p.dbg_base + v0);
+    d[0] = my_tiles; d[1] = (long long)__builtin_readcyclecounter() - cyc_all0; d[2] = cyc_bar; d[3] = cyc_mf; d[4] = cyc_epi; d[5] = 2;
+    d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    d[7] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
   }
 }
 
-template <int K, int D>
+template <int K, int D, bool DBG>
 __global__ void __launch_bounds__(512, 4) conv_wino_ws_kernel(const WinoArgs p, const int total) {
-  wino_ws_problem<K, D>(p, blockIdx.x, total, 0, gridDim.x);
+  wino_ws_problem<K, D, DBG>(p, blockIdx.x, total, 0, gridDim.x);
 }
 template <int K, int D>
 __device__ __forceinline__ void wino_ws_member(const WinoArgs& p, const int first, const int vend, const int b, const int G_) {
@@ -1085,11 +1103,17 @@ template <int K, int D>
 static size_t wino_ws_lds() { return (size_t)(WinoGeo<K, D, 4>::RAW_FLOATS + 2 * WinoGeo<K, D, 4>::PL_FLOATS) * 4; }
 template <int K, int D>
 static int wino_ws_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
-  auto kern = conv_wino_ws_kernel<K, D>;
-  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const size_t lds = wino_ws_lds<K, D>();
   const unsigned grid = (unsigned)std::min<long long>(total, 2LL * device_cu_count());
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
+  if (w.dbg) {                                             // stamped build (tools/wino_ws_timeline.py)
+    auto kern = conv_wino_ws_kernel<K, D, true>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
+  } else {
+    auto kern = conv_wino_ws_kernel<K, D, false>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
+  }
   return SVOC_OK;
 }
 template <int D>
@@ -1119,7 +1143,7 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
-  if (wino_ws_on() && WM == 4 && dil <= 3 && !w.dbg && (pw.nchunks & 1) == 0) {
+  if (wino_ws_on() && WM == 4 && dil <= 3 && (pw.nchunks & 1) == 0) {
 #define SVOC_WS(KK, DD) if (pw.K == KK && dil == DD) rc = wino_ws_launch_one<KK, DD>(w, total, st);
     SVOC_WS(3, 1) SVOC_WS(7, 1) SVOC_WS(11, 1) SVOC_WS(3, 3) SVOC_WS(7, 3) SVOC_WS(11, 3)
 #undef SVOC_WS
