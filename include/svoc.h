@@ -72,6 +72,18 @@ const char* svoc_build_arch(void);       /* "gfx950" */
 int svoc_stats_reset(void);
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches);
 int64_t svoc_stats_convolutions(void);
+/* 2 x the multiply-adds the matrix pipe ISSUED for those launches: equal to conv_flops for direct-form kernels, 2/3 (k=3),
+ * 5/7 (k=7), 8/11 (k=11) of it for the Winograd F(2,3) kernels.  bench.py's roofline.frac_executed is this / time / peak. */
+double svoc_stats_executed_flops(void);
+
+/* Kernel variants (tile shape, K split, Winograd or direct form, fused or unfused WN layer, MRF launch plan) are chosen
+ * from the launch size, and variants differ in summation order: by default one utterance alone and the same utterance
+ * inside a batch agree to fp32 rounding (<= 2e-6), not bit for bit.  svoc_set_variant_batch(n) makes every such choice
+ * as if the batch held n utterances (n <= 0: the real batch, the default; env SVOC_VARIANT_BATCH presets it).  A rank
+ * that runs a B/G-utterance shard with n = B produces exactly the bits of a single process running all B (SURVEY.md
+ * 8e "8-GPU output == 1-GPU output bitwise"); used by parallel.infer_sharded(bitwise=True).  Process-global; returns the
+ * previous value.  Replaces nothing in the reference (it has one code path per op: torch's). */
+int svoc_set_variant_batch(int n);
 
 /* Diagnostics: bracket every convolution launch with HIP events and aggregate by layer shape. */
 int svoc_profile_enable(int on);
@@ -179,6 +191,11 @@ int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T);
  * SVOC_GRAPH_MAX_FRAMES) are replayed from a hipGraph captured on their second call (SVOC_GRAPH=0 disables). */
 int svoc_synth_reserve(svoc_synth* h, int B, int T);
 int svoc_synth_hop(svoc_synth* h);         /* prod(upsample_rates) */
+/* Captured-plan bookkeeping of a handle: out5 = {live plans, captures so far, plans evicted, evictions that had to wait
+ * (hipEventSynchronize on the evicted plan's own completion event), plans retired but still executing}.  A shape earns
+ * a plan on its SVOC_GRAPH_MIN_SEEN-th call (default 2; first sights only bump a counter); at most 32 plans live, the
+ * least recently used makes room, and eviction never synchronises the device nor frees device memory. */
+int svoc_synth_plan_stats(svoc_synth* h, int64_t* out5);
 void svoc_synth_destroy(svoc_synth* h);
 
 /* ---- models.PosteriorEncoder (models.py:83-112): not on the infer path; enc_q of training / voice conversion ---- */

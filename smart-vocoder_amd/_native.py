@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVOC_LIB selects another build of the same library (A/B comparisons of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("SVOC_LIB") or os.path.join(_HERE, "csrc", "libsvoc_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
@@ -52,6 +52,8 @@ SIGNATURES = {
     "svoc_stats_reset": (_I, []),
     "svoc_stats_get": (_I, [C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(_L)]),
     "svoc_stats_convolutions": (_L, []),
+    "svoc_stats_executed_flops": (C.c_double, []),
+    "svoc_set_variant_batch": (_I, [_I]),
     "svoc_profile_enable": (_I, [_I]),
     "svoc_profile_report": (_I, [C.c_char_p, _I]),
     "svoc_debug_set_stamp_buffer": (_I, [_P]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     "svoc_synth_workspace_bytes": (_L, [_P, _I, _I]),
     "svoc_synth_reserve": (_I, [_P, _I, _I]),
     "svoc_synth_hop": (_I, [_P]),
+    "svoc_synth_plan_stats": (_I, [_P, C.POINTER(_L)]),
     "svoc_synth_destroy": (None, [_P]),
     "svoc_posterior_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _I, _I, *_TAB, C.c_char_p]),
     "svoc_posterior_forward": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I]),
@@ -210,7 +213,29 @@ def stats_reset():
 def stats_get():
     a, b, c = _L(0), C.c_double(0), _L(0)
     lib().svoc_stats_get(C.byref(a), C.byref(b), C.byref(c))
-    return dict(conv_launches=a.value, conv_flops=b.value, other_launches=c.value, convolutions=lib().svoc_stats_convolutions())
+    return dict(conv_launches=a.value, conv_flops=b.value, other_launches=c.value, convolutions=lib().svoc_stats_convolutions(),
+                executed_flops=lib().svoc_stats_executed_flops())
+
+
+def set_variant_batch(n):
+    """Kernel variants are chosen as if the batch held `n` utterances (0: the real batch); returns the previous value.
+    See include/svoc.h svoc_set_variant_batch."""
+    return lib().svoc_set_variant_batch(int(n))
+
+
+class variant_batch:
+    """``with variant_batch(n): ...`` - scoped svoc_set_variant_batch."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = set_variant_batch(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        set_variant_batch(self.prev)
+        return False
 
 
 def profile_enable(on=True):

@@ -567,7 +567,6 @@ __global__ void __launch_bounds__(WM* WN * 64, (MR * NR >= 8 ? 2 : 3)) conv_grou
 namespace {
 
 struct TileCfg { int WM, WN, MR, NR; int ks = 0; };
-constexpr TileCfg CFG_A{4, 1, 2, 4};   // 256 rows x 128 cols
 constexpr TileCfg CFG_B{2, 2, 2, 2};   // 128 x 128
 constexpr TileCfg CFG_C{2, 2, 1, 4};   //  64 x 256
 constexpr TileCfg CFG_D2{1, 4, 1, 2};  //  32 x 256
@@ -634,14 +633,13 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
   // overlapped with other tiles (small batches / short utterances).
   const int mt = pc.mtiles;
   const int ncu = device_cu_count();
+  const int Bv = variant_batch(B);                       // the batch the variant is chosen for (svoc_set_variant_batch)
   TileCfg cand[6];
   int ncand = 0;
   if (needs_pair) { cand[ncand++] = CFG_B; cand[ncand++] = CFG_E; }
   else {
-    // the 256x128 tile (8 accumulator tiles per wave, occupancy 2, register spills) measured slower than two
-    // 128x128 row-blocks for every C=256 layer (profiles/r01_c_*), so it is opt-in only
-    static const bool use_a = getenv("SVOC_TILE_256") && atoi(getenv("SVOC_TILE_256")) != 0;
-    if (mt % 8 == 0 && use_a) cand[ncand++] = CFG_A;
+    // (a 256x128 tile - 8 accumulator tiles per wave, occupancy 2, register spills - measured slower than two 128x128
+    // row blocks for every C=256 layer, profiles/r01_c_*; removed in round 3)
     if (mt % 4 == 0) cand[ncand++] = CFG_B;
     if (mt % 2 == 0) cand[ncand++] = CFG_C;
     if (mt % 2 != 0) cand[ncand++] = CFG_D2;
@@ -652,7 +650,7 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
   long long best = -1;
   for (int i = 0; i < ncand; ++i) {
     const int bn = cand[i].WN * cand[i].NR * 32, bm = cand[i].WM * cand[i].MR;
-    const long long nb = (long long)((a.Ncols + bn - 1) / bn) * ((mt + bm - 1) / bm) * B;
+    const long long nb = (long long)((a.Ncols + bn - 1) / bn) * ((mt + bm - 1) / bm) * Bv;
     if (nb >= ncu) { c = cand[i]; best = nb; break; }
     if (nb > best) { c = cand[i]; best = nb; }
   }
@@ -660,11 +658,10 @@ int prepare_conv(const PackedConv& pc, ConvArgs& a, int B, TileCfg& c) {
   {   // short inputs: when even the smallest tile leaves most CUs without a workgroup, split K over the four waves
     static const bool ks_on = !(getenv("SVOC_KSPLIT") && atoi(getenv("SVOC_KSPLIT")) == 0);
     const int mrk = needs_pair ? 2 : 1;
-    const long long nbk = (long long)((a.Ncols + 31) / 32) * ((mt + mrk - 1) / mrk) * B;
+    const long long nbk = (long long)((a.Ncols + 31) / 32) * ((mt + mrk - 1) / mrk) * Bv;
     const int groups = a.nchunks * pc.ktaps;             // per wave: groups of 4 k-steps
     // (measured: extending this to "fewer than two workgroups per CU" is neutral at 1 x 200 and 7 % slower at 4 x 512)
-    static const int ks_pct = getenv("SVOC_KS_PCT") ? atoi(getenv("SVOC_KS_PCT")) : 100;      // diagnostics: threshold in % of the CU count
-    if (ks_on && best * 100 < (long long)ncu * ks_pct && nbk > best && groups >= 2 && a.mode != EPI_UPS && a.mode != EPI_MAG) {
+    if (ks_on && best < (long long)ncu && nbk > best && groups >= 2 && a.mode != EPI_UPS && a.mode != EPI_MAG) {
       c = TileCfg{1, 1, mrk, 1, 1};
     }
   }
@@ -705,7 +702,6 @@ int launch_conv(const PackedConv& pc, ConvArgs a, int B, hipStream_t st) {
 
   if (c.ks) return c.MR == 2 ? launch_ks<2>(a, B, st) : launch_ks<1>(a, B, st);
 #define SVOC_LAUNCH(C) if (c.WM == C.WM && c.WN == C.WN && c.MR == C.MR && c.NR == C.NR) return launch_cfg<C.WM, C.WN, C.MR, C.NR>(a, B, st)
-  SVOC_LAUNCH(CFG_A);
   SVOC_LAUNCH(CFG_B);
   SVOC_LAUNCH(CFG_C);
   SVOC_LAUNCH(CFG_D2);

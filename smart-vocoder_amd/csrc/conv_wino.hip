@@ -1126,6 +1126,10 @@ static int wino_ws_launch_group(const WinoGroup& g, long long total, hipStream_t
   return SVOC_OK;
 }
 
+// share of the direct form's multiply-adds that the F(2,3) grouping issues: two products per output and three-tap group plus
+// one per left-over tap (k=3: 2/3, k=7: 5/7, k=11: 8/11); tile padding is not counted
+static double wino_exec_ratio(int K) { const int G = (K + 1) / 4; return (2.0 * G + (G - 1)) / (double)K; }
+
 // 1 = not eligible (caller uses the direct kernel)
 int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles) {
   WinoArgs w;
@@ -1133,9 +1137,9 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
   if (B <= 0 || !wino_args(pw, a, B, dil, WM, w)) return 1;
   const long long total = (long long)w.ntn * w.gy * B;
   if (min_tiles < 0) min_tiles = 2LL * device_cu_count();
-  if (total < min_tiles || total > 0x7fffffffLL) return 1;    // short inputs: the direct / K-split kernels
+  if ((long long)w.ntn * w.gy * variant_batch(B) < min_tiles || total > 0x7fffffffLL) return 1;    // short inputs: the direct / K-split kernels
   const double flops = pw.flops_per_col * (double)B * (double)a.Ncols;
-  stats_add_conv(flops);
+  stats_add_conv(flops, 1, flops * wino_exec_ratio(pw.K));
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
@@ -1165,7 +1169,7 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   if (n < 2 || n > 3 || B <= 0) return 1;
   WinoGroup g{};
   long long total = 0;
-  double flops = 0;
+  double flops = 0, exec_flops = 0;
   size_t lds = 0;
   const int WM = wino_wm(*pws[0]);
   for (int i = 0; i < n; ++i) {
@@ -1175,15 +1179,16 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     g.end[i] = (int)total;
     g.k[i] = pws[i]->K;
     flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
+    exec_flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino_exec_ratio(pws[i]->K);
     const int K = pws[i]->K;
     size_t l = 0;
     if (WM == 4) l = dil == 1 ? wino_lds<1, 4>(K) : (dil == 3 ? wino_lds<3, 4>(K) : wino_lds<5, 4>(K));
     else l = dil == 1 ? wino_lds<1, 2>(K) : (dil == 3 ? wino_lds<3, 2>(K) : wino_lds<5, 2>(K));
     lds = std::max(lds, l);
   }
-  if (total < 2LL * device_cu_count()) return 1;
+  if (total / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
   for (int i = n; i < 3; ++i) { g.end[i] = 0x7fffffff; g.k[i] = 3; }
-  stats_add_conv(flops, n);
+  stats_add_conv(flops, n, exec_flops);
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];

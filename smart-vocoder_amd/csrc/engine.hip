@@ -26,12 +26,9 @@ static void set_out(EpiOut& o, float* y, long long bs, int ld, int nrows, unsign
 }
 static void set_res(EpiOut& o, const float* r, long long bs, int ld) { o.res = r; o.res_bs = bs; o.res_ld = ld; }
 static inline int pad4(int n) { return round_up(n, 4); }
-// Row stride of the decoder's stage tensors.  Their natural lengths are powers of two times T; padding the
-// stride by a few cache lines keeps the 32 channel rows of a tile from mapping to the same HBM channels.
-static inline int stage_ld(int n) {
-  static const int extra = getenv("SVOC_LDPAD") ? atoi(getenv("SVOC_LDPAD")) : 0;
-  return round_up(n, 4) + extra;
-}
+// Row stride of the decoder's stage tensors (padding it by a few cache lines so that the 32 channel rows of a tile
+// do not map to the same HBM channels was measured neutral in round 1 and removed).
+static inline int stage_ld(int n) { return round_up(n, 4); }
 
 // =================================================================== WN (modules.py:111-185)
 struct WNStack {
@@ -455,6 +452,9 @@ struct Generator {
     for (int j = 0; j < nk; ++j) {
       const ResBlock& rb = *rbs[stage * nk + j];
       if (rb.kind != 1 || rb.ND != r0.ND) return false;
+      // a grouped launch carries ONE dilation for its three members: the chains must agree on it at every step
+      // (resblock_dilation_sizes like [[1,3,5],[3,5,1],[5,1,3]] run chain by chain on the stream plan instead)
+      for (int it = 0; it < rb.ND; ++it) if (rb.c1[it]->dil != r0.c1[it]->dil) return false;
     }
     return true;
   }
@@ -595,7 +595,7 @@ struct Generator {
       {
         static const bool on = !(getenv("SVOC_MRF_SMALL") && atoi(getenv("SVOC_MRF_SMALL")) == 0);
         const int mtl = cho / 32, wm = (mtl >= 4 && mtl % 4 == 0) ? 4 : 2;
-        const long long tiles = (long long)cfg.n_kernels * B * ((Lo + (wm == 4 ? 63 : 127)) / (wm == 4 ? 64 : 128)) * ((mtl + wm - 1) / wm);
+        const long long tiles = (long long)cfg.n_kernels * variant_batch(B) * ((Lo + (wm == 4 ? 63 : 127)) / (wm == 4 ? 64 : 128)) * ((mtl + wm - 1) / wm);
         small_stage = on && tiles < 2LL * device_cu_count();
       }
       if (use_streams && !small_stage && mrf_grouped(i, cho)) {
@@ -813,21 +813,37 @@ struct Synth {
     for (auto* c : flow.rev_p) { mix(c->ws.p); mix(c->enc.ws.p); }
     return h;
   }
+  struct PlanKey {
+    int B = 0, T = 0, Td = 0; float noise = 0; bool has_eps = false, want_zp = false;
+    bool operator==(const PlanKey& o) const { return B == o.B && T == o.T && Td == o.Td && noise == o.noise && has_eps == o.has_eps && want_zp == o.want_zp; }
+  };
   struct Plan {
     unsigned long long fp = 0;
-    int B = 0, T = 0, Td = 0; float noise = 0; bool has_eps = false, want_zp = false;
-    int seen = 0;                       // calls with this key (the first runs uncaptured: per-device kernel attributes, allocation)
+    PlanKey key;
     hipGraphExec_t exec = nullptr;
+    hipEvent_t done = nullptr;          // recorded behind every launch of `exec`: the exec is destroyed only once it has completed
     Generator::LastStage last;          // where the captured body leaves the last MRF stage
-    DevBuf stage;                       // mel | eps | lengths
-    long long conv_launches = 0, other_launches = 0, convs = 0; double conv_flops = 0;
+    long long conv_launches = 0, other_launches = 0, convs = 0; double conv_flops = 0, exec_flops = 0;
     unsigned long long last_use = 0;
-    ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
+    bool idle() const { return !done || hipEventQuery(done) == hipSuccess; }
+    ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); if (done) (void)hipEventDestroy(done); }
   };
-  std::vector<std::unique_ptr<Plan>> plans;
+  // A serving process sees hundreds of distinct utterance lengths below SVOC_GRAPH_MAX_FRAMES.  A shape earns a plan only
+  // when it comes back: first sights go into a fixed table of counters (no allocation, nothing to evict), and a plan is
+  // captured on the SVOC_GRAPH_MIN_SEEN-th call (default 2).  At most MAX_PLANS plans exist; the least recently used one
+  // makes room, and it is destroyed without any device-wide synchronisation: a plan whose last launch has not completed
+  // waits in `retired` (polled with hipEventQuery on later calls; only if more than MAX_RETIRED pile up does the oldest
+  // get a hipEventSynchronize on ITS event).  All plans read their inputs from one staging area sized for
+  // SVOC_GRAPH_MAX_FRAMES, allocated once, so that evicting a plan frees no device memory (hipFree synchronises).
+  static constexpr int MAX_PLANS = 32, MAX_RETIRED = 8, N_COUNTERS = 64;
+  struct Counter { PlanKey key; int seen = 0; unsigned long long last_use = 0; };
+  Counter counters[N_COUNTERS];
+  std::vector<std::unique_ptr<Plan>> plans, retired;
+  DevBuf plan_stage;                    // mel | eps | lengths at fixed offsets
   unsigned long long use_clock = 0;
+  long long plan_evictions = 0, plan_captures = 0, plan_sync_waits = 0;
   hipStream_t cap_st = nullptr;
-  ~Synth() { plans.clear(); if (cap_st) (void)hipStreamDestroy(cap_st); }
+  ~Synth() { plans.clear(); retired.clear(); if (cap_st) (void)hipStreamDestroy(cap_st); }
 
   static long long graph_max_frames() {
     static const long long v = getenv("SVOC_GRAPH_MAX_FRAMES") ? atoll(getenv("SVOC_GRAPH_MAX_FRAMES")) : 4096;
@@ -835,75 +851,127 @@ struct Synth {
     return on ? v : 0;
   }
 
+  // staging area shared by all plans: lengths | mel | eps at offsets that depend only on SVOC_GRAPH_MAX_FRAMES
+  struct Stage { int64_t* len; float* mel; float* eps; };
+  int stage_ptrs(Stage& sp) {
+    const size_t F = (size_t)graph_max_frames();
+    const size_t len_b = round_up((int)(F * sizeof(int64_t)), 256);
+    SVOC_TRY(plan_stage.ensure(len_b + F * (size_t)(cfg.n_mel + cfg.inter_channels) * sizeof(float)));
+    sp.len = reinterpret_cast<int64_t*>(plan_stage.p);
+    sp.mel = reinterpret_cast<float*>(static_cast<char*>(plan_stage.p) + len_b);
+    sp.eps = sp.mel + F * (size_t)cfg.n_mel;
+    return SVOC_OK;
+  }
+
   int capture(Plan& pl, hipStream_t st) {
-    const int B = pl.B, T = pl.T;
-    const size_t mel_n = (size_t)B * cfg.n_mel * T, eps_n = (size_t)B * cfg.inter_channels * T;
-    SVOC_TRY(pl.stage.ensure((mel_n + eps_n) * sizeof(float) + (size_t)B * sizeof(int64_t)));
+    const int B = pl.key.B, T = pl.key.T;
+    Stage sp;
+    SVOC_TRY(stage_ptrs(sp));
     SVOC_TRY(reserve(B, T));
     if (!cap_st) SVOC_HIP(hipStreamCreateWithFlags(&cap_st, hipStreamNonBlocking));
-    float* mel_s = pl.stage.f();
-    float* eps_s = mel_s + mel_n;
-    const int64_t* len_s = reinterpret_cast<const int64_t*>(eps_s + eps_n);
+    if (!pl.done) SVOC_HIP(hipEventCreateWithFlags(&pl.done, hipEventDisableTiming));
     long long cl0, ol0, cl1, ol1; double cf0, cf1;
     const long long nc0 = stats_convs();
+    const double ef0 = stats_exec_flops();
     stats_get(&cl0, &cf0, &ol0);
     SVOC_HIP(hipStreamBeginCapture(cap_st, hipStreamCaptureModeThreadLocal));
-    const int rc = body(cap_st, mel_s, len_s, pl.has_eps ? eps_s : nullptr, pl.noise, pl.Td, pl.want_zp, B, T);
+    const int rc = body(cap_st, sp.mel, sp.len, pl.key.has_eps ? sp.eps : nullptr, pl.key.noise, pl.key.Td, pl.key.want_zp, B, T);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(cap_st, &graph);
     stats_get(&cl1, &cf1, &ol1);
     const long long nc1 = stats_convs();
-    stats_add_bulk(cl0 - cl1, cf0 - cf1, ol0 - ol1, nc0 - nc1);          // the capture pass itself executed nothing
+    const double ef1 = stats_exec_flops();
+    stats_add_bulk(cl0 - cl1, cf0 - cf1, ol0 - ol1, nc0 - nc1, ef0 - ef1);          // the capture pass itself executed nothing
     if (rc != SVOC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) SVOC_FAIL(SVOC_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
     const hipError_t ei = hipGraphInstantiate(&pl.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { pl.exec = nullptr; SVOC_FAIL(SVOC_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
-    pl.conv_launches = cl1 - cl0; pl.conv_flops = cf1 - cf0; pl.other_launches = ol1 - ol0; pl.convs = nc1 - nc0;
+    pl.conv_launches = cl1 - cl0; pl.conv_flops = cf1 - cf0; pl.other_launches = ol1 - ol0; pl.convs = nc1 - nc0; pl.exec_flops = ef1 - ef0;
     pl.fp = ws_fingerprint();
     pl.last = dec.last;
+    ++plan_captures;
+    (void)st;
     return SVOC_OK;
+  }
+
+  // Takes plan i out of service.  Its graph may still be executing: it is destroyed when its completion event has fired.
+  void retire(size_t i) {
+    std::unique_ptr<Plan> p = std::move(plans[i]);
+    plans.erase(plans.begin() + i);
+    ++plan_evictions;
+    if (!p->idle()) retired.push_back(std::move(p));
+  }
+  void reap_retired() {
+    for (size_t i = 0; i < retired.size();) {
+      if (retired[i]->idle()) retired.erase(retired.begin() + i); else ++i;
+    }
+    while (retired.size() > (size_t)MAX_RETIRED) {        // bounded: wait for the OLDEST retired plan only (never the whole device)
+      (void)hipEventSynchronize(retired.front()->done);
+      ++plan_sync_waits;
+      retired.erase(retired.begin());
+    }
+  }
+
+  // The plan to replay for this call, or nullptr for direct launches.
+  Plan* plan_for(const PlanKey& key, hipStream_t st) {
+    static const int min_seen = getenv("SVOC_GRAPH_MIN_SEEN") ? std::max(2, atoi(getenv("SVOC_GRAPH_MIN_SEEN"))) : 2;
+    if ((long long)key.B * key.T > graph_max_frames() || prof_enabled()) return nullptr;
+    {   // a caller that is itself capturing (torch.cuda.graph around infer) gets plain launches: neither a nested capture
+        // nor a graph launch is legal on a capturing stream
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    }
+    if (!retired.empty()) reap_retired();
+    for (size_t i = 0; i < plans.size(); ++i)
+      if (plans[i]->key == key) {
+        Plan* pl = plans[i].get();
+        pl->last_use = ++use_clock;
+        if (pl->exec && pl->fp != ws_fingerprint()) {      // a workspace moved (grown by a larger shape): capture again
+          retire(i);
+          break;
+        }
+        return pl;
+      }
+    Counter* c = nullptr;
+    Counter* lru = &counters[0];
+    for (auto& q : counters) {
+      if (q.seen != 0 && q.key == key) { c = &q; break; }
+      if (q.last_use < lru->last_use) lru = &q;
+    }
+    if (!c) { c = lru; c->key = key; c->seen = 0; }
+    c->last_use = ++use_clock;
+    if (c->seen < 0) return nullptr;                       // capture failed for this shape before: direct launches
+    if (++c->seen < min_seen) return nullptr;
+    if (plans.size() >= (size_t)MAX_PLANS) {
+      size_t v = 0;
+      for (size_t i = 1; i < plans.size(); ++i) if (plans[i]->last_use < plans[v]->last_use) v = i;
+      retire(v);
+    }
+    std::unique_ptr<Plan> np(new Plan());
+    np->key = key;
+    np->last_use = use_clock;
+    if (capture(*np, st) != SVOC_OK) { c->seen = -1; return nullptr; }
+    plans.push_back(std::move(np));
+    return plans.back().get();
   }
 
   int infer(hipStream_t st, const float* mel, const int64_t* lengths, const float* eps, float noise_scale, int max_len, float* o,
             float* x_mask, float* z, float* z_p, float* m_p, float* logs_p, int B, int T) {
     const int Td = (max_len > 0 && max_len < T) ? max_len : T;
     const bool want_zp = z_p != nullptr;
-    Plan* pl = nullptr;
-    if ((long long)B * T <= graph_max_frames() && !prof_enabled()) {
-      for (auto& q : plans)
-        if (q->B == B && q->T == T && q->Td == Td && q->noise == noise_scale && q->has_eps == (eps != nullptr) && q->want_zp == want_zp) pl = q.get();
-      if (!pl) {
-        if (plans.size() >= 16) {   // evict the least recently used plan (its graph may still be executing: wait for it)
-          size_t v = 0;
-          for (size_t i = 1; i < plans.size(); ++i) if (plans[i]->last_use < plans[v]->last_use) v = i;
-          SVOC_HIP(hipDeviceSynchronize());
-          plans.erase(plans.begin() + v);
-        }
-        plans.emplace_back(new Plan());
-        pl = plans.back().get();
-        pl->B = B; pl->T = T; pl->Td = Td; pl->noise = noise_scale; pl->has_eps = eps != nullptr; pl->want_zp = want_zp;
-      }
-      pl->last_use = ++use_clock;
-      ++pl->seen;
-    }
-    if (pl && pl->seen >= 2) {
-      if (pl->exec && pl->fp != ws_fingerprint()) { (void)hipGraphExecDestroy(pl->exec); pl->exec = nullptr; }
-      if (!pl->exec) {
-        const int rc = capture(*pl, st);
-        if (rc != SVOC_OK) { pl->seen = -(1 << 30); pl = nullptr; }      // capture unavailable: stay on direct launches
-      }
-      if (pl && pl->exec) {
-        const size_t mel_n = (size_t)B * cfg.n_mel * T, eps_n = (size_t)B * cfg.inter_channels * T;
-        float* mel_s = pl->stage.f();
-        float* eps_s = mel_s + mel_n;
-        SVOC_HIP(hipMemcpyAsync(mel_s, mel, mel_n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        if (eps) SVOC_HIP(hipMemcpyAsync(eps_s, eps, eps_n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        SVOC_HIP(hipMemcpyAsync(eps_s + eps_n, lengths, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
-        SVOC_HIP(hipGraphLaunch(pl->exec, st));
-        stats_add_bulk(pl->conv_launches, pl->conv_flops, pl->other_launches, pl->convs);
-        return tail(st, pl->last, o, x_mask, z, z_p, m_p, logs_p, B, T);
-      }
+    PlanKey key; key.B = B; key.T = T; key.Td = Td; key.noise = noise_scale; key.has_eps = eps != nullptr; key.want_zp = want_zp;
+    if (Plan* pl = plan_for(key, st)) {
+      Stage sp;
+      SVOC_TRY(stage_ptrs(sp));
+      const size_t mel_n = (size_t)B * cfg.n_mel * T, eps_n = (size_t)B * cfg.inter_channels * T;
+      SVOC_HIP(hipMemcpyAsync(sp.mel, mel, mel_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (eps) SVOC_HIP(hipMemcpyAsync(sp.eps, eps, eps_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      SVOC_HIP(hipMemcpyAsync(sp.len, lengths, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+      SVOC_HIP(hipGraphLaunch(pl->exec, st));
+      SVOC_HIP(hipEventRecord(pl->done, st));
+      stats_add_bulk(pl->conv_launches, pl->conv_flops, pl->other_launches, pl->convs, pl->exec_flops);
+      return tail(st, pl->last, o, x_mask, z, z_p, m_p, logs_p, B, T);
     }
     SVOC_TRY(body(st, mel, lengths, eps, noise_scale, Td, want_zp, B, T));
     return tail(st, dec.last, o, x_mask, z, z_p, m_p, logs_p, B, T);
@@ -915,14 +983,14 @@ struct Synth {
 // ======================================================================= C ABI
 using namespace svoc;
 
-struct svoc_wn { WNStack m; };
-struct svoc_resblock { ResBlock m; };
-struct svoc_coupling { Coupling m; };
-struct svoc_flow { Flow m; };
-struct svoc_generator { Generator m; };
-struct svoc_synth { Synth m; };
-struct svoc_posterior { Posterior m; };
-struct svoc_mel_encoder { Posterior m; };
+struct svoc_wn : svoc::HandleDevice { WNStack m; };
+struct svoc_resblock : svoc::HandleDevice { ResBlock m; };
+struct svoc_coupling : svoc::HandleDevice { Coupling m; };
+struct svoc_flow : svoc::HandleDevice { Flow m; };
+struct svoc_generator : svoc::HandleDevice { Generator m; };
+struct svoc_synth : svoc::HandleDevice { Synth m; };
+struct svoc_posterior : svoc::HandleDevice { Posterior m; };
+struct svoc_mel_encoder : svoc::HandleDevice { Posterior m; };
 
 #define SVOC_GUARD_BEGIN try {
 #define SVOC_GUARD_END } catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
@@ -948,7 +1016,7 @@ int svoc_wn_forward(svoc_wn* h, void* stream, const float* x, const float* x_mas
   return h->m.forward(as_stream(stream), x, bs, T, x_mask, T, g, g_T, out, bs, T, B, T);
   SVOC_GUARD_END
 }
-void svoc_wn_destroy(svoc_wn* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_wn_destroy(svoc_wn* h) { svoc::destroy_handle(h); }
 
 int svoc_resblock_create(svoc_resblock** out, int kind, int channels, int kernel_size, const int* dilations, int n_dilations,
                          const svoc_tensor* tensors, int n_tensors, const char* prefix) {
@@ -968,7 +1036,7 @@ int svoc_resblock_forward(svoc_resblock* h, void* stream, const float* x, const 
   return h->m.forward(as_stream(stream), x, x_mask, y, B, L);
   SVOC_GUARD_END
 }
-void svoc_resblock_destroy(svoc_resblock* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_resblock_destroy(svoc_resblock* h) { svoc::destroy_handle(h); }
 
 int svoc_coupling_create(svoc_coupling** out, int channels, int hidden_channels, int kernel_size, int dilation_rate, int n_layers,
                          int gin_channels, int mean_only, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
@@ -994,7 +1062,7 @@ int svoc_coupling_forward(svoc_coupling* h, void* stream, const float* x, const 
   return m.run(st, x, bs, T, y, bs, T, x_mask, T, g, g_T, reverse, logdet, B, T);
   SVOC_GUARD_END
 }
-void svoc_coupling_destroy(svoc_coupling* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_coupling_destroy(svoc_coupling* h) { svoc::destroy_handle(h); }
 
 int svoc_flow_create(svoc_flow** out, int channels, int hidden_channels, int kernel_size, int dilation_rate, int n_layers, int n_flows,
                      int gin_channels, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
@@ -1015,7 +1083,7 @@ int svoc_flow_forward(svoc_flow* h, void* stream, const float* x, const float* x
   return h->m.forward(as_stream(stream), x, x_mask, g, g_T, reverse, y, B, T);
   SVOC_GUARD_END
 }
-void svoc_flow_destroy(svoc_flow* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_flow_destroy(svoc_flow* h) { svoc::destroy_handle(h); }
 
 int svoc_generator_create(svoc_generator** out, const svoc_generator_config* cfg, const svoc_tensor* tensors, int n_tensors,
                           const char* prefix) {
@@ -1036,7 +1104,7 @@ int svoc_generator_forward(svoc_generator* h, void* stream, const float* x, int 
   return h->m.forward(as_stream(stream), x, x_ld, x_bs, in_mask, in_mask_bs, g, out, B, T);
   SVOC_GUARD_END
 }
-void svoc_generator_destroy(svoc_generator* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_generator_destroy(svoc_generator* h) { svoc::destroy_handle(h); }
 
 int svoc_synth_create(svoc_synth** out, const svoc_synth_config* cfg, const svoc_tensor* tensors, int n_tensors) {
   if (!out || !cfg || !tensors) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_synth_create: null argument");
@@ -1065,7 +1133,13 @@ int svoc_synth_reserve(svoc_synth* h, int B, int T) {
   SVOC_GUARD_END
 }
 int svoc_synth_hop(svoc_synth* h) { return h ? h->m.dec.hop : 0; }
-void svoc_synth_destroy(svoc_synth* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+int svoc_synth_plan_stats(svoc_synth* h, int64_t* out5) {
+  if (!h || !out5) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_synth_plan_stats: null argument");
+  out5[0] = (int64_t)h->m.plans.size(); out5[1] = h->m.plan_captures; out5[2] = h->m.plan_evictions;
+  out5[3] = h->m.plan_sync_waits; out5[4] = (int64_t)h->m.retired.size();
+  return SVOC_OK;
+}
+void svoc_synth_destroy(svoc_synth* h) { svoc::destroy_handle(h); }
 
 int svoc_posterior_create(svoc_posterior** out, int in_channels, int out_channels, int hidden_channels, int kernel_size,
                           int dilation_rate, int n_layers, int gin_channels, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
@@ -1087,7 +1161,7 @@ int svoc_posterior_forward(svoc_posterior* h, void* stream, const float* x, cons
   return h->m.forward(as_stream(stream), x, lengths, g, g_T, eps, z, m, logs, x_mask, B, T);
   SVOC_GUARD_END
 }
-void svoc_posterior_destroy(svoc_posterior* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_posterior_destroy(svoc_posterior* h) { svoc::destroy_handle(h); }
 
 int svoc_mel_encoder_create(svoc_mel_encoder** out, int n_mel, int out_channels, int hidden_channels, int kernel_size,
                             int dilation_rate, int n_layers, int gin_channels, const svoc_tensor* tensors, int n_tensors,
@@ -1111,7 +1185,7 @@ int svoc_mel_encoder_forward(svoc_mel_encoder* h, void* stream, const float* x, 
   return h->m.forward(as_stream(stream), x, lengths, nullptr, 0, nullptr, nullptr, m, logs, x_mask, B, T, x_out);
   SVOC_GUARD_END
 }
-void svoc_mel_encoder_destroy(svoc_mel_encoder* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_mel_encoder_destroy(svoc_mel_encoder* h) { svoc::destroy_handle(h); }
 
 // ---- diagnostics: device buffer ([workgroup][8] int64, zeroed by the caller) that resblock_fused_kernel fills with its
 // phase cycle stamps; NULL switches the stamps off

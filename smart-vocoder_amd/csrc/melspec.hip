@@ -127,7 +127,7 @@ struct MelSpec {
 }  // namespace svoc
 
 using namespace svoc;
-struct svoc_melspec { MelSpec m; };
+struct svoc_melspec : svoc::HandleDevice { MelSpec m; };
 
 extern "C" {
 
@@ -161,6 +161,6 @@ int svoc_mel_filterbank(int sampling_rate, int n_fft, int n_mels, double fmin, d
   memcpy(out, fb.data(), fb.size() * sizeof(float));
   return SVOC_OK;
 }
-void svoc_melspec_destroy(svoc_melspec* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_melspec_destroy(svoc_melspec* h) { svoc::destroy_handle(h); }
 
 }  // extern "C"

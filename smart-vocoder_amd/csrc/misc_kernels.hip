@@ -19,6 +19,10 @@ int xcd_mapping_enabled() {
   return on;
 }
 
+static std::atomic<int> g_variant_batch{getenv("SVOC_VARIANT_BATCH") ? atoi(getenv("SVOC_VARIANT_BATCH")) : 0};
+int variant_batch(int B) { const int v = g_variant_batch.load(std::memory_order_relaxed); return v > 0 ? v : B; }
+int set_variant_batch(int n) { return g_variant_batch.exchange(n > 0 ? n : 0); }
+
 static std::mutex g_dev_mu;
 int device_cu_count() {
   static int cus[64] = {};
@@ -58,23 +62,28 @@ void set_error(const char* fmt, ...) {
 const char* last_error() { return g_err; }
 
 static std::atomic<long long> g_conv_launches{0}, g_other_launches{0}, g_convs{0};
-static std::atomic<double> g_conv_flops{0.0};
+static std::atomic<double> g_conv_flops{0.0}, g_exec_flops{0.0};
+static inline void atomic_add(std::atomic<double>& a, double v) {
+  double cur = a.load(std::memory_order_relaxed);
+  while (!a.compare_exchange_weak(cur, cur + v, std::memory_order_relaxed)) {}
+}
 long long stats_convs() { return g_convs.load(); }
-void stats_add_conv(double flops, int nconv) {
+double stats_exec_flops() { return g_exec_flops.load(); }
+void stats_add_conv(double flops, int nconv, double exec_flops) {
   g_conv_launches.fetch_add(1, std::memory_order_relaxed);
   g_convs.fetch_add(nconv, std::memory_order_relaxed);
-  double cur = g_conv_flops.load(std::memory_order_relaxed);
-  while (!g_conv_flops.compare_exchange_weak(cur, cur + flops, std::memory_order_relaxed)) {}
+  atomic_add(g_conv_flops, flops);
+  atomic_add(g_exec_flops, exec_flops < 0 ? flops : exec_flops);
 }
 void stats_add_other() { g_other_launches.fetch_add(1, std::memory_order_relaxed); }
-void stats_add_bulk(long long cl, double cf, long long ol, long long nc) {
+void stats_add_bulk(long long cl, double cf, long long ol, long long nc, double ef) {
   g_conv_launches.fetch_add(cl, std::memory_order_relaxed);
   g_convs.fetch_add(nc, std::memory_order_relaxed);
   g_other_launches.fetch_add(ol, std::memory_order_relaxed);
-  double cur = g_conv_flops.load(std::memory_order_relaxed);
-  while (!g_conv_flops.compare_exchange_weak(cur, cur + cf, std::memory_order_relaxed)) {}
+  atomic_add(g_conv_flops, cf);
+  atomic_add(g_exec_flops, ef);
 }
-void stats_reset() { g_conv_launches = 0; g_other_launches = 0; g_conv_flops = 0.0; g_convs = 0; }
+void stats_reset() { g_conv_launches = 0; g_other_launches = 0; g_conv_flops = 0.0; g_exec_flops = 0.0; g_convs = 0; }
 void stats_get(long long* cl, double* cf, long long* ol) {
   if (cl) *cl = g_conv_launches.load();
   if (cf) *cf = g_conv_flops.load();
@@ -332,7 +341,7 @@ int k_fill(hipStream_t st, float* p, size_t n, float v) {
 
 extern "C" {
 const char* svoc_last_error(void) { return svoc::last_error(); }
-int svoc_abi_version(void) { return 2; }
+int svoc_abi_version(void) { return 3; }
 const char* svoc_build_arch(void) { return "gfx950"; }
 int svoc_stats_reset(void) { svoc::stats_reset(); return SVOC_OK; }
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches) {
@@ -344,6 +353,8 @@ int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_la
   return SVOC_OK;
 }
 int64_t svoc_stats_convolutions(void) { return svoc::stats_convs(); }
+double svoc_stats_executed_flops(void) { return svoc::stats_exec_flops(); }
+int svoc_set_variant_batch(int n) { return svoc::set_variant_batch(n); }
 int svoc_profile_enable(int on) { svoc::prof_enable(on != 0); return SVOC_OK; }
 int svoc_profile_report(char* buf, int buflen) {
   if (!buf || buflen <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_profile_report: bad buffer");

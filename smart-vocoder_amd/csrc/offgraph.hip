@@ -536,8 +536,8 @@ struct ConvFlow {
 }  // namespace svoc
 
 using namespace svoc;
-struct svoc_dds { DDS m; };
-struct svoc_convflow { ConvFlow m; };
+struct svoc_dds : svoc::HandleDevice { DDS m; };
+struct svoc_convflow : svoc::HandleDevice { ConvFlow m; };
 
 #define SVOC_GUARD_BEGIN try {
 #define SVOC_GUARD_END } catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
@@ -563,7 +563,7 @@ int svoc_dds_forward(svoc_dds* h, void* stream, const float* x, const float* x_m
   return h->m.forward(as_stream(stream), x, bs, T, x_mask, T, g, g_T, y, bs, T, B, T);
   SVOC_GUARD_END
 }
-void svoc_dds_destroy(svoc_dds* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_dds_destroy(svoc_dds* h) { svoc::destroy_handle(h); }
 
 int svoc_convflow_create(svoc_convflow** out, int in_channels, int filter_channels, int kernel_size, int n_layers, int num_bins,
                          float tail_bound, const svoc_tensor* tensors, int n_tensors, const char* prefix) {
@@ -584,7 +584,7 @@ int svoc_convflow_forward(svoc_convflow* h, void* stream, const float* x, const 
   return h->m.forward(as_stream(stream), x, x_mask, g, g_T, reverse, y, logdet, B, T);
   SVOC_GUARD_END
 }
-void svoc_convflow_destroy(svoc_convflow* h) { if (h) { (void)hipDeviceSynchronize(); delete h; } }
+void svoc_convflow_destroy(svoc_convflow* h) { svoc::destroy_handle(h); }
 
 /* modules.LayerNorm.forward (modules.py:28-32): layer norm over dim 1 of x [B, C, T] */
 int svoc_layer_norm(void* stream, const float* x, const float* gamma, const float* beta, float eps, float* y, int B, int C, int T) {

@@ -656,7 +656,7 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
   }
   int rc2 = SVOC_OK;
   if (launch_v2(a, c1, c2, B, L, st, &rc2)) {
-    if (rc2 != SVOC_OK) return rc2;       // launched by the compile-time-specialised kernel
+    if (rc2 != SVOC_OK) { prof_end(st, prof_idx); return rc2; }       // launched by the compile-time-specialised kernel
   } else if (C == 32) {
     auto kern = resblock_fused_kernel<1, 4, 2>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));

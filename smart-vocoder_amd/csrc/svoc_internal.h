@@ -155,6 +155,12 @@ __device__ __forceinline__ int xcd_linear(int lin, int total, int on) {
 }
 #endif
 int xcd_mapping_enabled();   // misc_kernels.hip
+// Batch size that kernel-VARIANT choices are made for (misc_kernels.hip).  Tile shapes, K split, Winograd-vs-direct, fused-
+// vs-unfused WN layers and the MRF launch plan are picked from the launch size, and different variants sum in different
+// orders, so an utterance alone and inside a batch agree to fp32 rounding but not bit for bit.  svoc_set_variant_batch(n)
+// makes every such choice as if the batch were n (0 = the real batch): ranks that each run a shard of an n-utterance job
+// then produce exactly the bits a single process produces for the whole job.  Grid sizes still follow B.
+int variant_batch(int B);
 // Per-device launch prerequisites (misc_kernels.hip).  A process may drive several GPUs (one handle per device), so
 // neither the compute-unit count nor "this kernel may use 160 KiB of dynamic LDS" can live in a function-local static.
 int device_cu_count();                       // compute units of the CURRENT device (cached per device)
@@ -206,11 +212,32 @@ int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int h
 bool prof_enabled();
 int prof_begin(hipStream_t st, const std::string& desc, double flops);
 void prof_end(hipStream_t st, int idx);
-void stats_add_conv(double flops, int nconv = 1);   // one GEMM-family kernel launch computing nconv convolutions
+// one GEMM-family kernel launch computing nconv convolutions; exec_flops = 2 x the multiply-adds the matrix pipe really issues
+// for them (Winograd kernels: 2/3, 5/7, 8/11 of the direct form for k = 3, 7, 11; < 0: same as flops)
+void stats_add_conv(double flops, int nconv = 1, double exec_flops = -1.0);
+double stats_exec_flops();
 void stats_add_other();
 void stats_get(long long* conv_launches, double* conv_flops, long long* other_launches);
-void stats_add_bulk(long long conv_launches, double conv_flops, long long other_launches, long long convs);   // replay of a captured plan
+void stats_add_bulk(long long conv_launches, double conv_flops, long long other_launches, long long convs, double exec_flops);   // replay of a captured plan
 long long stats_convs();
+
+// Every ABI handle remembers the device it was created on: its workspaces, packed weights and captured graphs live there,
+// so destroy must synchronise and free on THAT device even when the caller's current device has moved on (a process that
+// drives several GPUs; Python GC of a module that lives on cuda:1 while cuda:0 is current).
+struct HandleDevice {
+  int dev = -1;
+  HandleDevice() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+};
+template <class H> inline void destroy_handle(H* h) {
+  if (!h) return;
+  int cur = -1;
+  const int dev = h->dev;
+  if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+  if (dev >= 0 && cur != dev) (void)hipSetDevice(dev);
+  (void)hipDeviceSynchronize();
+  delete h;
+  if (dev >= 0 && cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+}
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

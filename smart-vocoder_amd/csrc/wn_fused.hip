@@ -463,9 +463,9 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
       // the layer is latency-bound: run in_layer and res_skip as two K-split convolutions instead (conv_ksplit_kernel:
       // one row pair per workgroup, K split over its four waves: 42 + 84 workgroups with 240 / 24-MFMA chains at 1 x 200).
     static const bool small_on = !(getenv("SVOC_WN_SMALL") && atoi(getenv("SVOC_WN_SMALL")) == 0);
-    if (small_on && (long long)B * ((T + 31) / 32) < ncu / 2) return 1;
+    if (small_on && (long long)variant_batch(B) * ((T + 31) / 32) < ncu / 2) return 1;
   }
-  const int NR = ((long long)B * ((T + 63) / 64) >= 2LL * ncu) ? 2 : 1;
+  const int NR = ((long long)variant_batch(B) * ((T + 63) / 64) >= 2LL * ncu) ? 2 : 1;
   const int NA = NR * 32;
   const int minoff = -in_l.pad, maxoff = (in_l.ktaps - 1) * in_l.dil - in_l.pad;
   a.xoff0 = minoff & ~3;

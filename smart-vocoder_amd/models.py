@@ -329,6 +329,9 @@ class SynthesizerTrn(_HipModule):
     # receptive half-width of the whole path in mel frames: encoder WN 16*2 + flow 4*8*2 + decoder (conv_pre 3,
     # and <= 60/8 + 60/64 + 60/128 + 60/256 + upsampler taps) -- 128 covers it with margin
     RECEPTIVE_FRAMES = 128
+    # decoder alone (frames past an utterance's end that still influence samples inside it; encoder and flows are masked
+    # layer by layer, so nothing else reaches across the end): 3 + 1 + 60/8 + 60/64 + 60/128 + 60/256 + taps < 14
+    DECODER_RECEPTIVE_FRAMES = 16
 
     def infer_chunked(self, x, x_lengths, chunk_frames=1024, noise_scale=1, eps=None, halo_frames=None):
         """Long-form inference by time tiling: the mel is cut into chunks of `chunk_frames`, each is

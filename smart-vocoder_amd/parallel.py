@@ -75,21 +75,88 @@ def gather_waveforms(o_local, B, dst=0, group=None):
     return torch.cat([bufs[i][: b - a] for i, (a, b) in enumerate(bounds)], 0).to(dev)
 
 
-def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0, group=None):
+def _now(dev):
+    import time
+    if dev is not None and dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    return time.perf_counter()
+
+
+def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0, group=None, bucket=False, bitwise=False,
+                  halo_frames=None, timings=None):
     """Run net.infer on this rank's shard of a batch living on `src`; `src` gets the full [B,1,L] waveform back.
-    mel/lengths/eps need to be valid on `src` only (pass shapes via the src tensors broadcast below)."""
+    mel/lengths/eps need to be valid on `src` only (shapes are broadcast from there).
+
+    bucket=False (default): contiguous chunks of the batch as given, every shard runs all T frames - the result is the
+      reference's ``infer`` output for the whole batch, padding region included.
+    bucket=True: length bucketing before sharding (the reference's bucket idea, data_utils.py:130-226): utterances are
+      ordered longest first (``sort_by_length``), cut into contiguous shards, and each shard runs only
+      ``max(lengths of the shard) + halo`` frames (halo >= the decoder's receptive field, ``net.DECODER_RECEPTIVE_FRAMES``), so
+      ranks holding short utterances finish early.  Rows come back in the caller's order (un-permuted on gather).  Every
+      sample below ``lengths[i] * hop`` sees exactly the inputs it sees in the unsharded call; samples in the padding
+      region (which the reference computes from masked zeros and callers slice off) are returned as ZERO.
+    bitwise=True: kernel variants are chosen for the JOB's batch size on every rank (svoc_set_variant_batch), so the
+      gathered result is bit-identical to a single process running the whole batch under the same setting (SURVEY.md 8e);
+      with bucket=True the trimmed frame count differs per shard, so only bucket=False is bit-exact.
+    timings: optional dict, filled with host-side milliseconds {"scatter_ms", "infer_ms", "gather_ms"} (device
+      synchronised at each boundary - diagnostics, costs a sync per phase)."""
     rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
     dev = next(net.parameters()).device
-    meta = torch.zeros(3, dtype=torch.int64, device=_wire_device(dev, group))
+    wire = _wire_device(dev, group)
+    tdev = dev if timings is not None else None
+    t0 = _now(tdev) if timings is not None else 0.0
+    meta = torch.zeros(4, dtype=torch.int64, device=wire)
     if rank == src:
-        meta[0], meta[1], meta[2] = mel.shape[0], mel.shape[2], eps.shape[1]
+        meta[0], meta[1], meta[2], meta[3] = mel.shape[0], mel.shape[2], eps.shape[1], mel.shape[1]
     dist.broadcast(meta, src=src, group=group)
-    B, T, IC = (int(v) for v in meta.tolist())
-    m, l, e = scatter_batch([mel, lengths, eps] if rank == src else None, [(80, T), (), (IC, T)],
+    B, T, IC, n_mel = (int(v) for v in meta.tolist())
+    inv = None
+    if bucket:
+        # every rank needs the sorted lengths to size its own shard; only src has them
+        ln_all = torch.zeros(B, dtype=torch.int64, device=wire)
+        order = None
+        if rank == src:
+            order, inv = sort_by_length(lengths.to(wire))
+            ln_all.copy_(lengths.to(wire)[order])
+            od = order.to(mel.device)
+            mel, lengths, eps = mel[od], lengths.to(mel.device)[od], eps[od]
+        dist.broadcast(ln_all, src=src, group=group)
+    m, l, e = scatter_batch([mel, lengths, eps] if rank == src else None, [(n_mel, T), (), (IC, T)],
                             [torch.float32, torch.int64, torch.float32], B, src=src, device=dev, group=group)
+    t1 = _now(tdev) if timings is not None else 0.0
+    Td = T if max_len is None else min(T, max_len)
+    hop = net.dec.hop
     if m.shape[0] > 0:
-        o = net.infer(m, l, noise_scale=noise_scale, max_len=max_len, eps=e)[0]
+        Tr = T
+        if bucket:
+            a, b = shard_bounds(B, world)[rank]
+            halo = int(getattr(net, "DECODER_RECEPTIVE_FRAMES", 128) if halo_frames is None else halo_frames)
+            Tr = min(T, (int(ln_all[a:b].max().item()) + halo + 3) // 4 * 4)
+            if Tr < T:
+                m, e = m[:, :, :Tr].contiguous(), e[:, :, :Tr].contiguous()
+        ml = None if max_len is None else min(max_len, Tr)
+        if bitwise:
+            from . import _native as N
+            with N.variant_batch(B):
+                o = net.infer(m, l, noise_scale=noise_scale, max_len=ml, eps=e)[0]
+        else:
+            o = net.infer(m, l, noise_scale=noise_scale, max_len=ml, eps=e)[0]
+        if bucket:
+            full = torch.zeros(o.shape[0], 1, Td * hop, dtype=o.dtype, device=o.device)
+            n = min(o.shape[2], Td * hop)
+            full[:, :, :n] = o[:, :, :n]
+            # padding region -> zero (see docstring)
+            idx = torch.arange(Td * hop, device=o.device).view(1, 1, -1)
+            full = full * (idx < (l.to(o.device) * hop).view(-1, 1, 1))
+            o = full
     else:
-        Td = T if max_len is None else min(T, max_len)
-        o = torch.empty(0, 1, Td * net.dec.hop, device=dev)
-    return gather_waveforms(o, B, dst=src, group=group)
+        o = torch.empty(0, 1, Td * hop, device=dev)
+    t2 = _now(tdev) if timings is not None else 0.0
+    out = gather_waveforms(o, B, dst=src, group=group)
+    if out is not None and inv is not None:
+        out = out[inv.to(out.device)]
+    if timings is not None:
+        t3 = _now(tdev)
+        timings.update(scatter_ms=(t1 - t0) * 1e3, infer_ms=(t2 - t1) * 1e3, gather_ms=(t3 - t2) * 1e3)
+    return out

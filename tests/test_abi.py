@@ -99,3 +99,20 @@ def test_hparams_and_checkpoint_roundtrip(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
     (tmp_path / "G_20.pth").write_bytes(b"")
     assert utils.latest_checkpoint_path(str(tmp_path)).endswith("G_100.pth")
+
+
+def test_every_kernel_switch_has_a_variant_run():
+    """Every environment switch the library reads that changes WHICH kernel runs must be exercised by
+    tests/test_gpu_variants.py (and the variant suite must not name switches the library no longer reads)."""
+    import glob
+    import test_gpu_variants as V
+    read = set()
+    for f in glob.glob(os.path.join(cases.ROOT, "smart-vocoder_amd", "csrc", "*.hip")) + glob.glob(os.path.join(cases.ROOT, "smart-vocoder_amd", "csrc", "*.h")):
+        read |= set(re.findall(r'getenv\("(SVOC_[A-Z0-9_]+)"\)', open(f).read()))
+    # not kernel choices: sizes / thresholds of the plan cache, the variant-batch preset, diagnostics
+    tunables = {"SVOC_GRAPH_MAX_FRAMES", "SVOC_GRAPH_MIN_SEEN", "SVOC_VARIANT_BATCH", "SVOC_DBG_WALL", "SVOC_DBG_DUMP", "SVOC_RB_LDS_MIN"}
+    tested = set()
+    for env in V.VARIANTS.values():
+        tested |= set(env)
+    assert read - tunables - tested == set(), f"switches without a variant run: {sorted(read - tunables - tested)}"
+    assert tested - read == set(), f"variant runs of switches the library does not read: {sorted(tested - read)}"

@@ -545,6 +545,97 @@ def test_full_size_properties(M, net):
     assert o1.shape == (Bn, 1, Tn * 256)
 
 
+
+def test_c2_full_size_vs_oracle(M, net):
+    """BASELINE.json configs[1] - the bench workload itself, 16 x 512 frames, seed 1001 (exactly bench.py's tensors) -
+    against the CPU oracle over the WHOLE batch (the oracle needs ~10-40 s here): waveform RMS <= 1e-3 (north_star) and
+    relative RMS <= 1e-4, latents to the per-module tolerance."""
+    Bn, Tn = 16, 512
+    mel = T(sw.synthetic_mel(1001, Bn, Tn)); eps = T(sw.synthetic_eps(1001, Bn, Tn))
+    ln = torch.full((Bn,), Tn, dtype=torch.int64)
+    o, mask, (z, z_p, m_p, logs_p) = net.infer(mel.cuda(), ln.cuda(), noise_scale=0.667, eps=eps.cuda())
+    with torch.no_grad():
+        o_ref, mask_ref, (z_ref, zp_ref, mp_ref, lp_ref) = O.infer(sdT(cases.full_model_weights()), mel, ln, eps, 0.667)
+    check("c2 m_p", m_p, mp_ref); check("c2 logs_p", logs_p, lp_ref); check("c2 z_p", z_p, zp_ref); check("c2 z", z, z_ref, 5e-5, 1e-4)
+    err = (o.cpu() - o_ref).numpy()
+    rms, ref = float(np.sqrt((err ** 2).mean())), float(o_ref.pow(2).mean().sqrt())
+    print(f"c2 16x512: waveform rms err {rms:.3e} (ref rms {ref:.3f}, rel {rms / ref:.2e}), max {np.abs(err).max():.3e}")
+    assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)
+
+
+def test_variant_batch_pins_kernel_choice(M, net):
+    """svoc_set_variant_batch(n): kernel variants are chosen as if the batch held n utterances, so a shard of a job
+    reproduces the whole job's bits ("8-GPU output == 1-GPU output bitwise").  16 x 200 frames: alone, a
+    2-utterance shard takes the short-input variants (K-split convolutions, unfused WN layers, per-chain streams); pinned to
+    16 it must equal rows of the 16-utterance run bit for bit."""
+    Bn, Tn = 16, 200
+    mel = T(sw.synthetic_mel(77, Bn, Tn)).cuda(); eps = T(sw.synthetic_eps(77, Bn, Tn)).cuda()
+    ln = torch.full((Bn,), Tn, dtype=torch.int64).cuda(); ln[5] = 131
+    M.native.profile_enable(True)                 # keeps every call on direct launches (graph replay is bit-identical anyway)
+    try:
+        full = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+        assert M.native.set_variant_batch(0) == 0
+        loose = net.infer(mel[4:6], ln[4:6], noise_scale=0.667, eps=eps[4:6])[0]
+        with M.native.variant_batch(Bn):
+            pinned = net.infer(mel[4:6], ln[4:6], noise_scale=0.667, eps=eps[4:6])[0]
+            pinned1 = net.infer(mel[15:16], ln[15:16], noise_scale=0.667, eps=eps[15:16])[0]
+        assert M.native.set_variant_batch(0) == 0     # the context manager restored the default
+    finally:
+        M.native.profile_enable(False)
+    assert torch.equal(pinned, full[4:6]) and torch.equal(pinned1, full[15:16])
+    assert (loose - full[4:6]).abs().max().item() <= BATCH_TOL
+
+
+def test_plan_cache_many_shapes_never_syncs_the_device(M, net):
+    """A serving process sees many distinct short lengths.  First sights only bump a counter (no plan, no capture); a
+    shape earns a captured plan on its second call; beyond 32 plans the least recently used is retired WITHOUT a device
+    synchronisation (svoc_synth_plan_stats: waits == 0 here because retired plans have long completed); results stay
+    equal to direct launches throughout."""
+    import ctypes
+    N = M.native
+    h = net._native()
+    def stats():
+        out = (ctypes.c_int64 * 5)()
+        N.check(N.lib().svoc_synth_plan_stats(h, out))
+        return list(out)
+    base = stats()
+    lens = list(range(40, 40 + 2 * 40, 2))                        # 40 distinct T
+    data = {t: (T(sw.synthetic_mel(900 + t, 1, t)).cuda(), torch.tensor([t]).cuda(), T(sw.synthetic_eps(900 + t, 1, t)).cuda()) for t in lens}
+    first = {}
+    for t in lens:                                                # first sight: counters only
+        mel, ln, eps = data[t]
+        first[t] = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0].clone()
+    s1 = stats()
+    assert s1[1] == base[1] and s1[0] == base[0], (base, s1)      # no capture, no new plan
+    for t in lens:                                                # second sight: capture + replay
+        mel, ln, eps = data[t]
+        assert torch.equal(net.infer(mel, ln, noise_scale=0.667, eps=eps)[0], first[t]), t
+    s2 = stats()
+    assert s2[1] - base[1] == len(lens) and s2[0] <= 32 and s2[2] - base[2] >= len(lens) - 32, (base, s2)
+    torch.cuda.synchronize()
+    for t in lens[-8:]:                                           # the most recent ones are still planned: pure replay
+        mel, ln, eps = data[t]
+        assert torch.equal(net.infer(mel, ln, noise_scale=0.667, eps=eps)[0], first[t]), t
+    s3 = stats()
+    assert s3[1] == s2[1] and s3[3] == base[3], (s2, s3)           # no re-capture, and no eviction ever waited
+
+
+def test_generator_mixed_dilation_orders_vs_oracle(M):
+    """resblock_dilation_sizes that differ between the chains ([[1,3,5],[3,5,1],[5,1,3]]): a grouped MRF launch carries ONE
+    dilation for its three members, so such a configuration must not take the grouped plan (it silently used the first
+    chain's dilations before).  C = 128 / 64 stages at a length where the grouped Winograd launches would apply."""
+    rds = [[1, 3, 5], [3, 5, 1], [5, 1, 3]]
+    c = dict(initial_channel=32, resblock="1", rks=[3, 7, 11], rds=rds, ur=[4, 4], uic=256, uks=[8, 8], gin=0)
+    sd = sw.fill_state_dict(cases.generator_shapes(c), 7711, 1.0)
+    m = load(M.models.Generator(c["initial_channel"], c["resblock"], c["rks"], c["rds"], c["ur"], c["uic"], c["uks"], gin_channels=0), sd)
+    x = T(cases.rnd(7711, "x", (4, 32, 600), 1.0))
+    y = m(x.cuda())
+    with torch.no_grad():
+        ref = O.generator(sdT(sd), x, prefix="", resblock="1", resblock_kernel_sizes=c["rks"], resblock_dilation_sizes=rds,
+                          upsample_rates=c["ur"], upsample_kernel_sizes=c["uks"])
+    check("generator mixed dilations", y, ref, 5e-5, 1e-4)
+
+
 def test_infer_long_form_tiling(M, net):
     """Long input (T=1024, B=1) against the oracle over the WHOLE waveform: many time tiles and every halo.  (The full C5
     shape, 8 x 4096, is test_c5_full_size below.)"""

@@ -1,14 +1,21 @@
-"""The alternate kernel paths are selected by environment variables that the library reads once per process, so each
-variant runs a slice of the parity suite in a subprocess:
-  SVOC_WS=1                      experimental persistent wave-specialised convolution kernel (csrc/conv_ws.hip)
-  SVOC_WS=2                      ... with two consumer sets per workgroup
-  SVOC_FUSE=0 SVOC_FUSE_WN=0     unfused fallbacks (two convolutions per ResBlock iteration / WN layer)
+"""The alternate kernel paths that still ship are selected by environment variables the library reads once per process, so
+each variant runs a slice of the parity suite in a subprocess.  Every `getenv` in csrc/ that changes a kernel choice is
+listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run checks the two lists against each other):
+
+  SVOC_FUSE=0 SVOC_FUSE_WN=0     unfused fallbacks: two convolutions per ResBlock iteration / WN layer
+  SVOC_FUSE_V=1                  generic fused-ResBlock kernel instead of the compile-time-specialised one
+  SVOC_FUSE64=1                  C=64 stage on the fused direct-form ResBlock kernel instead of Winograd conv by conv
   SVOC_STREAMS=0                 single-stream MRF
-  SVOC_WN_KSPLIT=0               6-wave WN layer kernel (one wave per row pair) instead of the 12-wave K-split one
-  SVOC_FUSE_WS=1                 persistent fused-ResBlock kernel with loader waves (experiment)
-  SVOC_XCD=0                     natural workgroup -> tile order instead of the XCD-aware one
   SVOC_GROUP=0                   MRF chains on separate streams for every stage (no grouped launches)
-  SVOC_TILE_256=1                256x128 tile for the C=256 stage
+  SVOC_WINO=0                    direct-form grouped kernel (conv_group_kernel) instead of Winograd F(2,3)
+  SVOC_WINO_WS=0                 four-wave Winograd kernels instead of the wave-specialised eight-wave ones
+  SVOC_WINO_WM=2                 2x2 wave layout (64-row tiles) for the Winograd kernels at C >= 128
+  SVOC_WN_KSPLIT=0               6-wave WN layer kernel (one wave per row pair) instead of the 12-wave K-split one
+  SVOC_KSPLIT=0 SVOC_WN_SMALL=0 SVOC_MRF_SMALL=0    short inputs on the throughput kernels (no K-split convolutions, fused WN
+                                 layers, grouped MRF launches)
+  SVOC_GRAPH=0                   short inputs as direct launches (no captured hipGraph plans)
+  SVOC_XCD=0                     natural workgroup -> tile order instead of the XCD-aware one
+  SVOC_LN_V2=0                   round-1 LayerNorm / DDSConv tile kernel
 """
 import os
 import subprocess
@@ -20,15 +27,31 @@ import cases
 
 pytestmark = pytest.mark.gpu
 
-SLICE = "test_infer_vs_reference_golden or test_resblock1 or test_wn or test_generator or test_coupling"
+SLICE = ("test_infer_vs_reference_golden or test_resblock1 or test_wn or test_generator or test_coupling or "
+         "test_infer_long_form_tiling or test_small_shape_graph_replay or test_conv1d_winograd or test_dds or test_layer_norm")
+
+VARIANTS = {
+    "unfused": {"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"},
+    "generic_fused_resblock": {"SVOC_FUSE_V": "1"},
+    "fused_c64": {"SVOC_FUSE64": "1"},
+    "single_stream": {"SVOC_STREAMS": "0"},
+    "ungrouped": {"SVOC_GROUP": "0"},
+    "no_winograd": {"SVOC_WINO": "0"},
+    "winograd_4wave": {"SVOC_WINO_WS": "0"},
+    "winograd_2x2": {"SVOC_WINO_WM": "2"},
+    "wn_no_ksplit": {"SVOC_WN_KSPLIT": "0"},
+    "no_small_shape_kernels": {"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"},
+    "no_graph": {"SVOC_GRAPH": "0"},
+    "natural_tile_order": {"SVOC_XCD": "0"},
+    "layernorm_v1": {"SVOC_LN_V2": "0"},
+}
 
 
-@pytest.mark.parametrize("env", [{"SVOC_WS": "1"}, {"SVOC_WS": "2"}, {"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"}, {"SVOC_STREAMS": "0"}, {"SVOC_GROUP": "0"}, {"SVOC_WN_KSPLIT": "0"}, {"SVOC_FUSE_WS": "1"}, {"SVOC_XCD": "0"},
-                                 {"SVOC_TILE_256": "1"}], ids=["ws", "ws2", "unfused", "single_stream", "ungrouped", "wn_no_ksplit", "fused_rb_loader_waves", "natural_tile_order", "tile256"])
-def test_variant(env):
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_variant(name):
     e = dict(os.environ)
-    e.update(env)
+    e.update(VARIANTS[name])
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(cases.ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
                         "-m", "gpu", "-p", "no:cacheprovider", "-k", SLICE], env=e, cwd=cases.ROOT, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=900)
+                       stderr=subprocess.STDOUT, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -19,6 +19,8 @@ def _free_port():
 class _FakeNet(torch.nn.Module):
     """Stands in for SynthesizerTrn on CPU: 'waveform' = a deterministic function of (mel, eps, lengths)."""
 
+    RECEPTIVE_FRAMES = 2
+
     class _Dec:
         hop = 4
 
@@ -56,6 +58,23 @@ def _worker(rank, world, port, B, T, q):
     if rank == 0:
         ref = net.infer(mel, ln, noise_scale=0.5, eps=eps)[0]
         ok = ok and torch.equal(o, ref)
+    # length bucketing: rows come back in the caller's order, the valid region is the single-process result, the padding
+    # region is zero; the timing dict is filled; bitwise=True sets and restores the library's variant batch
+    tm = {}
+    ob = parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                                noise_scale=0.5, src=0, bucket=True, timings=tm)
+    ok = ok and set(tm) == {"scatter_ms", "infer_ms", "gather_ms"}
+    if rank == 0:
+        ok = ok and ob.shape == ref.shape
+        for i in range(B):
+            n = int(ln[i]) * 4
+            ok = ok and torch.equal(ob[i, :, :n], ref[i, :, :n]) and float(ob[i, :, n:].abs().sum()) == 0.0
+    from smart_vocoder_amd import _native as N
+    o2 = parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                                noise_scale=0.5, src=0, bitwise=True)
+    ok = ok and N.set_variant_batch(0) == 0          # restored after the call
+    if rank == 0:
+        ok = ok and torch.equal(o2, ref)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,6 +1,8 @@
 """N>1 data path with the REAL model on one GPU: two ranks share device 0 and talk over gloo (the collective an 8-GPU
 node runs over RCCL/xGMI is the same scatter/gather in smart-vocoder_amd/parallel.py, with host staging only for gloo).
-Checks infer_sharded == single-process infer (to fp32 rounding: kernel variants depend on the launch size), and that bench.py's --gpus 2 path runs end to end.
+Checks infer_sharded == single-process infer - to fp32 rounding by default (kernel variants depend on the launch size),
+BIT FOR BIT with bitwise=True (svoc_set_variant_batch pins the variants to the job's batch size), and with
+length bucketing (sort, trim, un-permute) on a ragged batch - and that bench.py's --gpus 2 path runs end to end.
 No scaling number is derived from this setup."""
 import json
 import os
@@ -46,6 +48,29 @@ def _worker(rank, world, port, B, T, q):
             ok = o.is_cuda and o.shape == ref.shape and (o - ref).abs().max().item() <= 2e-6
         else:
             ok = o is None
+        # bitwise: every rank picks the kernel variants of the whole job -> identical bits to one process running the job
+        from smart_vocoder_amd import _native as N
+        ob = parallel.infer_sharded(net, mel, ln, eps, noise_scale=0.667, src=0, bitwise=True)
+        if rank == 0:
+            N.profile_enable(True)                 # direct launches (the library's graph replay is bit-identical to them)
+            with N.variant_batch(B):
+                ref_b = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+            N.profile_enable(False)
+            ok = ok and torch.equal(ob, ref_b)
+        # length bucketing on a ragged batch: rows return in the caller's order, valid region == unsharded, padding == 0
+        ln2 = None
+        if rank == 0:
+            ln2 = torch.tensor([T - 3 * i * (i + 1) for i in range(B)], dtype=torch.int64).clamp(min=5).cuda()
+            ln2 = ln2[torch.randperm(B, generator=torch.Generator().manual_seed(3))]
+        ok2 = True
+        ok_shape = parallel.infer_sharded(net, mel, ln2, eps, noise_scale=0.667, src=0, bucket=True, halo_frames=16)
+        if rank == 0:
+            ref2 = net.infer(mel, ln2, noise_scale=0.667, eps=eps)[0]
+            ok2 = ok_shape.shape == ref2.shape
+            for i in range(B):
+                n = int(ln2[i]) * 256
+                ok2 = ok2 and (ok_shape[i, :, :n] - ref2[i, :, :n]).abs().max().item() <= 2e-6 and float(ok_shape[i, :, n:].abs().sum()) == 0.0
+        ok = ok and ok2
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
