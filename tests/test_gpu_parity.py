@@ -598,24 +598,24 @@ def test_plan_cache_many_shapes_never_syncs_the_device(M, net):
         out = (ctypes.c_int64 * 5)()
         N.check(N.lib().svoc_synth_plan_stats(h, out))
         return list(out)
-    base = stats()
+    base = stats()                                                # (noise_scale 0.123: no other test shares these plan keys)
     lens = list(range(40, 40 + 2 * 40, 2))                        # 40 distinct T
     data = {t: (T(sw.synthetic_mel(900 + t, 1, t)).cuda(), torch.tensor([t]).cuda(), T(sw.synthetic_eps(900 + t, 1, t)).cuda()) for t in lens}
     first = {}
     for t in lens:                                                # first sight: counters only
         mel, ln, eps = data[t]
-        first[t] = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0].clone()
+        first[t] = net.infer(mel, ln, noise_scale=0.123, eps=eps)[0].clone()
     s1 = stats()
     assert s1[1] == base[1] and s1[0] == base[0], (base, s1)      # no capture, no new plan
     for t in lens:                                                # second sight: capture + replay
         mel, ln, eps = data[t]
-        assert torch.equal(net.infer(mel, ln, noise_scale=0.667, eps=eps)[0], first[t]), t
+        assert torch.equal(net.infer(mel, ln, noise_scale=0.123, eps=eps)[0], first[t]), t
     s2 = stats()
     assert s2[1] - base[1] == len(lens) and s2[0] <= 32 and s2[2] - base[2] >= len(lens) - 32, (base, s2)
     torch.cuda.synchronize()
     for t in lens[-8:]:                                           # the most recent ones are still planned: pure replay
         mel, ln, eps = data[t]
-        assert torch.equal(net.infer(mel, ln, noise_scale=0.667, eps=eps)[0], first[t]), t
+        assert torch.equal(net.infer(mel, ln, noise_scale=0.123, eps=eps)[0], first[t]), t
     s3 = stats()
     assert s3[1] == s2[1] and s3[3] == base[3], (s2, s3)           # no re-capture, and no eviction ever waited
 
