@@ -21,6 +21,7 @@
 // accumulator tiles.  Per 32-channel chunk: raw tile (leaky-relu'd, zero padded) -> LDS -> transform pass -> six planes
 // in LDS -> 16 * (4 G + 2 ND) MFMAs per wave with fragment reads at immediate offsets.
 #include "svoc_internal.h"
+#include "wino_common.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -28,20 +29,6 @@
 #include <type_traits>
 
 namespace svoc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct WinoArgs {
-  const float* x; long long x_bs; int x_ld; int Cin; int L;      // input [B][Cin][x_ld], valid columns [0, L)
-  float pre_slope;                                                  // leaky-relu applied while staging (1 = none)
-  const float* wp; const float* bias; int nchunks; int mtiles;      // transformed weights (pack_wino), bias [32 * mtiles]
-  float* y; long long y_bs; int y_ld;                               // output [B][Cout][y_ld]
-  const float* res; long long res_bs; int res_ld;                   // F_RES
-  unsigned flags; float div;                                        // F_RES | F_ACC | F_DIV
-  int ntn; int gy; int xcd;                                         // column tiles per row, row blocks, XCD-aware order
-  long long* dbg; int dbg_base;                                     // optional [workgroups][16] stamps (svoc_debug_set_stamp_buffer)
-};
-struct WinoGroup { WinoArgs a[3]; int end[3]; int k[3]; };
 
 // Dilation D (1, 3, 5) is handled through the polyphase view: a convolution with dilation D is D interleaved undilated
 // convolutions, so the pair of outputs that shares a group's four products is (n, n + D) instead of (n, n + 1).  A tile
@@ -88,50 +75,10 @@ struct WinoGeo {
   static constexpr int LDS_BYTES = (RAW_FLOATS + PL_FLOATS) * 4;
 };
 
-template <int OFF>
-__device__ __forceinline__ float wino_lds_rd(unsigned addr) {
-  float v;
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset field");
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-__device__ __forceinline__ void wino_wait4(float (&b)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])); }
-__device__ __forceinline__ float wino_pick(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
-
-// B fragments of one k-group (4 k-steps = channels 8*KG .. 8*KG+7) of a plane whose rows start BASE floats into the
-// plane area, row stride PQ, at column offset COL: lane (l31, hi) reads row 8*KG + 2*s + hi.
-// `baddr` = LDS byte address of the plane area + (hi * PQ + this lane's pair index u) * 4.
-template <int PQ, int BASE, int KG, int COL>
-__device__ __forceinline__ void wino_frag(float (&b)[4], unsigned baddr) {
-  constexpr int O = BASE + 8 * KG * PQ + COL;
-  b[0] = wino_lds_rd<(O) * 4>(baddr);
-  b[1] = wino_lds_rd<(O + 2 * PQ) * 4>(baddr);
-  b[2] = wino_lds_rd<(O + 4 * PQ) * 4>(baddr);
-  b[3] = wino_lds_rd<(O + 6 * PQ) * 4>(baddr);
-}
-
-template <int T, int N, class F>
-__device__ __forceinline__ void wino_static_for(F&& f) {
-  if constexpr (T < N) {
-    f(std::integral_constant<int, T>{});
-    wino_static_for<T + 1, N>(f);
-  }
-}
 // step t of a chunk (see mfma_chunk): direct-tap steps request 8 fragment values (E and O), group steps 4
 template <int K> constexpr bool wino_step_direct(int t) { return t / 4 >= 4 * ((K + 1) / 4); }
 template <int K> constexpr int wino_step_reads(int t) {
   return t >= 4 * (4 * ((K + 1) / 4) + (K + 1) / 4 - 1) ? 0 : (wino_step_direct<K>(t) ? 8 : 4);
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// leaky relu of four values in 6 instructions (2 packed multiplies + 4 max; fmaxf() costs a canonicalising max more each)
-__device__ __forceinline__ void wino_lrelu4(float4& q, const float slope) {
-  const f32x2 s2 = {slope, slope};
-  const f32x2 a = (f32x2){q.x, q.y} * s2, b = (f32x2){q.z, q.w} * s2;
-  asm("v_max_f32 %0, %1, %2" : "=v"(q.x) : "v"(q.x), "v"(a.x));
-  asm("v_max_f32 %0, %1, %2" : "=v"(q.y) : "v"(q.y), "v"(a.y));
-  asm("v_max_f32 %0, %1, %2" : "=v"(q.z) : "v"(q.z), "v"(b.x));
-  asm("v_max_f32 %0, %1, %2" : "=v"(q.w) : "v"(q.w), "v"(b.y));
 }
 
 // Persistent workgroups (one per CU slot walking a strided list of tiles, tile-independent set-up done once, next tile's
@@ -998,6 +945,14 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
   if (r < rowsP) bp[r] = (bias && r < Cout) ? bias[r] : 0.f;
 }
 
+// conv_wino4.hip: the F(4,3) form
+bool wino4_enabled();
+int wino4_slots(int K);
+int wino4_tile_w(int D);
+int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
+int wino4_launch(const WinoArgs& w, int K, int D, long long total, hipStream_t st);
+int wino4_launch_group(const WinoGroup& g, int D, long long total, hipStream_t st);
+
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
   return on && (dil == 1 || dil == 3 || dil == 5) && (K == 3 || K == 7 || K == 11) && Cin >= 64 && (Cin % KC) == 0 && (Cout % 32) == 0;
@@ -1022,6 +977,12 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
   hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_or_v, g ? scale.f() : nullptr,
                      pw.wp.f(), Cin, Cout, K, pw.nchunks, pw.slots, total);
   hipLaunchKernelGGL(wino_bias_kernel, dim3((pw.mtiles * 32 + 255) / 256), dim3(256), 0, st, bias, pw.bias.f(), Cout, pw.mtiles * 32);
+  if (wino4_enabled() && pw.mtiles % 4 == 0 && (pw.nchunks & 1) == 0) {   // F(4,3) image: 4 x 1 wave layout only, even chunk counts
+    const long long total4 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K) * 4 * 256;
+    SVOC_TRY(pw.wp4.ensure((size_t)(total4 + 1024) * sizeof(float)));
+    SVOC_HIP(hipMemsetAsync(pw.wp4.f() + total4, 0, 1024 * sizeof(float), st));
+    SVOC_TRY(pack_wino4_image(pw.wp4.f(), Cin, Cout, K, w_or_v, g ? scale.f() : nullptr, st));
+  }
   SVOC_HIP(hipGetLastError());
   SVOC_HIP(hipStreamSynchronize(st));                      // `scale` is freed on return
   return SVOC_OK;
@@ -1130,6 +1091,23 @@ static int wino_ws_launch_group(const WinoGroup& g, long long total, hipStream_t
 // one per left-over tap (k=3: 2/3, k=7: 5/7, k=11: 8/11); tile padding is not counted
 static double wino_exec_ratio(int K) { const int G = (K + 1) / 4; return (2.0 * G + (G - 1)) / (double)K; }
 
+// F(4,3) form (conv_wino4.hip): four-row-tile blocks; dilation 1 additionally needs 16-byte aligned rows of a length that is a multiple of four
+static double wino4_exec_ratio(int K) { const int G = (K + 1) / 4; return (1.5 * G + (G - 1)) / (double)K; }
+static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const WinoArgs& w, WinoArgs& w4) {
+  if (!wino4_enabled() || !pw.wp4.p || !(dil == 1 || dil == 3 || dil == 5) || (dil == 1 && (a.Ncols & 3))) return false;
+  const EpiOut& o = a.out[0];
+  if (dil == 1) {                                           // contiguous outputs: 16-byte stores
+    if ((reinterpret_cast<uintptr_t>(o.y) & 15) || (o.y_ld & 3) || (o.y_bs & 3)) return false;
+    if ((o.flags & F_RES) && ((reinterpret_cast<uintptr_t>(o.res) & 15) || (o.res_ld & 3) || (o.res_bs & 3))) return false;
+  }
+  w4 = w;
+  w4.wp = pw.wp4.f();
+  const int W = wino4_tile_w(dil);
+  w4.ntn = (a.Ncols + W - 1) / W;
+  w4.gy = pw.mtiles / 4;
+  return true;
+}
+
 // 1 = not eligible (caller uses the direct kernel)
 int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles) {
   WinoArgs w;
@@ -1139,14 +1117,23 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
   if (min_tiles < 0) min_tiles = 2LL * device_cu_count();
   if ((long long)w.ntn * w.gy * variant_batch(B) < min_tiles || total > 0x7fffffffLL) return 1;    // short inputs: the direct / K-split kernels
   const double flops = pw.flops_per_col * (double)B * (double)a.Ncols;
-  stats_add_conv(flops, 1, flops * wino_exec_ratio(pw.K));
+  WinoArgs w4;
+  const bool f4 = WM == 4 && wino4_args(pw, a, dil, w, w4);
+  stats_add_conv(flops, 1, flops * (f4 ? wino4_exec_ratio(pw.K) : wino_exec_ratio(pw.K)));
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "wino  Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%d", pw.Cin, pw.Cout, pw.K, dil, a.Ncols, B, WM, 4 / WM);
+    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%d", f4 ? "wino4" : "wino ", pw.Cin, pw.Cout, pw.K, dil, a.Ncols, B, WM, 4 / WM);
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
+  if (f4) {
+    rc = wino4_launch(w4, pw.K, dil, (long long)w4.ntn * w4.gy * B, st);
+    prof_end(st, prof_idx);
+    if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
+    SVOC_HIP(hipGetLastError());
+    return SVOC_OK;
+  }
   if (wino_ws_on() && WM == 4 && dil <= 3 && (pw.nchunks & 1) == 0) {
 #define SVOC_WS(KK, DD) if (pw.K == KK && dil == DD) rc = wino_ws_launch_one<KK, DD>(w, total, st);
     SVOC_WS(3, 1) SVOC_WS(7, 1) SVOC_WS(11, 1) SVOC_WS(3, 3) SVOC_WS(7, 3) SVOC_WS(11, 3)
@@ -1167,9 +1154,10 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
 
 int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st) {
   if (n < 2 || n > 3 || B <= 0) return 1;
-  WinoGroup g{};
-  long long total = 0;
-  double flops = 0, exec_flops = 0;
+  WinoGroup g{}, g4{};
+  long long total = 0, total4 = 0;
+  bool f4 = n == 3 && pws[0]->K == 11 && pws[1]->K == 7 && pws[2]->K == 3;
+  double flops = 0, exec_flops = 0, exec4 = 0;
   size_t lds = 0;
   const int WM = wino_wm(*pws[0]);
   for (int i = 0; i < n; ++i) {
@@ -1180,6 +1168,9 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     g.k[i] = pws[i]->K;
     flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
     exec_flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino_exec_ratio(pws[i]->K);
+    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K);
+    f4 = f4 && WM == 4 && wino4_args(*pws[i], as[i], dil, g.a[i], g4.a[i]);
+    if (f4) { total4 += (long long)g4.a[i].ntn * g4.a[i].gy * B; g4.end[i] = (int)total4; g4.k[i] = pws[i]->K; }
     const int K = pws[i]->K;
     size_t l = 0;
     if (WM == 4) l = dil == 1 ? wino_lds<1, 4>(K) : (dil == 3 ? wino_lds<3, 4>(K) : wino_lds<5, 4>(K));
@@ -1188,16 +1179,17 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   }
   if (total / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
   for (int i = n; i < 3; ++i) { g.end[i] = 0x7fffffff; g.k[i] = 3; }
-  stats_add_conv(flops, n, exec_flops);
+  stats_add_conv(flops, n, f4 ? exec4 : exec_flops);
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "winoG Ci%-4d Co%-4d k%d/%d/%d d%d N%-7d B%-3d %dx%d", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, dil,
+    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%d/%d/%d d%d N%-7d B%-3d %dx%d", f4 ? "wino4G" : "winoG", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, dil,
              as[0].Ncols, B, WM, 4 / WM);
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
-  if (wino_ws_on() && WM == 4 && dil <= 3 && n == 3 && pws[0]->K == 11 && pws[1]->K == 7 && pws[2]->K == 3 && (pws[1]->nchunks & 1) == 0)
+  if (f4) rc = wino4_launch_group(g4, dil, total4, st);
+  else if (wino_ws_on() && WM == 4 && dil <= 3 && n == 3 && pws[0]->K == 11 && pws[1]->K == 7 && pws[2]->K == 3 && (pws[1]->nchunks & 1) == 0)
     rc = dil == 1 ? wino_ws_launch_group<1>(g, total, st) : wino_ws_launch_group<3>(g, total, st);
   else if (WM == 4) rc = dil == 1 ? wino_launch_group<1, 4>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 4>(g, total, lds, st) : wino_launch_group<5, 4>(g, total, lds, st));
   else rc = dil == 1 ? wino_launch_group<1, 2>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 2>(g, total, lds, st) : wino_launch_group<5, 2>(g, total, lds, st));

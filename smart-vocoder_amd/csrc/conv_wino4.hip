@@ -1,0 +1,589 @@
+// Winograd F(4,3) implicit-GEMM convolution for the ResBlock convolutions of the decoder's C >= 128 stages (reference
+// modules.py:190-207: convs1 / convs2, k = 3 / 7 / 11).  Round 3: the F(2,3) kernels (conv_wino.hip) issue 15/21 of the
+// direct form's multiply-adds and keep the matrix pipe ~80 % busy, so the next lever is again FEWER MFMAs: F(4,3) issues 12/21.
+//
+// A k-tap convolution is split into three-tap groups at tap offsets 0, 4, 8 plus the left-over taps 3, 7 (as in conv_wino.hip).
+// Each group is a minimal F(4,3) filtering: the four outputs y[4q .. 4q+3] from the six inputs d_j = x[4q - pad + 4g + j]
+// with six products instead of twelve (Lavin & Gray's matrices, correlation form):
+//     V0 = 4 d0 - 5 d2 + d4            U0 = w0 / 4                      y0 = M0 + M1 + M2 + M3 + M4
+//     V1 = -4 d1 - 4 d2 + d3 + d4      U1 = -(w0 + w1 + w2) / 6         y1 = M1 - M2 + 2 M3 - 2 M4
+//     V2 =  4 d1 - 4 d2 - d3 + d4      U2 = -(w0 - w1 + w2) / 6         y2 = M1 + M2 + 4 M3 + 4 M4
+//     V3 = -2 d1 - d2 + 2 d3 + d4      U3 = (w0 + 2 w1 + 4 w2) / 24     y3 = M1 - M2 + 8 M3 - 8 M4 + M5
+//     V4 =  2 d1 - d2 - 2 d3 + d4      U4 = (w0 - 2 w1 + 4 w2) / 24
+//     V5 =  4 d1 - 5 d3 + d5           U5 = w2                          M_p = sum_c U_p[c] * V_p[c]   (the GEMM)
+// The window step (4) equals the group spacing, so every group reads the SAME six transformed planes V_p[c][q'] at
+// q' = q + g and accumulates into ONE set of six transform-domain accumulators.  A left-over tap contributes
+// w * x[4q + r + 4t + 3 - pad] to output r of the tile; with X_r'[q'] = d_{1+r'} of window q' (the four samples a window adds to
+// its predecessor, stored by the same transform item) that is X_{(r+2)%4}[q + t + (r+2)/4]: r = 0 goes into M0 (part of y0
+// only), r = 3 into M5 (part of y3 only), r = 1 / 2 into two accumulators of their own.  MFMAs per output and channel pair:
+// k=3: 1.5 (F(2,3): 2, direct 3), k=7: 4 (5, 7), k=11: 6.5 (8, 11).  Dilation D through the polyphase view (as conv_wino.hip):
+// the four outputs of a window are n, n + D, n + 2D, n + 3D; a tile holds (32 / D) * D windows.
+// fp32 throughout; the transforms scale by up to 8, measured waveform error below (tests assert <= 1e-4 relative RMS).
+//
+// Kernel form: wave-specialised persistent workgroups, ONE per CU (eight accumulator tiles = 128 registers per consumer):
+// waves 0-3 = consumers, one 32-row tile x 32 windows (= 128 outputs) each: nothing but the MFMA stream (fragment reads two
+// steps ahead at immediate LDS offsets, weights one slot ahead) and the epilogue; waves 4-7 = producers: producer p stages
+// and transforms channel rows 8p .. 8p+7 of every 32-channel chunk one stage ahead into the other of two plane sets; one
+// workgroup barrier per stage.  A stage carries 16 * (6 G + 4 ND) = 96 / 256 / 416 MFMAs per consumer (k = 3 / 7 / 11).
+#include "svoc_internal.h"
+#include "wino_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace svoc {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int K, int D>
+struct W4Geo {
+  // 32-channel chunks per stage: k = 3 carries only 96 MFMAs per chunk and consumer, so its stages hold two chunks (fewer
+  // barriers; the plane sets of k = 7 / 11 would not fit twice)
+  static constexpr int CPS = (K == 3 && D == 1) ? 2 : 1;
+  static constexpr int KS = CPS * KC;                     // channels per stage
+  static constexpr int G = (K + 1) / 4;                   // three-tap groups at tap offsets 0, 4, 8
+  static constexpr int ND = G - 1;                        // left-over single taps (3, 7)
+  static constexpr int PADT = (K - 1) / 2;                // padding in taps (columns: PADT * D)
+  static constexpr int WSLOTS = 6 * G + ND;               // weight slots per 32-channel chunk
+  static constexpr int NGS = 24 * G;                      // steps (4 MFMAs each) of the groups; a tap adds 16 steps
+  static constexpr int NSTEP = NGS + 16 * ND;
+  static constexpr int QB = 32 / D;                       // q blocks per tile
+  static constexpr int NWU = QB * D;                      // windows (lanes) per tile
+  static constexpr int W = 4 * NWU;                       // output columns per tile (128 / 120 / 120)
+  static constexpr int NQ = QB + G - 1;                   // windows per phase and row
+  static constexpr int PQ = NQ * D;                       // plane entries per row: entry q' * D + phase
+  static constexpr int XOFF = -((PADT * D + 3) & ~3);     // raw tile starts at n0 + XOFF (multiple of 4)
+  static constexpr int LEAD = -XOFF - PADT * D;           // raw index of d0 of window 0, phase 0
+  static constexpr int LASTRD = LEAD + (4 * (NQ - 1) + 5) * D + D - 1;
+  static constexpr int RAW = (LASTRD + 1 + 3) & ~3;       // raw tile columns
+  static constexpr int NPL = ND > 0 ? 10 : 6;             // V0..V5 (+ X0..X3)
+  static constexpr int NACC = ND > 0 ? 8 : 6;
+  static constexpr int PLANE = KS * PQ;
+  static constexpr int PLF = NPL * PLANE;                 // floats per plane set
+  static constexpr int RAW_FLOATS = KS * RAW;
+  static constexpr int LDS_BYTES = (RAW_FLOATS + 2 * PLF) * 4;
+  // step t of a chunk: which weight slot, plane, column (in windows) and accumulator
+  static constexpr bool tap(int t) { return t >= NGS; }
+  static constexpr int tr(int t) { return ((t - NGS) % 16) / 4; }                        // tap steps: output index r
+  static constexpr int wslot(int t) { return t < NGS ? t / 4 : 6 * G + (t - NGS) / 16; }
+  static constexpr int plane(int t) { return t < NGS ? (t / 4) % 6 : 6 + (tr(t) + 2) % 4; }
+  static constexpr int colq(int t) { return t < NGS ? (t / 4) / 6 : (t - NGS) / 16 + (tr(t) + 2) / 4; }
+  static constexpr int acc(int t) { return t < NGS ? (t / 4) % 6 : (tr(t) == 0 ? 0 : (tr(t) == 3 ? 5 : 5 + tr(t))); }
+};
+
+template <int K, int D, bool DBG = false>
+__device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
+  using Geo = W4Geo<K, D>;
+  constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQ = Geo::PQ, RAW = Geo::RAW, WSLOTS = Geo::WSLOTS;
+  constexpr int NWU = Geo::NWU, XOFF = Geo::XOFF, NQ = Geo::NQ, LEAD = Geo::LEAD, PLANE = Geo::PLANE, PLF = Geo::PLF;
+  constexpr int NSTEP = Geo::NSTEP, NACC = Geo::NACC, CPS = Geo::CPS, KS = Geo::KS, RPW = KS / 4;
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  float* const raw = wl;                                   // [KC][RAW], producers only
+  float* const pl = wl + Geo::RAW_FLOATS;                  // two plane sets of PLF floats
+  if (v0 >= vend) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+  const int ntiles_all = vend - first;
+  const int nch = p.nchunks;                               // 32-channel chunks
+  const int nst = nch / CPS;                               // stages per tile
+  const int my_tiles = (vend - v0 + stride - 1) / stride;
+  const int nstages = my_tiles * nst;
+  auto locate = [&](int v, int& n0_, int& bz_, int& by_) {
+    const int tl = xcd_linear(v - first, ntiles_all, p.xcd);
+    const int t = tl / p.ntn;
+    bz_ = t / p.gy;
+    n0_ = (tl - t * p.ntn) * Geo::W;
+    by_ = t - bz_ * p.gy;
+  };
+
+  if (wave >= 4) {
+    // ================================================================= producer
+    const int pw_ = wave - 4;
+    constexpr int R4 = RAW / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;      // producer p owns channel rows RPW p .. RPW p + RPW - 1
+    constexpr int IPR = NQ * D, NIW = RPW * IPR, TPW = (NIW + 63) / 64;    // transform items: one window each
+    const long long ldb = (long long)p.x_ld * 4;
+    const float slope = p.pre_slope;
+    unsigned goff[SPW];
+    float* rdst[SPW];
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      const int it = min(lane + 64 * u, NGW - 1);
+      const int row = RPW * pw_ + it / R4, g4 = it % R4;
+      goff[u] = (unsigned)(row * p.x_ld + 4 * g4) * 4u;
+      rdst[u] = raw + row * RAW + 4 * g4;
+    }
+    const float* tsrc[TPW];
+    int tdst[TPW];                                         // float offset of the item's entry inside plane 0 of a set
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int it = min(lane + 64 * u, NIW - 1);
+      const int row = RPW * pw_ + it / IPR, e = it % IPR;
+      const int tq = e / D, tph = e - tq * D;
+      // D = 1: the sixteen-byte group that holds d1..d4 (LEAD = 3) or d0..d2 | d3..d5 (LEAD = 1) of the window starts at 4 tq (+ 4)
+      tsrc[u] = D == 1 ? raw + row * RAW + 4 * tq : raw + row * RAW + LEAD + 4 * tq * D + tph;
+      tdst[u] = row * PQ + e;
+    }
+    float4 v[SPW];
+    int n0 = 0, bz = 0, by = 0;
+    auto issue = [&](const char* xb_, int xs_, bool interior_, int ch) {
+      const char* cb = xb_ + (long long)ch * KS * ldb;
+      if (interior_) {
+        const char* ct = cb + (long long)xs_ * 4;
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) v[u] = *reinterpret_cast<const float4*>(ct + goff[u]);
+      } else {
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+          const int it = min(l_ + 64 * u, NGW - 1);
+          const int row = RPW * pw_ + it / R4, tg = xs_ + 4 * (it % R4);
+          v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)((tg >= 0 && tg + 3 < L) ? tg : 0) * 4);
+        }
+      }
+    };
+    locate(v0, n0, bz, by);
+    {
+      const int xs = n0 + XOFF;
+      issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs, xs >= 0 && xs + RAW <= L, 0);
+    }
+    int ti = 0, ch = 0;                                    // stage s = (tile ti, stage ch of the tile)
+    long long pc_all0 = 0, pc_bar = 0;
+    if constexpr (DBG) pc_all0 = (long long)__builtin_readcyclecounter();
+    for (int s_ = 0; s_ < nstages; ++s_) {
+      const int xs_start = n0 + XOFF;
+      const bool interior = xs_start >= 0 && xs_start + RAW <= L;
+      const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
+      // ---- publish own rows (lrelu, zero padding on edge tiles)
+      if (interior) {
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+          if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
+            float4 q = v[u];
+            wino_lrelu4(q, slope);
+            *reinterpret_cast<float4*>(rdst[u]) = q;
+          }
+        }
+      } else {
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+          if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
+            const int it = l_ + 64 * u;
+            const int row = RPW * pw_ + it / R4, tg = xs_start + 4 * (it % R4);
+            float4 q = v[u];
+            if (!(tg >= 0 && tg + 3 < L)) {
+              const float* xr = reinterpret_cast<const float*>(xb + (long long)(ch * KS + row) * ldb);
+              q.x = (tg >= 0 && tg < L) ? xr[tg] : 0.f;
+              q.y = (tg + 1 >= 0 && tg + 1 < L) ? xr[tg + 1] : 0.f;
+              q.z = (tg + 2 >= 0 && tg + 2 < L) ? xr[tg + 2] : 0.f;
+              q.w = (tg + 3 >= 0 && tg + 3 < L) ? xr[tg + 3] : 0.f;
+            }
+            wino_lrelu4(q, slope);
+            *reinterpret_cast<float4*>(rdst[u]) = q;
+          }
+        }
+      }
+      // ---- request the next stage's raw rows (next chunk, or chunk 0 of this workgroup's next tile)
+      int nti = ti, nchn = ch + 1, n0n = n0, bzn = bz, byn = by;
+      if (nchn == nst) { nchn = 0; ++nti; if (nti < my_tiles) locate(v0 + nti * stride, n0n, bzn, byn); }
+      if (s_ + 1 < nstages) {
+        const int xsn = n0n + XOFF;
+        issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= L, nchn);
+      }
+      // ---- transform own rows into plane set s & 1 (LDS operations of one wave execute in order: no barrier needed)
+      float* const pb = pl + (s_ & 1) * PLF;
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
+          const float* r = tsrc[u];
+          float* o = pb + tdst[u];
+          float d0, d1, d2, d3, d4, d5;
+          if constexpr (D == 1 && LEAD == 3) {
+            const float4 fm = *reinterpret_cast<const float4*>(r + 4);
+            d0 = r[3]; d1 = fm.x; d2 = fm.y; d3 = fm.z; d4 = fm.w; d5 = r[8];
+          } else if constexpr (D == 1) {
+            static_assert(D != 1 || LEAD == 3 || LEAD == 1, "window alignment");
+            const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
+            d0 = fa.y; d1 = fa.z; d2 = fa.w; d3 = fb.x; d4 = fb.y; d5 = fb.z;
+          } else {
+            d0 = r[0]; d1 = r[D]; d2 = r[2 * D]; d3 = r[3 * D]; d4 = r[4 * D]; d5 = r[5 * D];
+          }
+          const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);      // d4 - 4 d2, d3 - 4 d1
+          const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+          o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+          o[PLANE] = a_ + b_;
+          o[2 * PLANE] = a_ - b_;
+          o[3 * PLANE] = c_ + e_;
+          o[4 * PLANE] = c_ - e_;
+          o[5 * PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+          if constexpr (ND > 0) { o[6 * PLANE] = d1; o[7 * PLANE] = d2; o[8 * PLANE] = d3; o[9 * PLANE] = d4; }
+        }
+      }
+      long long pb0 = 0;
+      if constexpr (DBG) pb0 = (long long)__builtin_readcyclecounter();
+      __syncthreads();                                     // B_s: plane set s & 1 complete
+      if constexpr (DBG) pc_bar += (long long)__builtin_readcyclecounter() - pb0;
+      ti = nti; ch = nchn; n0 = n0n; bz = bzn; by = byn;
+    }
+    if constexpr (DBG) if (tid == 256) {                   // producer wave 0: total cycles, cycles spent waiting at the stage barriers
+      long long* d = p.dbg + 16 * (long long)(p.dbg_base + v0);
+      d[8] = (long long)__builtin_readcyclecounter() - pc_all0; d[9] = pc_bar;
+    }
+    return;
+  }
+
+  // =================================================================== consumer: row tile `wave`
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int uu = l31;
+  const unsigned pbase = (unsigned)(size_t)pl;
+  const unsigned baddr0 = pbase + (unsigned)(hi * PQ + uu) * 4u;
+  const unsigned wlane = (unsigned)lane * 16u;
+  f32x16 M[NACC];
+  float4 a[2][4];
+  // MFMA stream of one 32-channel chunk (chunk CC of the stage: plane rows 32 CC ..): NSTEP steps of four MFMAs, fragment
+  // reads two steps ahead in two register sets, the next weight slot's four float4 requested at the first step of each slot
+  // Weights stream through buffer loads: descriptor base = packed image, SGPR offset = (row tile, chunk, slot), VGPR offset =
+  // lane * 16, immediate = k-group.  The per-slot address arithmetic is then SALU only: a VALU instruction in the consumer
+  // stream costs the matrix pipe its issue time AND breaks the back-to-back forwarding of dependent MFMAs.
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
+  auto wload = [&](float4& dst, int soff, auto kg_c) {
+    constexpr int KGO = decltype(kg_c)::value * 1024;
+    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane + KGO, soff, 0);
+    dst = *reinterpret_cast<const float4*>(&t);
+  };
+  auto wload4 = [&](float4 (&dst)[4], int soff) {
+    wload(dst[0], soff, std::integral_constant<int, 0>{}); wload(dst[1], soff, std::integral_constant<int, 1>{});
+    wload(dst[2], soff, std::integral_constant<int, 2>{}); wload(dst[3], soff, std::integral_constant<int, 3>{});
+  };
+  // wa / wnext: byte offsets of the chunk's / the following chunk's slot 0 inside the image (wnext < 0: none)
+  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto par, auto cc) {
+    constexpr int PAR = decltype(par)::value, CC = decltype(cc)::value;
+    float fb[2][4];
+    auto request = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      if constexpr (T < NSTEP) wino_frag<PQ, Geo::plane(T) * PLANE + CC * KC * PQ, T % 4, Geo::colq(T) * D>(fb[T & 1], baddr);
+    };
+    auto step = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      constexpr int WS = Geo::wslot(T), KG = T % 4;
+      if constexpr (T < Geo::NGS ? KG == 0 : (T - Geo::NGS) % 16 == 0) {
+        if constexpr (WS + 1 < WSLOTS) wload4(a[(PAR + WS + 1) & 1], wa + (WS + 1) * 4096);
+        else if (wnext >= 0) wload4(a[(PAR + WS + 1) & 1], wnext);
+      }
+      {
+        float(&b)[4] = fb[T & 1];
+        if constexpr (T + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      }
+      const float4 av = a[(PAR + WS) & 1][KG];
+      constexpr int AC = Geo::acc(T);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) M[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[AC], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      request(std::integral_constant<int, T + 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    request(std::integral_constant<int, 0>{});
+    request(std::integral_constant<int, 1>{});
+    wino_static_for<0, NSTEP>(step);
+  };
+  auto wtile = [&](int mt_) -> int { return __builtin_amdgcn_readfirstlane(mt_ * nch * WSLOTS * 4096); };
+  const int lpart = 4 * (uu / D) * D + (uu % D);           // this lane's first output inside the tile (then + D, + 2D, + 3D)
+  const unsigned ylb = (unsigned)p.y_ld * 4u, rlb = (unsigned)p.res_ld * 4u;
+  unsigned yo4[4], ro4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    yo4[i] = (unsigned)((4 * hi + i) * p.y_ld + lpart) * 4u;
+    ro4[i] = (unsigned)((4 * hi + i) * p.res_ld + lpart) * 4u;
+  }
+  // fast epilogue: contiguous outputs (D = 1, L % 4 == 0: host), residual but no read-modify-write of y
+  const bool res_only = D == 1 && (p.flags & F_RES) && !(p.flags & F_ACC);
+  long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0;     // diagnostics (stamped build): consumer wave 0 of each workgroup
+  long long wall0 = 0;
+  if constexpr (DBG) { cyc_all0 = (long long)__builtin_readcyclecounter(); wall0 = (long long)wall_clock64(); }
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int n0, bz, by;
+    locate(v0 + ti * stride, n0, bz, by);
+    const int mt = by * 4 + wave;
+    const bool row_ok = mt < p.mtiles;
+    const int mtc = row_ok ? mt : p.mtiles - 1;
+    const int wt = wtile(mtc);
+    if (ti == 0) wload4(a[0], wt);
+    {   // the bias starts in M1: y0 and y2 contain M1 + M2, y1 and y3 contain M1 - M2, so all four outputs receive it once
+      const float* bias = p.bias + mtc * 32 + 4 * hi;
+#pragma unroll
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) M[q][i] = q == 1 ? bias[(i & 3) + 8 * (i >> 2)] : 0.f;
+    }
+    int wnext_tile = -1;
+    if (ti + 1 < my_tiles) {
+      int n0n, bzn, byn;
+      locate(v0 + (ti + 1) * stride, n0n, bzn, byn);
+      const int mtn = byn * 4 + wave;
+      wnext_tile = wtile(mtn < p.mtiles ? mtn : p.mtiles - 1);
+    }
+    const int ne = n0 + lpart;
+    const bool lane_ok = row_ok && uu < NWU && ne < L;
+    char* const ybase = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld + n0);
+    const char* const rbase = reinterpret_cast<const char*>(p.res + (long long)bz * p.res_bs + (long long)(mt * 32) * p.res_ld + n0);
+    float4 rvA[8];                                         // residual of accumulator rows 0..7, requested under the tile's last stage
+    auto stage = [&](int st_, auto par) {
+      const int s_ = ti * nst + st_;
+      long long c0 = 0, c1 = 0;
+      if constexpr (DBG) c0 = (long long)__builtin_readcyclecounter();
+      __syncthreads();                                     // B_s: plane set s & 1 is complete, set (s - 1) & 1 may be overwritten
+      if constexpr (DBG) c1 = (long long)__builtin_readcyclecounter();
+      if (st_ == nst - 1 && res_only && lane_ok) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rvA[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (r >> 2)) * rlb + ro4[r & 3]);
+      }
+      const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
+      const int wa = wt + (st_ * CPS) * WSLOTS * 4096;
+      if constexpr (CPS == 1) {
+        const int wnext = st_ + 1 < nst ? wa + WSLOTS * 4096 : wnext_tile;
+        mfma_chunk(baddr0 + off, wa, wnext, par, std::integral_constant<int, 0>{});
+      } else {
+        static_assert(CPS == 1 || (WSLOTS & 1) == 0, "two chunks per stage need an even slot count");
+        mfma_chunk(baddr0 + off, wa, wa + WSLOTS * 4096, par, std::integral_constant<int, 0>{});
+        const int wnext = st_ + 1 < nst ? wa + 2 * WSLOTS * 4096 : wnext_tile;
+        mfma_chunk(baddr0 + off, wa + WSLOTS * 4096, wnext, par, std::integral_constant<int, CPS - 1>{});
+      }
+      if constexpr (DBG) { cyc_bar += c1 - c0; cyc_mf += (long long)__builtin_readcyclecounter() - c1; }
+    };
+    if constexpr ((WSLOTS & 1) == 0) {
+      for (int st_ = 0; st_ < nst; ++st_) stage(st_, std::integral_constant<int, 0>{});
+    } else {                                               // odd slot count: the starting register set alternates; nch is even (host)
+      for (int st_ = 0; st_ < nst; st_ += 2) {
+        stage(st_, std::integral_constant<int, 0>{});
+        stage(st_ + 1, std::integral_constant<int, 1>{});
+      }
+    }
+    // ---- output transform + epilogue: the lane owns y[row][ne + r D], r = 0..3, for its 16 accumulator rows, four at a time
+    long long ce0 = 0;
+    if constexpr (DBG) ce0 = (long long)__builtin_readcyclecounter();
+    if (lane_ok) {
+      auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
+        constexpr int Q = decltype(q_c)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * Q + r;
+          const float t1 = M[1][i] + M[2][i], t2 = M[1][i] - M[2][i], t3 = M[3][i] + M[4][i], t4 = M[3][i] - M[4][i];
+          float y0 = M[0][i] + (t1 + t3);
+          float y1 = __builtin_fmaf(2.f, t4, t2);
+          float y2 = __builtin_fmaf(4.f, t3, t1);
+          float y3 = __builtin_fmaf(8.f, t4, t2) + M[5][i];
+          if constexpr (ND > 0) { y1 += M[6][i]; y2 += M[7][i]; }
+          vo[r] = make_float4(y0, y1, y2, y3);
+        }
+      };
+      auto divide = [&](float4 (&vo)[4]) {                 // x / div as x * (1 / div) with one residual correction (as conv_wino.hip)
+        const float dv = p.div, rc = 1.0f / dv;
+        auto dv1 = [&](float x) { const float q = x * rc; return __builtin_fmaf(__builtin_fmaf(-q, dv, x), rc, q); };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
+      };
+      if (res_only) {
+        if constexpr (D == 1) {
+          auto quarter = [&](auto q_c, const float4* rv) {
+            constexpr int Q = decltype(q_c)::value;
+            float4 vo[4];
+            ytrans(q_c, vo);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w; }
+            if (p.flags & F_DIV) divide(vo);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q) * ylb + yo4[r]) = vo[r];
+          };
+          quarter(std::integral_constant<int, 0>{}, rvA);
+          float4 rvB[8];                                   // requested once the first quarter's accumulator registers are free
+#pragma unroll
+          for (int r = 0; r < 8; ++r) rvB[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (2 + (r >> 2))) * rlb + ro4[r & 3]);
+          quarter(std::integral_constant<int, 1>{}, rvA + 4);
+          quarter(std::integral_constant<int, 2>{}, rvB);
+          quarter(std::integral_constant<int, 3>{}, rvB + 4);
+        }
+      } else {
+        const int nval = D == 1 ? 4 : min(4, (L - ne + D - 1) / D);      // outputs of this lane inside [0, L)
+        auto ld4 = [&](const char* q) -> float4 {
+          if constexpr (D == 1) return *reinterpret_cast<const float4*>(q);
+          else {
+            float4 t = make_float4(*reinterpret_cast<const float*>(q), 0.f, 0.f, 0.f);
+            if (nval > 1) t.y = *reinterpret_cast<const float*>(q + 4 * D);
+            if (nval > 2) t.z = *reinterpret_cast<const float*>(q + 8 * D);
+            if (nval > 3) t.w = *reinterpret_cast<const float*>(q + 12 * D);
+            return t;
+          }
+        };
+        auto quarter = [&](auto q_c) {
+          constexpr int Q = decltype(q_c)::value;
+          float4 vo[4];
+          ytrans(q_c, vo);
+          if (p.flags & F_RES) {
+            float4 rv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = ld4(rbase + (size_t)(8 * Q) * rlb + ro4[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w; }
+          }
+          if (p.flags & F_ACC) {
+            float4 yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = ld4(ybase + (size_t)(8 * Q) * ylb + yo4[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vo[r].x = yv[r].x + vo[r].x; vo[r].y = yv[r].y + vo[r].y; vo[r].z = yv[r].z + vo[r].z; vo[r].w = yv[r].w + vo[r].w; }
+          }
+          if (p.flags & F_DIV) divide(vo);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            char* q = ybase + (size_t)(8 * Q) * ylb + yo4[r];
+            if constexpr (D == 1) *reinterpret_cast<float4*>(q) = vo[r];
+            else {
+              *reinterpret_cast<float*>(q) = vo[r].x;
+              if (nval > 1) *reinterpret_cast<float*>(q + 4 * D) = vo[r].y;
+              if (nval > 2) *reinterpret_cast<float*>(q + 8 * D) = vo[r].z;
+              if (nval > 3) *reinterpret_cast<float*>(q + 12 * D) = vo[r].w;
+            }
+          }
+        };
+        quarter(std::integral_constant<int, 0>{});
+        quarter(std::integral_constant<int, 1>{});
+        quarter(std::integral_constant<int, 2>{});
+        quarter(std::integral_constant<int, 3>{});
+      }
+    }
+    if constexpr (DBG) cyc_epi += (long long)__builtin_readcyclecounter() - ce0;
+  }
+  if constexpr (DBG) if (tid == 0) {      // [workgroup][16]: 0 tiles, 1 total cycles, 2 barrier waits, 3 MFMA streams, 4 epilogues, 5 marker, 6 HW_ID, 7 XCC_ID
+    long long* d = p.dbg + 16 * (long long)(p.dbg_base + v0);
+    d[0] = my_tiles; d[1] = (long long)__builtin_readcyclecounter() - cyc_all0; d[2] = cyc_bar; d[3] = cyc_mf; d[4] = cyc_epi; d[5] = 4;
+    d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    d[7] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    d[10] = wall0; d[11] = (long long)wall_clock64();     // 100 MHz constant clock: effective shader clock = d[1] / (d[11] - d[10]) * 100 MHz
+  }
+}
+
+template <int K, int D, bool DBG>
+__global__ void __launch_bounds__(512, 2) conv_wino4_kernel(const WinoArgs p, const int total) {
+  wino4_problem<K, D, DBG>(p, blockIdx.x, total, 0, gridDim.x);
+}
+template <int K, int D>
+__device__ __forceinline__ void wino4_member(const WinoArgs& p, const int first, const int vend, const int b, const int G_) {
+  if (vend <= first) return;
+  int v0 = b - first % G_;
+  if (v0 < 0) v0 += G_;
+  wino4_problem<K, D>(p, v0 + first, vend, first, G_);
+}
+// the MRF chains' three convolutions of one step (k = 11 / 7 / 3) back to back in one persistent launch
+template <int D>
+__global__ void __launch_bounds__(512, 2) conv_wino4_group_kernel(const WinoGroup g) {
+  const int b = blockIdx.x, G_ = gridDim.x;
+  wino4_member<11, D>(g.a[0], 0, g.end[0], b, G_);
+  __syncthreads();
+  wino4_member<7, D>(g.a[1], g.end[0], g.end[1], b, G_);
+  __syncthreads();
+  wino4_member<3, D>(g.a[2], g.end[1], g.end[2], b, G_);
+}
+
+// ------------------------------------------------------------------ weight transform + packing
+// wp[m-tile][chunk][slot][k-group][lane][4] as pack_wino (conv_wino.hip) with slots = 6 G + ND: slot 6 g + p holds U_p of the
+// three-tap group g, slot 6 G + t the plain tap 4 t + 3.
+__global__ void pack_wino4_kernel(const float* __restrict__ src, const float* __restrict__ scale, float* __restrict__ wp, int Cin,
+                                  int Cout, int K, int nchunks, int slots, long long total) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int s = (int)(e & 3);
+  const int lane = (int)((e >> 2) & 63);
+  long long rest = e >> 8;
+  const int kg = (int)(rest & 3); rest >>= 2;
+  const int slot = (int)(rest % slots); rest /= slots;
+  const int ch = (int)(rest % nchunks);
+  const int mt = (int)(rest / nchunks);
+  const int row = mt * 32 + (lane & 31);
+  const int chan = ch * KC + 2 * (4 * kg + s) + (lane >> 5);
+  float val = 0.f;
+  if (row < Cout && chan < Cin) {
+    const float* w = src + ((long long)row * Cin + chan) * K;
+    const float sc = scale ? scale[row] : 1.0f;
+    const int G = (K + 1) / 4;
+    if (slot < 6 * G) {
+      const int g = slot / 6, pp = slot % 6;
+      const float w0 = w[4 * g] * sc, w1 = w[4 * g + 1] * sc, w2 = w[4 * g + 2] * sc;
+      switch (pp) {
+        case 0: val = 0.25f * w0; break;
+        case 1: val = -((w0 + w2) + w1) * (1.0f / 6.0f); break;
+        case 2: val = -((w0 + w2) - w1) * (1.0f / 6.0f); break;
+        case 3: val = ((w0 + 4.f * w2) + 2.f * w1) * (1.0f / 24.0f); break;
+        case 4: val = ((w0 + 4.f * w2) - 2.f * w1) * (1.0f / 24.0f); break;
+        default: val = w2; break;
+      }
+    } else {
+      val = w[4 * (slot - 6 * G) + 3] * sc;               // taps 3, 7
+    }
+  }
+  wp[e] = val;
+}
+
+int wino4_slots(int K) { const int G = (K + 1) / 4; return 6 * G + (G - 1); }
+
+int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st) {
+  const int nchunks = (Cin + KC - 1) / KC, mtiles = (Cout + 31) / 32, slots = wino4_slots(K);
+  const long long total = (long long)mtiles * nchunks * slots * 4 * 256;
+  hipLaunchKernelGGL(pack_wino4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_or_v, scale, wp4, Cin, Cout, K, nchunks,
+                     slots, total);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+
+// ------------------------------------------------------------------ launches
+bool wino4_enabled() {
+  static const bool on = !(getenv("SVOC_WINO_F4") && atoi(getenv("SVOC_WINO_F4")) == 0);      // SVOC_WINO_F4=0: the F(2,3) kernels
+  return on;
+}
+template <int K, int D>
+static size_t wino4_lds() { return (size_t)W4Geo<K, D>::LDS_BYTES; }
+int wino4_tile_w(int D) { return 4 * ((32 / D) * D); }
+
+template <int K, int D>
+static int wino4_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
+  static_assert(W4Geo<K, D>::LDS_BYTES <= 160 * 1024, "tile does not fit");
+  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
+  const size_t lds = wino4_lds<K, D>();
+  if (w.dbg) {                                             // stamped build (tools/wino4_timeline.py)
+    auto kern = conv_wino4_kernel<K, D, true>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
+  } else {
+    auto kern = conv_wino4_kernel<K, D, false>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
+  }
+  return SVOC_OK;
+}
+int wino4_launch(const WinoArgs& w, int K, int D, long long total, hipStream_t st) {
+  int rc = 1;
+#define SVOC_W4(KK, DD) if (K == KK && D == DD) rc = wino4_launch_one<KK, DD>(w, total, st);
+  SVOC_W4(3, 1) SVOC_W4(7, 1) SVOC_W4(11, 1) SVOC_W4(3, 3) SVOC_W4(7, 3) SVOC_W4(11, 3) SVOC_W4(3, 5) SVOC_W4(7, 5) SVOC_W4(11, 5)
+#undef SVOC_W4
+  return rc;
+}
+template <int D>
+static int wino4_launch_group_d(const WinoGroup& g, long long total, hipStream_t st) {
+  auto kern = conv_wino4_group_kernel<D>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const size_t l11 = wino4_lds<11, D>(), l7 = wino4_lds<7, D>(), l3 = wino4_lds<3, D>();
+  const size_t lds = std::max(l11, std::max(l7, l3));
+  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
+  return SVOC_OK;
+}
+int wino4_launch_group(const WinoGroup& g, int D, long long total, hipStream_t st) {
+  return D == 1 ? wino4_launch_group_d<1>(g, total, st) : (D == 3 ? wino4_launch_group_d<3>(g, total, st) : wino4_launch_group_d<5>(g, total, st));
+}
+
+}  // namespace svoc

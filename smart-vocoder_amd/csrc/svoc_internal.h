@@ -172,6 +172,7 @@ int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, i
 // conv_wino.hip: Winograd F(2,3) form of the big convolutions (k = 3 / 7 / 11, dilation 1 / 3 / 5, C >= 64): 1/3 fewer MFMAs
 struct PackedWino {
   DevBuf wp, bias;
+  DevBuf wp4;                     // F(4,3) image (conv_wino4.hip), present when that form is enabled and the shape is eligible
   int Cin = 0, Cout = 0, K = 0, nchunks = 0, mtiles = 0, slots = 0;
   double flops_per_col = 0;       // algorithmic 2*MAC of the convolution per output column
 };

@@ -24,8 +24,8 @@ with torch.no_grad():
     net.infer(mel, lengths, noise_scale=0.667, eps=eps)
 torch.cuda.synchronize()
 
-interval = 2000                                   # 20 us per sample
-nsamples = 40000                                  # up to 0.8 s
+interval = 5000                                   # 50 us per sample
+nsamples = 40000                                  # up to 2 s
 buf = torch.zeros(nsamples * 3, dtype=torch.long, device="cuda")
 marks = torch.zeros(2 * steps + 2, dtype=torch.long, device="cuda")
 stop = torch.zeros(1, dtype=torch.int32, device="cuda")
