@@ -108,8 +108,8 @@ def cpu_baseline(sd_np, seed, keep=None):
 def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     """Per-launch duration of the dominant kernel, measured live with HIP events on the launch stream by the library's
     event profiler (every GEMM-family launch bracketed by hipEventRecord): the grouped launch of the C=128 stage's
-    three undilated convolutions k=11/7/3 (conv_wino_ws_group_kernel<1>, Winograd F(2,3) form; conv_group_kernel when
-    SVOC_WINO=0).  Runs after the timed region."""
+    three undilated convolutions k=11/7/3 (conv_wino4_group_kernel<1,4>, Winograd F(4,3) form; conv_wino_ws_group_kernel<1>,
+    F(2,3), when SVOC_WINO_F4=0; conv_group_kernel when SVOC_WINO=0).  Runs after the timed region."""
     from smart_vocoder_amd import _native
     _native.profile_enable(True)
     with torch.no_grad():
@@ -120,12 +120,12 @@ def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     _native.profile_enable(False)
     best = None
     for line in rep.splitlines():
-        if not (line.startswith("group ") or line.startswith("winoG ")):
+        if not (line.startswith("group ") or line.startswith("winoG ") or line.startswith("wino4G ")):
             continue
         f = line.split()
         n, total_ms, mean_us, tfl = int(f[-4]), float(f[-3]), float(f[-2]), float(f[-1])
         if best is None or total_ms > best["total_ms"]:
-            best = dict(desc=" ".join(f[:-4]), n=n, total_ms=total_ms, mean_us=mean_us, tflops=tfl, wino=line.startswith("winoG "))
+            best = dict(desc=" ".join(f[:-4]), n=n, total_ms=total_ms, mean_us=mean_us, tflops=tfl, wino=line.startswith("winoG "), wino4=line.startswith("wino4G "))
     return best, rep
 
 
@@ -314,9 +314,9 @@ def main():
                            "winograd_form_floor_ms": stats["executed_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "direct_form_floor_ms": stats["conv_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino(_ws)(_group)_kernel (Winograd F(2,3)), conv_mfma_kernel, conv_group_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group)_kernel (Winograd F(4,3), C>=64 ResBlock convolutions), conv_mfma_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel (fallbacks: conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
                            "note": "achieved/frac = algorithmic direct-form 2*MAC of the convolutions (SURVEY.md 8d) / time: with the Winograd F(2,3) kernels "
-                                   "(which issue 2/3, 5/7, 8/11 of those multiply-adds for k=3/7/11) the direct-form peak is NOT a bound on it; "
+                                   "(which issue 1/2, 4/7, 6.5/11 of those multiply-adds for k=3/7/11 in F(4,3) form) the direct-form peak is NOT a bound on it; "
                                    "achieved_executed/frac_executed = 2*MAC the matrix pipe really issued (counted per launch by the library) / time, "
                                    "bounded by the peak; winograd_form_floor_ms = executed FLOPs of one step at 157.3 TFLOP/s",
                            "gemm_launches_per_step": stats["conv_launches"] / args.steps,
@@ -326,12 +326,14 @@ def main():
                            "gpu_ms_per_step_rank0": gpu_ms / args.steps}
         if dom:
             # Winograd form: the launch computes the same convolutions (same algorithmic 2*MAC) while
-            # issuing (8 + 5 + 2) / (11 + 7 + 3) of them as MFMAs, so `achieved` (algorithmic) may exceed the direct-form
-            # MFMA peak; `mfma_pipe_frac` prices the multiply-adds the matrix pipe really executed
-            executed = 15.0 / 21.0 if dom["wino"] else 1.0
+            # issuing (6.5 + 4 + 1.5) / (11 + 7 + 3) of them as MFMAs (F(4,3); F(2,3): (8 + 5 + 2) / 21), so `achieved`
+            # (algorithmic) may exceed the direct-form MFMA peak; `mfma_pipe_frac` prices the multiply-adds the matrix
+            # pipe really executed
+            executed = 12.0 / 21.0 if dom["wino4"] else (15.0 / 21.0 if dom["wino"] else 1.0)
             res["roofline"]["dominant_kernel"] = {
-                "name": (("conv_wino_group_kernel<1> " if os.environ.get("SVOC_WINO_WS") == "0" else "conv_wino_ws_group_kernel<1> ")
-                         if dom["wino"] else "conv_group_kernel<2,2,2,2> ") + dom["desc"],
+                "name": ("conv_wino4_group_kernel<1,4> " if dom["wino4"] else
+                         (("conv_wino_group_kernel<1> " if os.environ.get("SVOC_WINO_WS") == "0" else "conv_wino_ws_group_kernel<1> ")
+                          if dom["wino"] else "conv_group_kernel<2,2,2,2> ")) + dom["desc"],
                 "launches_measured": dom["n"], "avg_launch_us": dom["mean_us"],
                 "flop_per_launch": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6,
                 "achieved": dom["tflops"], "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,

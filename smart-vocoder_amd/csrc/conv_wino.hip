@@ -948,10 +948,10 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
 // conv_wino4.hip: the F(4,3) form
 bool wino4_enabled();
 int wino4_slots(int K);
-int wino4_tile_w(int D);
+int wino4_tile_w(int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
-int wino4_launch(const WinoArgs& w, int K, int D, long long total, hipStream_t st);
-int wino4_launch_group(const WinoGroup& g, int D, long long total, hipStream_t st);
+int wino4_launch(const WinoArgs& w, int K, int D, int NC, long long total, hipStream_t st);
+int wino4_launch_group(const WinoGroup& g, int D, int NC, long long total, hipStream_t st);
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
@@ -977,7 +977,7 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
   hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_or_v, g ? scale.f() : nullptr,
                      pw.wp.f(), Cin, Cout, K, pw.nchunks, pw.slots, total);
   hipLaunchKernelGGL(wino_bias_kernel, dim3((pw.mtiles * 32 + 255) / 256), dim3(256), 0, st, bias, pw.bias.f(), Cout, pw.mtiles * 32);
-  if (wino4_enabled() && pw.mtiles % 4 == 0 && (pw.nchunks & 1) == 0) {   // F(4,3) image: 4 x 1 wave layout only, even chunk counts
+  if (wino4_enabled() && pw.mtiles % 2 == 0 && (pw.nchunks & 1) == 0) {   // F(4,3) image: 64- or 128-row blocks, even chunk counts
     const long long total4 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K) * 4 * 256;
     SVOC_TRY(pw.wp4.ensure((size_t)(total4 + 1024) * sizeof(float)));
     SVOC_HIP(hipMemsetAsync(pw.wp4.f() + total4, 0, 1024 * sizeof(float), st));
@@ -1093,6 +1093,7 @@ static double wino_exec_ratio(int K) { const int G = (K + 1) / 4; return (2.0 * 
 
 // F(4,3) form (conv_wino4.hip): four-row-tile blocks; dilation 1 additionally needs 16-byte aligned rows of a length that is a multiple of four
 static double wino4_exec_ratio(int K) { const int G = (K + 1) / 4; return (1.5 * G + (G - 1)) / (double)K; }
+static int wino4_nc(const PackedWino& pw) { return pw.mtiles % 4 == 0 ? 4 : 2; }      // row tiles per workgroup: 128- or 64-row blocks
 static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const WinoArgs& w, WinoArgs& w4) {
   if (!wino4_enabled() || !pw.wp4.p || !(dil == 1 || dil == 3 || dil == 5) || (dil == 1 && (a.Ncols & 3))) return false;
   const EpiOut& o = a.out[0];
@@ -1102,9 +1103,9 @@ static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const W
   }
   w4 = w;
   w4.wp = pw.wp4.f();
-  const int W = wino4_tile_w(dil);
+  const int W = wino4_tile_w(dil, wino4_nc(pw));
   w4.ntn = (a.Ncols + W - 1) / W;
-  w4.gy = pw.mtiles / 4;
+  w4.gy = pw.mtiles / wino4_nc(pw);
   return true;
 }
 
@@ -1118,7 +1119,7 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
   if ((long long)w.ntn * w.gy * variant_batch(B) < min_tiles || total > 0x7fffffffLL) return 1;    // short inputs: the direct / K-split kernels
   const double flops = pw.flops_per_col * (double)B * (double)a.Ncols;
   WinoArgs w4;
-  const bool f4 = WM == 4 && wino4_args(pw, a, dil, w, w4);
+  const bool f4 = wino4_args(pw, a, dil, w, w4);
   stats_add_conv(flops, 1, flops * (f4 ? wino4_exec_ratio(pw.K) : wino_exec_ratio(pw.K)));
   int prof_idx = -1;
   if (prof_enabled()) {
@@ -1128,7 +1129,7 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
   }
   int rc = SVOC_OK;
   if (f4) {
-    rc = wino4_launch(w4, pw.K, dil, (long long)w4.ntn * w4.gy * B, st);
+    rc = wino4_launch(w4, pw.K, dil, wino4_nc(pw), (long long)w4.ntn * w4.gy * B, st);
     prof_end(st, prof_idx);
     if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
     SVOC_HIP(hipGetLastError());
@@ -1169,7 +1170,7 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
     exec_flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino_exec_ratio(pws[i]->K);
     exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K);
-    f4 = f4 && WM == 4 && wino4_args(*pws[i], as[i], dil, g.a[i], g4.a[i]);
+    f4 = f4 && wino4_nc(*pws[i]) == wino4_nc(*pws[0]) && wino4_args(*pws[i], as[i], dil, g.a[i], g4.a[i]);
     if (f4) { total4 += (long long)g4.a[i].ntn * g4.a[i].gy * B; g4.end[i] = (int)total4; g4.k[i] = pws[i]->K; }
     const int K = pws[i]->K;
     size_t l = 0;
@@ -1188,7 +1189,7 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
-  if (f4) rc = wino4_launch_group(g4, dil, total4, st);
+  if (f4) rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), total4, st);
   else if (wino_ws_on() && WM == 4 && dil <= 3 && n == 3 && pws[0]->K == 11 && pws[1]->K == 7 && pws[2]->K == 3 && (pws[1]->nchunks & 1) == 0)
     rc = dil == 1 ? wino_ws_launch_group<1>(g, total, st) : wino_ws_launch_group<3>(g, total, st);
   else if (WM == 4) rc = dil == 1 ? wino_launch_group<1, 4>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 4>(g, total, lds, st) : wino_launch_group<5, 4>(g, total, lds, st));

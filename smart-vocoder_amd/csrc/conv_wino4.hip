@@ -36,22 +36,29 @@ namespace svoc {
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-template <int K, int D>
+// NRT = row tiles per workgroup.  The four consumers are 4 x 1 (NRT = 4: 128 rows x 32 windows, C % 128 == 0) or 2 x 2
+// (NRT = 2: 64 rows x 64 windows, C = 64) - always one consumer per SIMD (a first 64-row variant with two consumers and two
+// producers per workgroup, two workgroups per CU, put both workgroups' consumers on the same two SIMDs and ran at 45 % of the
+// pipe: profiles/r03_f_winograd_f43_c64_null.txt).  Channels per stage KS: 32 (one weight chunk); 64 for k = 3 with NRT = 4
+// (only 96 MFMAs per chunk and consumer: two chunks per stage; the plane sets of k = 7 / 11 would not fit twice); with NRT = 2
+// the planes are twice as wide, so k = 7 / 11 stage 16 channels = half a weight chunk (k-groups {0,1} or {2,3} of every slot).
+template <int K, int D, int NRT = 4>
 struct W4Geo {
-  // 32-channel chunks per stage: k = 3 carries only 96 MFMAs per chunk and consumer, so its stages hold two chunks (fewer
-  // barriers; the plane sets of k = 7 / 11 would not fit twice)
-  static constexpr int CPS = (K == 3 && D == 1) ? 2 : 1;
-  static constexpr int KS = CPS * KC;                     // channels per stage
+  static constexpr int NCT = 4 / NRT;                     // column tiles (of 32 windows) per workgroup
+  static constexpr int KS = NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32);   // channels per stage
+  static constexpr int CPS = KS >= KC ? KS / KC : 1;      // weight chunks per stage
+  static constexpr int HALVES = KS < KC ? KC / KS : 1;    // stages per weight chunk
+  static constexpr int KGS = KS < KC ? KS / 8 : 4;        // k-groups (of 8 channels = 4 k-steps) per stage and chunk
   static constexpr int G = (K + 1) / 4;                   // three-tap groups at tap offsets 0, 4, 8
   static constexpr int ND = G - 1;                        // left-over single taps (3, 7)
   static constexpr int PADT = (K - 1) / 2;                // padding in taps (columns: PADT * D)
   static constexpr int WSLOTS = 6 * G + ND;               // weight slots per 32-channel chunk
-  static constexpr int NGS = 24 * G;                      // steps (4 MFMAs each) of the groups; a tap adds 16 steps
-  static constexpr int NSTEP = NGS + 16 * ND;
+  static constexpr int NGS = 6 * G * KGS;                 // steps (4 MFMAs each) of the groups; a tap adds 4 * KGS steps
+  static constexpr int NSTEP = NGS + 4 * KGS * ND;
   static constexpr int QB = 32 / D;                       // q blocks per tile
   static constexpr int NWU = QB * D;                      // windows (lanes) per tile
-  static constexpr int W = 4 * NWU;                       // output columns per tile (128 / 120 / 120)
-  static constexpr int NQ = QB + G - 1;                   // windows per phase and row
+  static constexpr int W = 4 * NWU * NCT;                 // output columns per workgroup tile (NCT x 128 / 120 / 120)
+  static constexpr int NQ = NCT * QB + G - 1;             // windows per phase and row
   static constexpr int PQ = NQ * D;                       // plane entries per row: entry q' * D + phase
   static constexpr int XOFF = -((PADT * D + 3) & ~3);     // raw tile starts at n0 + XOFF (multiple of 4)
   static constexpr int LEAD = -XOFF - PADT * D;           // raw index of d0 of window 0, phase 0
@@ -65,19 +72,21 @@ struct W4Geo {
   static constexpr int LDS_BYTES = (RAW_FLOATS + 2 * PLF) * 4;
   // step t of a chunk: which weight slot, plane, column (in windows) and accumulator
   static constexpr bool tap(int t) { return t >= NGS; }
-  static constexpr int tr(int t) { return ((t - NGS) % 16) / 4; }                        // tap steps: output index r
-  static constexpr int wslot(int t) { return t < NGS ? t / 4 : 6 * G + (t - NGS) / 16; }
-  static constexpr int plane(int t) { return t < NGS ? (t / 4) % 6 : 6 + (tr(t) + 2) % 4; }
-  static constexpr int colq(int t) { return t < NGS ? (t / 4) / 6 : (t - NGS) / 16 + (tr(t) + 2) / 4; }
-  static constexpr int acc(int t) { return t < NGS ? (t / 4) % 6 : (tr(t) == 0 ? 0 : (tr(t) == 3 ? 5 : 5 + tr(t))); }
+  static constexpr int tr(int t) { return ((t - NGS) % (4 * KGS)) / KGS; }               // tap steps: output index r
+  static constexpr int kgi(int t) { return t % KGS; }                                    // k-group of the step inside the stage
+  static constexpr bool slot_first(int t) { return t < NGS ? t % KGS == 0 : (t - NGS) % (4 * KGS) == 0; }
+  static constexpr int wslot(int t) { return t < NGS ? t / KGS : 6 * G + (t - NGS) / (4 * KGS); }
+  static constexpr int plane(int t) { return t < NGS ? (t / KGS) % 6 : 6 + (tr(t) + 2) % 4; }
+  static constexpr int colq(int t) { return t < NGS ? (t / KGS) / 6 : (t - NGS) / (4 * KGS) + (tr(t) + 2) / 4; }
+  static constexpr int acc(int t) { return t < NGS ? (t / KGS) % 6 : (tr(t) == 0 ? 0 : (tr(t) == 3 ? 5 : 5 + tr(t))); }
 };
 
-template <int K, int D, bool DBG = false>
+template <int K, int D, int NRT = 4, bool DBG = false>
 __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
-  using Geo = W4Geo<K, D>;
+  using Geo = W4Geo<K, D, NRT>;
   constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQ = Geo::PQ, RAW = Geo::RAW, WSLOTS = Geo::WSLOTS;
   constexpr int NWU = Geo::NWU, XOFF = Geo::XOFF, NQ = Geo::NQ, LEAD = Geo::LEAD, PLANE = Geo::PLANE, PLF = Geo::PLF;
-  constexpr int NSTEP = Geo::NSTEP, NACC = Geo::NACC, CPS = Geo::CPS, KS = Geo::KS, RPW = KS / 4;
+  constexpr int NSTEP = Geo::NSTEP, NACC = Geo::NACC, CPS = Geo::CPS, KS = Geo::KS, RPW = KS / 4, HALVES = Geo::HALVES, KGS = Geo::KGS;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* const raw = wl;                                   // [KC][RAW], producers only
   float* const pl = wl + Geo::RAW_FLOATS;                  // two plane sets of PLF floats
@@ -88,7 +97,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   const int L = p.L;
   const int ntiles_all = vend - first;
   const int nch = p.nchunks;                               // 32-channel chunks
-  const int nst = nch / CPS;                               // stages per tile
+  const int nst = nch * HALVES / CPS;                      // stages per tile
   const int my_tiles = (vend - v0 + stride - 1) / stride;
   const int nstages = my_tiles * nst;
   auto locate = [&](int v, int& n0_, int& bz_, int& by_) {
@@ -237,15 +246,16 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     return;
   }
 
-  // =================================================================== consumer: row tile `wave`
+  // =================================================================== consumer: row tile rt, column tile ct of the workgroup
   const int l31 = lane & 31, hi = lane >> 5;
-  const int uu = l31;
+  const int rt = NRT == 4 ? wave : (wave & 1), ct = NRT == 4 ? 0 : (wave >> 1);
+  const int uu = ct * NWU + l31;                           // this lane's window inside the workgroup tile
   const unsigned pbase = (unsigned)(size_t)pl;
   const unsigned baddr0 = pbase + (unsigned)(hi * PQ + uu) * 4u;
   const unsigned wlane = (unsigned)lane * 16u;
   f32x16 M[NACC];
-  float4 a[2][4];
-  // MFMA stream of one 32-channel chunk (chunk CC of the stage: plane rows 32 CC ..): NSTEP steps of four MFMAs, fragment
+  float4 a[2][KGS];
+  // MFMA stream of one 32-channel chunk (chunk CC of the stage: plane rows 32 CC ..) or of half HF of a chunk (KS = 16): NSTEP steps of four MFMAs, fragment
   // reads two steps ahead in two register sets, the next weight slot's four float4 requested at the first step of each slot
   // Weights stream through buffer loads: descriptor base = packed image, SGPR offset = (row tile, chunk, slot), VGPR offset =
   // lane * 16, immediate = k-group.  The per-slot address arithmetic is then SALU only: a VALU instruction in the consumer
@@ -256,24 +266,27 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane + KGO, soff, 0);
     dst = *reinterpret_cast<const float4*>(&t);
   };
-  auto wload4 = [&](float4 (&dst)[4], int soff) {
-    wload(dst[0], soff, std::integral_constant<int, 0>{}); wload(dst[1], soff, std::integral_constant<int, 1>{});
-    wload(dst[2], soff, std::integral_constant<int, 2>{}); wload(dst[3], soff, std::integral_constant<int, 3>{});
+  auto wload4 = [&](float4 (&dst)[KGS], int soff, auto hf) {       // the KGS k-groups of half HF of a slot
+    constexpr int K0 = decltype(hf)::value * KGS;
+    wload(dst[0], soff, std::integral_constant<int, K0>{}); wload(dst[1], soff, std::integral_constant<int, K0 + 1>{});
+    if constexpr (KGS == 4) { wload(dst[2], soff, std::integral_constant<int, K0 + 2>{}); wload(dst[3], soff, std::integral_constant<int, K0 + 3>{}); }
   };
   // wa / wnext: byte offsets of the chunk's / the following chunk's slot 0 inside the image (wnext < 0: none)
-  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto par, auto cc) {
-    constexpr int PAR = decltype(par)::value, CC = decltype(cc)::value;
+  // wnext belongs to half NHF (the other half of the same chunk when HALVES == 2 and HF == 0, else half 0 of the next chunk)
+  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto par, auto cc, auto hf) {
+    constexpr int PAR = decltype(par)::value, CC = decltype(cc)::value, HF = decltype(hf)::value;
+    constexpr int NHF = (HALVES == 2 && HF == 0) ? 1 : 0;
     float fb[2][4];
     auto request = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
-      if constexpr (T < NSTEP) wino_frag<PQ, Geo::plane(T) * PLANE + CC * KC * PQ, T % 4, Geo::colq(T) * D>(fb[T & 1], baddr);
+      if constexpr (T < NSTEP) wino_frag<PQ, Geo::plane(T) * PLANE + CC * KC * PQ, Geo::kgi(T), Geo::colq(T) * D>(fb[T & 1], baddr);
     };
     auto step = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
-      constexpr int WS = Geo::wslot(T), KG = T % 4;
-      if constexpr (T < Geo::NGS ? KG == 0 : (T - Geo::NGS) % 16 == 0) {
-        if constexpr (WS + 1 < WSLOTS) wload4(a[(PAR + WS + 1) & 1], wa + (WS + 1) * 4096);
-        else if (wnext >= 0) wload4(a[(PAR + WS + 1) & 1], wnext);
+      constexpr int WS = Geo::wslot(T), KG = Geo::kgi(T);
+      if constexpr (Geo::slot_first(T)) {
+        if constexpr (WS + 1 < WSLOTS) wload4(a[(PAR + WS + 1) & 1], wa + (WS + 1) * 4096, hf);
+        else if (wnext >= 0) wload4(a[(PAR + WS + 1) & 1], wnext, std::integral_constant<int, NHF>{});
       }
       {
         float(&b)[4] = fb[T & 1];
@@ -309,11 +322,11 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   for (int ti = 0; ti < my_tiles; ++ti) {
     int n0, bz, by;
     locate(v0 + ti * stride, n0, bz, by);
-    const int mt = by * 4 + wave;
+    const int mt = by * NRT + rt;
     const bool row_ok = mt < p.mtiles;
     const int mtc = row_ok ? mt : p.mtiles - 1;
     const int wt = wtile(mtc);
-    if (ti == 0) wload4(a[0], wt);
+    if (ti == 0) wload4(a[0], wt, std::integral_constant<int, 0>{});
     {   // the bias starts in M1: y0 and y2 contain M1 + M2, y1 and y3 contain M1 - M2, so all four outputs receive it once
       const float* bias = p.bias + mtc * 32 + 4 * hi;
 #pragma unroll
@@ -325,15 +338,16 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     if (ti + 1 < my_tiles) {
       int n0n, bzn, byn;
       locate(v0 + (ti + 1) * stride, n0n, bzn, byn);
-      const int mtn = byn * 4 + wave;
+      const int mtn = byn * NRT + rt;
       wnext_tile = wtile(mtn < p.mtiles ? mtn : p.mtiles - 1);
     }
     const int ne = n0 + lpart;
-    const bool lane_ok = row_ok && uu < NWU && ne < L;
+    const bool lane_ok = row_ok && l31 < NWU && ne < L;
     char* const ybase = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld + n0);
     const char* const rbase = reinterpret_cast<const char*>(p.res + (long long)bz * p.res_bs + (long long)(mt * 32) * p.res_ld + n0);
     float4 rvA[8];                                         // residual of accumulator rows 0..7, requested under the tile's last stage
-    auto stage = [&](int st_, auto par) {
+    auto stage = [&](int st_, auto par, auto hf) {
+      constexpr int HF = decltype(hf)::value;
       const int s_ = ti * nst + st_;
       long long c0 = 0, c1 = 0;
       if constexpr (DBG) c0 = (long long)__builtin_readcyclecounter();
@@ -344,24 +358,37 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
         for (int r = 0; r < 8; ++r) rvA[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (r >> 2)) * rlb + ro4[r & 3]);
       }
       const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
-      const int wa = wt + (st_ * CPS) * WSLOTS * 4096;
-      if constexpr (CPS == 1) {
+      constexpr auto c0_ = std::integral_constant<int, 0>{};
+      if constexpr (HALVES == 2) {                         // half a chunk per stage: the same slots again for the second half
+        const int wa = wt + (st_ >> 1) * WSLOTS * 4096;
+        const int wnext = HF == 0 ? wa : (st_ + 1 < nst ? wa + WSLOTS * 4096 : wnext_tile);
+        mfma_chunk(baddr0 + off, wa, wnext, par, c0_, hf);
+      } else if constexpr (CPS == 1) {
+        const int wa = wt + st_ * WSLOTS * 4096;
         const int wnext = st_ + 1 < nst ? wa + WSLOTS * 4096 : wnext_tile;
-        mfma_chunk(baddr0 + off, wa, wnext, par, std::integral_constant<int, 0>{});
+        mfma_chunk(baddr0 + off, wa, wnext, par, c0_, c0_);
       } else {
         static_assert(CPS == 1 || (WSLOTS & 1) == 0, "two chunks per stage need an even slot count");
-        mfma_chunk(baddr0 + off, wa, wa + WSLOTS * 4096, par, std::integral_constant<int, 0>{});
+        const int wa = wt + (st_ * CPS) * WSLOTS * 4096;
+        mfma_chunk(baddr0 + off, wa, wa + WSLOTS * 4096, par, c0_, c0_);
         const int wnext = st_ + 1 < nst ? wa + 2 * WSLOTS * 4096 : wnext_tile;
-        mfma_chunk(baddr0 + off, wa + WSLOTS * 4096, wnext, par, std::integral_constant<int, CPS - 1>{});
+        mfma_chunk(baddr0 + off, wa + WSLOTS * 4096, wnext, par, std::integral_constant<int, CPS - 1>{}, c0_);
       }
       if constexpr (DBG) { cyc_bar += c1 - c0; cyc_mf += (long long)__builtin_readcyclecounter() - c1; }
     };
-    if constexpr ((WSLOTS & 1) == 0) {
-      for (int st_ = 0; st_ < nst; ++st_) stage(st_, std::integral_constant<int, 0>{});
-    } else {                                               // odd slot count: the starting register set alternates; nch is even (host)
+    // the register set of a stage's first slot alternates when a stage has an odd number of slots (k = 7); stages come in
+    // pairs then (nch is even: host), as they do when a chunk is two stages
+    if constexpr (HALVES == 2) {
       for (int st_ = 0; st_ < nst; st_ += 2) {
-        stage(st_, std::integral_constant<int, 0>{});
-        stage(st_ + 1, std::integral_constant<int, 1>{});
+        stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        stage(st_ + 1, std::integral_constant<int, WSLOTS & 1>{}, std::integral_constant<int, 1>{});
+      }
+    } else if constexpr ((WSLOTS & 1) == 0) {
+      for (int st_ = 0; st_ < nst; ++st_) stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    } else {
+      for (int st_ = 0; st_ < nst; st_ += 2) {
+        stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        stage(st_ + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
       }
     }
     // ---- output transform + epilogue: the lane owns y[row][ne + r D], r = 0..3, for its 16 accumulator rows, four at a time
@@ -468,26 +495,26 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   }
 }
 
-template <int K, int D, bool DBG>
+template <int K, int D, int NRT, bool DBG>
 __global__ void __launch_bounds__(512, 2) conv_wino4_kernel(const WinoArgs p, const int total) {
-  wino4_problem<K, D, DBG>(p, blockIdx.x, total, 0, gridDim.x);
+  wino4_problem<K, D, NRT, DBG>(p, blockIdx.x, total, 0, gridDim.x);
 }
-template <int K, int D>
+template <int K, int D, int NRT>
 __device__ __forceinline__ void wino4_member(const WinoArgs& p, const int first, const int vend, const int b, const int G_) {
   if (vend <= first) return;
   int v0 = b - first % G_;
   if (v0 < 0) v0 += G_;
-  wino4_problem<K, D>(p, v0 + first, vend, first, G_);
+  wino4_problem<K, D, NRT>(p, v0 + first, vend, first, G_);
 }
 // the MRF chains' three convolutions of one step (k = 11 / 7 / 3) back to back in one persistent launch
-template <int D>
+template <int D, int NRT>
 __global__ void __launch_bounds__(512, 2) conv_wino4_group_kernel(const WinoGroup g) {
   const int b = blockIdx.x, G_ = gridDim.x;
-  wino4_member<11, D>(g.a[0], 0, g.end[0], b, G_);
+  wino4_member<11, D, NRT>(g.a[0], 0, g.end[0], b, G_);
   __syncthreads();
-  wino4_member<7, D>(g.a[1], g.end[0], g.end[1], b, G_);
+  wino4_member<7, D, NRT>(g.a[1], g.end[0], g.end[1], b, G_);
   __syncthreads();
-  wino4_member<3, D>(g.a[2], g.end[1], g.end[2], b, G_);
+  wino4_member<3, D, NRT>(g.a[2], g.end[1], g.end[2], b, G_);
 }
 
 // ------------------------------------------------------------------ weight transform + packing
@@ -545,45 +572,47 @@ bool wino4_enabled() {
   static const bool on = !(getenv("SVOC_WINO_F4") && atoi(getenv("SVOC_WINO_F4")) == 0);      // SVOC_WINO_F4=0: the F(2,3) kernels
   return on;
 }
-template <int K, int D>
-static size_t wino4_lds() { return (size_t)W4Geo<K, D>::LDS_BYTES; }
-int wino4_tile_w(int D) { return 4 * ((32 / D) * D); }
+template <int K, int D, int NRT>
+static size_t wino4_lds() { return (size_t)W4Geo<K, D, NRT>::LDS_BYTES; }
+int wino4_tile_w(int D, int NRT) { return 4 * ((32 / D) * D) * (4 / NRT); }
+// one persistent workgroup per CU (eight waves of up to 256 registers)
+static unsigned wino4_grid(long long total) { return (unsigned)std::min<long long>(total, (long long)device_cu_count()); }
 
-template <int K, int D>
+template <int K, int D, int NRT>
 static int wino4_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
-  static_assert(W4Geo<K, D>::LDS_BYTES <= 160 * 1024, "tile does not fit");
-  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
-  const size_t lds = wino4_lds<K, D>();
+  static_assert(W4Geo<K, D, NRT>::LDS_BYTES <= 160 * 1024, "tile does not fit");
+  const unsigned grid = wino4_grid(total);
+  const size_t lds = wino4_lds<K, D, NRT>();
   if (w.dbg) {                                             // stamped build (tools/wino4_timeline.py)
-    auto kern = conv_wino4_kernel<K, D, true>;
+    auto kern = conv_wino4_kernel<K, D, NRT, true>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
   } else {
-    auto kern = conv_wino4_kernel<K, D, false>;
+    auto kern = conv_wino4_kernel<K, D, NRT, false>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
   }
   return SVOC_OK;
 }
-int wino4_launch(const WinoArgs& w, int K, int D, long long total, hipStream_t st) {
+int wino4_launch(const WinoArgs& w, int K, int D, int NRT, long long total, hipStream_t st) {
   int rc = 1;
-#define SVOC_W4(KK, DD) if (K == KK && D == DD) rc = wino4_launch_one<KK, DD>(w, total, st);
+#define SVOC_W4(KK, DD) if (K == KK && D == DD) rc = NRT == 4 ? wino4_launch_one<KK, DD, 4>(w, total, st) : wino4_launch_one<KK, DD, 2>(w, total, st);
   SVOC_W4(3, 1) SVOC_W4(7, 1) SVOC_W4(11, 1) SVOC_W4(3, 3) SVOC_W4(7, 3) SVOC_W4(11, 3) SVOC_W4(3, 5) SVOC_W4(7, 5) SVOC_W4(11, 5)
 #undef SVOC_W4
   return rc;
 }
-template <int D>
+template <int D, int NRT>
 static int wino4_launch_group_d(const WinoGroup& g, long long total, hipStream_t st) {
-  auto kern = conv_wino4_group_kernel<D>;
+  auto kern = conv_wino4_group_kernel<D, NRT>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  const size_t l11 = wino4_lds<11, D>(), l7 = wino4_lds<7, D>(), l3 = wino4_lds<3, D>();
+  const size_t l11 = wino4_lds<11, D, NRT>(), l7 = wino4_lds<7, D, NRT>(), l3 = wino4_lds<3, D, NRT>();
   const size_t lds = std::max(l11, std::max(l7, l3));
-  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
+  hipLaunchKernelGGL(kern, dim3(wino4_grid(total)), dim3(512), lds, st, g);
   return SVOC_OK;
 }
-int wino4_launch_group(const WinoGroup& g, int D, long long total, hipStream_t st) {
-  return D == 1 ? wino4_launch_group_d<1>(g, total, st) : (D == 3 ? wino4_launch_group_d<3>(g, total, st) : wino4_launch_group_d<5>(g, total, st));
+int wino4_launch_group(const WinoGroup& g, int D, int NRT, long long total, hipStream_t st) {
+  if (NRT == 4) return D == 1 ? wino4_launch_group_d<1, 4>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 4>(g, total, st) : wino4_launch_group_d<5, 4>(g, total, st));
+  return D == 1 ? wino4_launch_group_d<1, 2>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 2>(g, total, st) : wino4_launch_group_d<5, 2>(g, total, st));
 }
 
 }  // namespace svoc

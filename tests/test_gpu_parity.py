@@ -108,7 +108,9 @@ def test_conv1d_winograd(M, C, co, k, d, L, B, res):
     (n, n + d)) against torch's direct convolution: every (k, d) of the model, ragged last tiles (L not a multiple of the
     128/126/120-column tiles), inputs shorter than the halo, odd row-block counts (Cout = 96), lanes whose second
     output falls beyond the end (dilated tiles), the 64-pair tiles of C = 64 incl. the k = 11 / d = 5 variant that stores E / O with its own geometry."""
-    import ctypes
+    import ctypes, os
+    if os.environ.get("SVOC_WINO") == "0":
+        pytest.skip("SVOC_WINO=0: the Winograd entry point refuses by design (variant run of the direct-form fallback)")
     seed = 300 + C + 7 * k + L + 1000 * d
     v = T(cases.rnd(seed, "v", (co, C, k), 1.0 / np.sqrt(C * k)))
     g = T((0.5 + sw.uniform01(seed, "g", co)).astype(np.float32)).reshape(co, 1, 1)

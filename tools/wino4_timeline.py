@@ -5,7 +5,7 @@ import numpy as np, torch
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R)
 os.environ.setdefault("SVOC_WINO_F4", "1")
 from smart_vocoder_amd import _native as N
-C, k, d = (int(v) for v in sys.argv[1:4]); B = 16; L = 32768 if C == 128 else 4096
+C, k, d = (int(v) for v in sys.argv[1:4]); B = int(os.environ.get("WB", "16")); L = int(os.environ.get("WL", "0")) or (32768 if C == 128 else 4096)
 lib = N.lib()
 g = torch.Generator().manual_seed(1)
 x = (torch.randn(B, C, L, generator=g) * 0.5).cuda(); wv = (torch.randn(C, C, k, generator=g) * 0.05).cuda()
