@@ -1103,6 +1103,8 @@ static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const W
   }
   w4 = w;
   w4.wp = pw.wp4.f();
+  static const bool prio = !(getenv("SVOC_W4_PRIO") && atoi(getenv("SVOC_W4_PRIO")) == 0);      // producers at s_setprio 3 (conv_wino4.hip)
+  if (prio) w4.flags |= 0x100u;
   const int W = wino4_tile_w(dil, wino4_nc(pw));
   w4.ntn = (a.Ncols + W - 1) / W;
   w4.gy = pw.mtiles / wino4_nc(pw);

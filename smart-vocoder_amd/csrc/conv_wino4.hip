@@ -111,6 +111,12 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   if (wave >= 4) {
     // ================================================================= producer
     const int pw_ = wave - 4;
+    // Producers outrank the consumers for issue: fp32 MFMAs and VALU instructions exclude each other on a SIMD
+    // (tools/mfma_valu_probe.hip), and the older consumer wave wins the arbitration by age, so at equal priority the
+    // producer only advances in the gaps of the MFMA stream and the consumers then wait for it at the stage barrier.
+    // Measured (profiles/r03_i_f43_producer_priority.txt): barrier waits of the consumers halve, k = 11 tile 120.7k -> 118.6k cycles,
+    // 16 x 512 step 33.2 -> 33.0 ms.  SVOC_W4_PRIO=0 switches it off.
+    if (p.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
     constexpr int R4 = RAW / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;      // producer p owns channel rows RPW p .. RPW p + RPW - 1
     constexpr int IPR = NQ * D, NIW = RPW * IPR, TPW = (NIW + 63) / 64;    // transform items: one window each
     const long long ldb = (long long)p.x_ld * 4;
