@@ -187,7 +187,7 @@ int svoc_synth_infer(svoc_synth* h, void* stream, const float* mel, const int64_
                      float* logs_p, int B, int T);
 int64_t svoc_synth_workspace_bytes(svoc_synth* h, int B, int T);
 /* Pre-sizes every workspace of the path for batches up to [B, T] (may block, see "blocking behaviour"); afterwards
- * svoc_synth_infer at that or any smaller shape neither allocates nor synchronises.  Short inputs (B*T <= 4096 frames,
+ * svoc_synth_infer at that or any smaller shape neither allocates nor synchronises.  Batches of up to 32768 frames (B*T,
  * SVOC_GRAPH_MAX_FRAMES) are replayed from a hipGraph captured on their second call (SVOC_GRAPH=0 disables). */
 int svoc_synth_reserve(svoc_synth* h, int B, int T);
 int svoc_synth_hop(svoc_synth* h);         /* prod(upsample_rates) */

@@ -948,7 +948,7 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
 // conv_wino4.hip: the F(4,3) form
 bool wino4_enabled();
 int wino4_slots(int K);
-int wino4_tile_w(int D, int NRT);
+int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
 int wino4_launch(const WinoArgs& w, int K, int D, int NC, long long total, hipStream_t st);
 int wino4_launch_group(const WinoGroup& g, int D, int NC, long long total, hipStream_t st);
@@ -1105,8 +1105,7 @@ static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const W
   w4.wp = pw.wp4.f();
   static const bool prio = !(getenv("SVOC_W4_PRIO") && atoi(getenv("SVOC_W4_PRIO")) == 0);      // producers at s_setprio 3 (conv_wino4.hip)
   if (prio) w4.flags |= 0x100u;
-  const int W = wino4_tile_w(dil, wino4_nc(pw));
-  w4.ntn = (a.Ncols + W - 1) / W;
+  w4.ntn = wino4_ntn(a.Ncols, dil, wino4_nc(pw));
   w4.gy = pw.mtiles / wino4_nc(pw);
   return true;
 }

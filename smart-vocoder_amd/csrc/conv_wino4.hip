@@ -55,15 +55,19 @@ struct W4Geo {
   static constexpr int WSLOTS = 6 * G + ND;               // weight slots per 32-channel chunk
   static constexpr int NGS = 6 * G * KGS;                 // steps (4 MFMAs each) of the groups; a tap adds 4 * KGS steps
   static constexpr int NSTEP = NGS + 4 * KGS * ND;
-  static constexpr int QB = 32 / D;                       // q blocks per tile
-  static constexpr int NWU = QB * D;                      // windows (lanes) per tile
-  static constexpr int W = 4 * NWU * NCT;                 // output columns per workgroup tile (NCT x 128 / 120 / 120)
-  static constexpr int NQ = NCT * QB + G - 1;             // windows per phase and row
-  static constexpr int PQ = NQ * D;                       // plane entries per row: entry q' * D + phase
-  static constexpr int XOFF = -((PADT * D + 3) & ~3);     // raw tile starts at n0 + XOFF (multiple of 4)
-  static constexpr int LEAD = -XOFF - PADT * D;           // raw index of d0 of window 0, phase 0
-  static constexpr int LASTRD = LEAD + (4 * (NQ - 1) + 5) * D + D - 1;
-  static constexpr int RAW = (LASTRD + 1 + 3) & ~3;       // raw tile columns
+  // Windows are numbered along a row: window w = D * b + ph (q block b, phase ph) owns the outputs 4 D b + ph + r D, r = 0..3.  A
+  // workgroup tile is NWT = 32 NCT CONSECUTIVE windows [w0, w0 + NWT): with D = 1 that is the output range [4 w0, 4 w0 + 4 NWT); with
+  // D > 1 a tile may start inside a q block (ph0 = w0 % D), so every lane has a window (a first version gave a tile (32 / D) D
+  // windows: 30 of 32 lanes, 7 % more tiles).  Entry e of a plane row = window w0 + e; group g reads entry e + g D.
+  static constexpr int NWT = 32 * NCT;                    // windows per workgroup tile
+  static constexpr int W = 4 * NWT;                       // D = 1: output columns per workgroup tile
+  static constexpr int NE = NWT + (G - 1) * D;            // windows staged per row and stage
+  static constexpr int PQ = NE;                           // plane row stride
+  static constexpr int XOFF = -((PADT * D + 3) & ~3);     // D = 1: raw tile starts at 4 w0 + XOFF (multiple of 4)
+  static constexpr int LEAD = -XOFF - PADT * D;           // D = 1: raw index of d0 of window w0
+  // raw tile columns.  D = 1: d5 of the last window + 1.  D > 1: first sample f(w0) = 4 D b0 + ph0 - PADT D rounded down to a
+  // multiple of 4 (lead <= 3); f grows by at most 4 NE + 5 D over NE windows and a window spans 5 D more
+  static constexpr int RAW = D == 1 ? ((LEAD + 4 * (NE - 1) + 5 + 1 + 3) & ~3) : ((4 * NE + 10 * D + 4 + 3) & ~3);
   static constexpr int NPL = ND > 0 ? 10 : 6;             // V0..V5 (+ X0..X3)
   static constexpr int NACC = ND > 0 ? 8 : 6;
   static constexpr int PLANE = KS * PQ;
@@ -85,7 +89,7 @@ template <int K, int D, int NRT = 4, bool DBG = false>
 __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
   using Geo = W4Geo<K, D, NRT>;
   constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQ = Geo::PQ, RAW = Geo::RAW, WSLOTS = Geo::WSLOTS;
-  constexpr int NWU = Geo::NWU, XOFF = Geo::XOFF, NQ = Geo::NQ, LEAD = Geo::LEAD, PLANE = Geo::PLANE, PLF = Geo::PLF;
+  constexpr int NWT = Geo::NWT, NCT = Geo::NCT, XOFF = Geo::XOFF, NE = Geo::NE, LEAD = Geo::LEAD, PLANE = Geo::PLANE, PLF = Geo::PLF;
   constexpr int NSTEP = Geo::NSTEP, NACC = Geo::NACC, CPS = Geo::CPS, KS = Geo::KS, RPW = KS / 4, HALVES = Geo::HALVES, KGS = Geo::KGS;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* const raw = wl;                                   // [KC][RAW], producers only
@@ -100,12 +104,25 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   const int nst = nch * HALVES / CPS;                      // stages per tile
   const int my_tiles = (vend - v0 + stride - 1) / stride;
   const int nstages = my_tiles * nst;
-  auto locate = [&](int v, int& n0_, int& bz_, int& by_) {
+  // tile v -> (first window w0 of the tile, batch element, row block)
+  auto locate = [&](int v, int& w0_, int& bz_, int& by_) {
     const int tl = xcd_linear(v - first, ntiles_all, p.xcd);
     const int t = tl / p.ntn;
     bz_ = t / p.gy;
-    n0_ = (tl - t * p.ntn) * Geo::W;
+    w0_ = (tl - t * p.ntn) * NWT;
     by_ = t - bz_ * p.gy;
+  };
+  // raw tile of the tile that starts at window w0: first column xs (multiple of 4) and, for D > 1, the phase of window w0 and
+  // the raw index `lead` of its first sample
+  auto origin = [&](int w0_, int& xs_, int& ph0_, int& lead_) {
+    if constexpr (D == 1) { xs_ = 4 * w0_ + XOFF; ph0_ = 0; lead_ = LEAD; }
+    else {
+      const int b0 = w0_ / D;
+      ph0_ = w0_ - b0 * D;
+      const int f0 = 4 * D * b0 + ph0_ - PADT * D;
+      xs_ = f0 & ~3;                                       // two's complement: rounds towards minus infinity
+      lead_ = f0 - xs_;
+    }
   };
 
   if (wave >= 4) {
@@ -118,7 +135,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     // 16 x 512 step 33.2 -> 33.0 ms.  SVOC_W4_PRIO=0 switches it off.
     if (p.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
     constexpr int R4 = RAW / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;      // producer p owns channel rows RPW p .. RPW p + RPW - 1
-    constexpr int IPR = NQ * D, NIW = RPW * IPR, TPW = (NIW + 63) / 64;    // transform items: one window each
+    constexpr int IPR = NE, NIW = RPW * IPR, TPW = (NIW + 63) / 64;        // transform items: one window each
     const long long ldb = (long long)p.x_ld * 4;
     const float slope = p.pre_slope;
     unsigned goff[SPW];
@@ -130,19 +147,33 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       goff[u] = (unsigned)(row * p.x_ld + 4 * g4) * 4u;
       rdst[u] = raw + row * RAW + 4 * g4;
     }
-    const float* tsrc[TPW];
+    const float* tsrc[TPW];                                // D = 1: the item's samples; D > 1: the item's raw row (the column follows the tile)
     int tdst[TPW];                                         // float offset of the item's entry inside plane 0 of a set
+    int tent[TPW];                                         // D > 1: the item's entry index e
+    int toff[TPW];                                         // D > 1: raw column of the item's d0 in the current tile
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       const int it = min(lane + 64 * u, NIW - 1);
       const int row = RPW * pw_ + it / IPR, e = it % IPR;
-      const int tq = e / D, tph = e - tq * D;
-      // D = 1: the sixteen-byte group that holds d1..d4 (LEAD = 3) or d0..d2 | d3..d5 (LEAD = 1) of the window starts at 4 tq (+ 4)
-      tsrc[u] = D == 1 ? raw + row * RAW + 4 * tq : raw + row * RAW + LEAD + 4 * tq * D + tph;
+      // D = 1: the sixteen-byte group that holds d1..d4 (LEAD = 3) or d0..d2 | d3..d5 (LEAD = 1) of the window starts at 4 e (+ 4)
+      tsrc[u] = D == 1 ? raw + row * RAW + 4 * e : raw + row * RAW;
       tdst[u] = row * PQ + e;
+      tent[u] = e; toff[u] = 0;
     }
+    // D > 1: entry e is window w0 + e = (q block b0 + (ph0 + e) / D, phase (ph0 + e) % D): its d0 sits 4 D qe + pe - ph0 samples
+    // behind the tile's first sample
+    auto retarget = [&](int ph0_, int lead_) {
+      if constexpr (D > 1) {
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+          const int t = ph0_ + tent[u];
+          const int qe = t / D, pe = t - qe * D;
+          toff[u] = lead_ + 4 * D * qe + pe - ph0_;
+        }
+      }
+    };
     float4 v[SPW];
-    int n0 = 0, bz = 0, by = 0;
+    int w0 = 0, bz = 0, by = 0, xs0 = 0, ph0 = 0, lead0 = 0;
     auto issue = [&](const char* xb_, int xs_, bool interior_, int ch) {
       const char* cb = xb_ + (long long)ch * KS * ldb;
       if (interior_) {
@@ -160,16 +191,15 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
         }
       }
     };
-    locate(v0, n0, bz, by);
-    {
-      const int xs = n0 + XOFF;
-      issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs, xs >= 0 && xs + RAW <= L, 0);
-    }
+    locate(v0, w0, bz, by);
+    origin(w0, xs0, ph0, lead0);
+    retarget(ph0, lead0);
+    issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs0, xs0 >= 0 && xs0 + RAW <= L, 0);
     int ti = 0, ch = 0;                                    // stage s = (tile ti, stage ch of the tile)
     long long pc_all0 = 0, pc_bar = 0;
     if constexpr (DBG) pc_all0 = (long long)__builtin_readcyclecounter();
     for (int s_ = 0; s_ < nstages; ++s_) {
-      const int xs_start = n0 + XOFF;
+      const int xs_start = xs0;
       const bool interior = xs_start >= 0 && xs_start + RAW <= L;
       const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
       // ---- publish own rows (lrelu, zero padding on edge tiles)
@@ -204,18 +234,15 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
         }
       }
       // ---- request the next stage's raw rows (next chunk, or chunk 0 of this workgroup's next tile)
-      int nti = ti, nchn = ch + 1, n0n = n0, bzn = bz, byn = by;
-      if (nchn == nst) { nchn = 0; ++nti; if (nti < my_tiles) locate(v0 + nti * stride, n0n, bzn, byn); }
-      if (s_ + 1 < nstages) {
-        const int xsn = n0n + XOFF;
-        issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= L, nchn);
-      }
+      int nti = ti, nchn = ch + 1, w0n = w0, bzn = bz, byn = by, xsn = xs0, ph0n = ph0, leadn = lead0;
+      if (nchn == nst) { nchn = 0; ++nti; if (nti < my_tiles) { locate(v0 + nti * stride, w0n, bzn, byn); origin(w0n, xsn, ph0n, leadn); } }
+      if (s_ + 1 < nstages) issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= L, nchn);
       // ---- transform own rows into plane set s & 1 (LDS operations of one wave execute in order: no barrier needed)
       float* const pb = pl + (s_ & 1) * PLF;
 #pragma unroll
       for (int u = 0; u < TPW; ++u) {
         if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
-          const float* r = tsrc[u];
+          const float* r = D == 1 ? tsrc[u] : tsrc[u] + toff[u];
           float* o = pb + tdst[u];
           float d0, d1, d2, d3, d4, d5;
           if constexpr (D == 1 && LEAD == 3) {
@@ -243,7 +270,8 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       if constexpr (DBG) pb0 = (long long)__builtin_readcyclecounter();
       __syncthreads();                                     // B_s: plane set s & 1 complete
       if constexpr (DBG) pc_bar += (long long)__builtin_readcyclecounter() - pb0;
-      ti = nti; ch = nchn; n0 = n0n; bz = bzn; by = byn;
+      if (nti != ti) retarget(ph0n, leadn);                // the next stage belongs to another tile
+      ti = nti; ch = nchn; w0 = w0n; bz = bzn; by = byn; xs0 = xsn; ph0 = ph0n; lead0 = leadn;
     }
     if constexpr (DBG) if (tid == 256) {                   // producer wave 0: total cycles, cycles spent waiting at the stage barriers
       long long* d = p.dbg + 16 * (long long)(p.dbg_base + v0);
@@ -255,7 +283,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   // =================================================================== consumer: row tile rt, column tile ct of the workgroup
   const int l31 = lane & 31, hi = lane >> 5;
   const int rt = NRT == 4 ? wave : (wave & 1), ct = NRT == 4 ? 0 : (wave >> 1);
-  const int uu = ct * NWU + l31;                           // this lane's window inside the workgroup tile
+  const int uu = ct * 32 + l31;                            // this lane's window inside the workgroup tile
   const unsigned pbase = (unsigned)(size_t)pl;
   const unsigned baddr0 = pbase + (unsigned)(hi * PQ + uu) * 4u;
   const unsigned wlane = (unsigned)lane * 16u;
@@ -312,22 +340,49 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     wino_static_for<0, NSTEP>(step);
   };
   auto wtile = [&](int mt_) -> int { return __builtin_amdgcn_readfirstlane(mt_ * nch * WSLOTS * 4096); };
-  const int lpart = 4 * (uu / D) * D + (uu % D);           // this lane's first output inside the tile (then + D, + 2D, + 3D)
+  // byte offsets of this lane's first output (then + D, + 2D, + 3D) in rows 4 hi + i of a 32-row block.  D = 1: relative to the
+  // tile's first column (fixed); D > 1: absolute column of window w0 + uu, recomputed per tile
   const unsigned ylb = (unsigned)p.y_ld * 4u, rlb = (unsigned)p.res_ld * 4u;
   unsigned yo4[4], ro4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    yo4[i] = (unsigned)((4 * hi + i) * p.y_ld + lpart) * 4u;
-    ro4[i] = (unsigned)((4 * hi + i) * p.res_ld + lpart) * 4u;
+    yo4[i] = (unsigned)((4 * hi + i) * p.y_ld + 4 * uu) * 4u;
+    ro4[i] = (unsigned)((4 * hi + i) * p.res_ld + 4 * uu) * 4u;
   }
-  // fast epilogue: contiguous outputs (D = 1, L % 4 == 0: host), residual but no read-modify-write of y
-  const bool res_only = D == 1 && (p.flags & F_RES) && !(p.flags & F_ACC);
+  // fast epilogue: residual but no read-modify-write of y, and every lane's four outputs exist (D = 1: L % 4 == 0, host;
+  // D > 1: the tile lies inside [0, L), decided per tile)
+  const bool res_flags = (p.flags & F_RES) && !(p.flags & F_ACC);
+  auto ldq = [&](const char* q) -> float4 {                // the lane's four outputs of one row: 16 bytes (D = 1) or four dwords D apart
+    if constexpr (D == 1) return *reinterpret_cast<const float4*>(q);
+    else return make_float4(*reinterpret_cast<const float*>(q), *reinterpret_cast<const float*>(q + 4 * D),
+                            *reinterpret_cast<const float*>(q + 8 * D), *reinterpret_cast<const float*>(q + 12 * D));
+  };
+  auto stq = [&](char* q, const float4& v) {
+    if constexpr (D == 1) *reinterpret_cast<float4*>(q) = v;
+    else {
+      *reinterpret_cast<float*>(q) = v.x; *reinterpret_cast<float*>(q + 4 * D) = v.y;
+      *reinterpret_cast<float*>(q + 8 * D) = v.z; *reinterpret_cast<float*>(q + 12 * D) = v.w;
+    }
+  };
   long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0;     // diagnostics (stamped build): consumer wave 0 of each workgroup
   long long wall0 = 0;
   if constexpr (DBG) { cyc_all0 = (long long)__builtin_readcyclecounter(); wall0 = (long long)wall_clock64(); }
   for (int ti = 0; ti < my_tiles; ++ti) {
-    int n0, bz, by;
-    locate(v0 + ti * stride, n0, bz, by);
+    int w0, bz, by;
+    locate(v0 + ti * stride, w0, bz, by);
+    int ne, n0;                                            // this lane's first output column; column the row bases point at
+    bool tile_full;                                        // every lane of the tile has its four outputs inside [0, L)
+    if constexpr (D == 1) { n0 = 4 * w0; ne = n0 + 4 * uu; tile_full = true; }
+    else {
+      const int w = w0 + uu, b = w / D, ph = w - b * D;
+      ne = 4 * D * b + ph; n0 = 0;
+      tile_full = 4 * D * ((w0 + NWT - 1) / D + 1) <= L;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        yo4[i] = (unsigned)((4 * hi + i) * p.y_ld + ne) * 4u;
+        ro4[i] = (unsigned)((4 * hi + i) * p.res_ld + ne) * 4u;
+      }
+    }
     const int mt = by * NRT + rt;
     const bool row_ok = mt < p.mtiles;
     const int mtc = row_ok ? mt : p.mtiles - 1;
@@ -347,8 +402,8 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       const int mtn = byn * NRT + rt;
       wnext_tile = wtile(mtn < p.mtiles ? mtn : p.mtiles - 1);
     }
-    const int ne = n0 + lpart;
-    const bool lane_ok = row_ok && l31 < NWU && ne < L;
+    const bool lane_ok = row_ok && ne < L;
+    const bool res_only = res_flags && tile_full;
     char* const ybase = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld + n0);
     const char* const rbase = reinterpret_cast<const char*>(p.res + (long long)bz * p.res_bs + (long long)(mt * 32) * p.res_ld + n0);
     float4 rvA[8];                                         // residual of accumulator rows 0..7, requested under the tile's last stage
@@ -361,7 +416,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       if constexpr (DBG) c1 = (long long)__builtin_readcyclecounter();
       if (st_ == nst - 1 && res_only && lane_ok) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) rvA[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (r >> 2)) * rlb + ro4[r & 3]);
+        for (int r = 0; r < 8; ++r) rvA[r] = ldq(rbase + (size_t)(8 * (r >> 2)) * rlb + ro4[r & 3]);
       }
       const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
       constexpr auto c0_ = std::integral_constant<int, 0>{};
@@ -422,7 +477,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
         for (int r = 0; r < 4; ++r) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
       };
       if (res_only) {
-        if constexpr (D == 1) {
+        {
           auto quarter = [&](auto q_c, const float4* rv) {
             constexpr int Q = decltype(q_c)::value;
             float4 vo[4];
@@ -431,12 +486,12 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
             for (int r = 0; r < 4; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w; }
             if (p.flags & F_DIV) divide(vo);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q) * ylb + yo4[r]) = vo[r];
+            for (int r = 0; r < 4; ++r) stq(ybase + (size_t)(8 * Q) * ylb + yo4[r], vo[r]);
           };
           quarter(std::integral_constant<int, 0>{}, rvA);
           float4 rvB[8];                                   // requested once the first quarter's accumulator registers are free
 #pragma unroll
-          for (int r = 0; r < 8; ++r) rvB[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (2 + (r >> 2))) * rlb + ro4[r & 3]);
+          for (int r = 0; r < 8; ++r) rvB[r] = ldq(rbase + (size_t)(8 * (2 + (r >> 2))) * rlb + ro4[r & 3]);
           quarter(std::integral_constant<int, 1>{}, rvA + 4);
           quarter(std::integral_constant<int, 2>{}, rvB);
           quarter(std::integral_constant<int, 3>{}, rvB + 4);
@@ -580,7 +635,12 @@ bool wino4_enabled() {
 }
 template <int K, int D, int NRT>
 static size_t wino4_lds() { return (size_t)W4Geo<K, D, NRT>::LDS_BYTES; }
-int wino4_tile_w(int D, int NRT) { return 4 * ((32 / D) * D) * (4 / NRT); }
+// column tiles per row: a tile is 32 * (4 / NRT) consecutive windows; a row of L outputs has D * ceil(L / 4D) windows
+int wino4_ntn(int L, int D, int NRT) {
+  const long long nw = (long long)D * ((L + 4 * D - 1) / (4 * D));
+  const int nwt = 32 * (4 / NRT);
+  return (int)((nw + nwt - 1) / nwt);
+}
 // one persistent workgroup per CU (eight waves of up to 256 registers)
 static unsigned wino4_grid(long long total) { return (unsigned)std::min<long long>(total, (long long)device_cu_count()); }
 

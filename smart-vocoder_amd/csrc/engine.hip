@@ -846,7 +846,7 @@ struct Synth {
   ~Synth() { plans.clear(); retired.clear(); if (cap_st) (void)hipStreamDestroy(cap_st); }
 
   static long long graph_max_frames() {
-    static const long long v = getenv("SVOC_GRAPH_MAX_FRAMES") ? atoll(getenv("SVOC_GRAPH_MAX_FRAMES")) : 4096;
+    static const long long v = getenv("SVOC_GRAPH_MAX_FRAMES") ? atoll(getenv("SVOC_GRAPH_MAX_FRAMES")) : 32768;
     static const bool on = !(getenv("SVOC_GRAPH") && atoi(getenv("SVOC_GRAPH")) == 0);
     return on ? v : 0;
   }
