@@ -952,6 +952,7 @@ int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
 int wino4_launch(const WinoArgs& w, int K, int D, int NC, long long total, hipStream_t st);
 int wino4_launch_group(const WinoGroup& g, int D, int NC, long long total, hipStream_t st);
+int wino4_launch_accum(const WinoGroup& g, int NRT, long long total, hipStream_t st);
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
@@ -1150,6 +1151,42 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
 #undef SVOC_W
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc;
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+
+// The three chains' last convolutions (k = 3, 7, 11 in chain order, dilation 1), each with its own epilogue flags (residual;
+// + accumulate; + accumulate and divide) into one output: ONE launch of conv_wino4_accum_kernel.  1 = not eligible (the caller
+// runs them one by one).
+int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st) {
+  static const bool on = !(getenv("SVOC_W4_ACCUM") && atoi(getenv("SVOC_W4_ACCUM")) == 0);
+  if (!on || B <= 0 || !pws[0] || !pws[1] || !pws[2] || pws[0]->K != 3 || pws[1]->K != 7 || pws[2]->K != 11) return 1;
+  WinoGroup g4{};
+  double flops = 0, exec4 = 0;
+  long long total = 0;
+  const int WM = wino_wm(*pws[0]);
+  for (int i = 0; i < 3; ++i) {
+    WinoArgs w;
+    if (wino_wm(*pws[i]) != WM || wino4_nc(*pws[i]) != wino4_nc(*pws[0]) || !wino_args(*pws[i], as[i], B, 1, WM, w)) return 1;
+    if (!wino4_args(*pws[i], as[i], 1, w, g4.a[i])) return 1;
+    const long long t = (long long)g4.a[i].ntn * g4.a[i].gy * B;
+    if (i == 0) total = t;
+    if (t != total || total > 0x7fffffffLL || as[i].out[0].y != as[0].out[0].y) return 1;      // one tile space, one output tensor
+    g4.end[i] = (int)total; g4.k[i] = pws[i]->K;
+    flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
+    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K);
+  }
+  if (total * 3 / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
+  stats_add_conv(flops, 3, exec4);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "wino4A Ci%-4d Co%-4d k3+7+11 accumulate N%-7d B%-3d", pws[0]->Cin, pws[0]->Cout, as[0].Ncols, B);
+    prof_idx = prof_begin(st, d, flops);
+  }
+  const int rc = wino4_launch_accum(g4, wino4_nc(*pws[0]), total, st);
+  prof_end(st, prof_idx);
+  if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;
 }

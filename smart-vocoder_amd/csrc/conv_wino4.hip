@@ -578,6 +578,22 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_group_kernel(const WinoGrou
   wino4_member<3, D, NRT>(g.a[2], g.end[1], g.end[2], b, G_);
 }
 
+// The last convolutions of the three MRF chains accumulate into ONE tensor in chain order, xs = rb_0 + rb_1 + rb_2, x = xs / 3
+// (reference models.py:149-155).  As three launches each pays its own tail and the k = 3 one runs alone; here every workgroup
+// walks the SAME tiles for the three members in chain order (k = 3, 7, 11: no rotation of the assignment), so the tile a wave
+// accumulates into was written by that very wave (same lane, same registers' worth of addresses) one member earlier: program
+// order makes the read-modify-write safe without any inter-workgroup synchronisation, and the summation order of the reference
+// is kept bit for bit.
+template <int NRT>
+__global__ void __launch_bounds__(512, 2) conv_wino4_accum_kernel(const WinoGroup g) {
+  const int b = blockIdx.x, G_ = gridDim.x, total = g.end[0];
+  wino4_problem<3, 1, NRT>(g.a[0], b, total, 0, G_);
+  __syncthreads();
+  wino4_problem<7, 1, NRT>(g.a[1], b, total, 0, G_);
+  __syncthreads();
+  wino4_problem<11, 1, NRT>(g.a[2], b, total, 0, G_);
+}
+
 // ------------------------------------------------------------------ weight transform + packing
 // wp[m-tile][chunk][slot][k-group][lane][4] as pack_wino (conv_wino.hip) with slots = 6 G + ND: slot 6 g + p holds U_p of the
 // three-tap group g, slot 6 G + t the plain tap 4 t + 3.
@@ -675,6 +691,19 @@ static int wino4_launch_group_d(const WinoGroup& g, long long total, hipStream_t
   const size_t lds = std::max(l11, std::max(l7, l3));
   hipLaunchKernelGGL(kern, dim3(wino4_grid(total)), dim3(512), lds, st, g);
   return SVOC_OK;
+}
+template <int NRT>
+static int wino4_launch_accum_n(const WinoGroup& g, long long total, hipStream_t st) {
+  auto kern = conv_wino4_accum_kernel<NRT>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const size_t l11 = wino4_lds<11, 1, NRT>(), l7 = wino4_lds<7, 1, NRT>(), l3 = wino4_lds<3, 1, NRT>();
+  const size_t lds = std::max(l11, std::max(l7, l3));
+  hipLaunchKernelGGL(kern, dim3(wino4_grid(total)), dim3(512), lds, st, g);
+  return SVOC_OK;
+}
+// members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each)
+int wino4_launch_accum(const WinoGroup& g, int NRT, long long total, hipStream_t st) {
+  return NRT == 4 ? wino4_launch_accum_n<4>(g, total, st) : wino4_launch_accum_n<2>(g, total, st);
 }
 int wino4_launch_group(const WinoGroup& g, int D, int NRT, long long total, hipStream_t st) {
   if (NRT == 4) return D == 1 ? wino4_launch_group_d<1, 4>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 4>(g, total, st) : wino4_launch_group_d<5, 4>(g, total, st));

@@ -519,7 +519,29 @@ struct Generator {
         SVOC_TRY(launch3(all_w, 1));
         for (int q = 0; q < nk; ++q) cur[order[q]] = nxt[q];
       } else {
-        for (int j = 0; j < nk; ++j) {        // xs = sum_j ResBlock_j(x) / n, accumulated in chain order (models.py:149-155)
+        // xs = sum_j ResBlock_j(x) / n, accumulated in chain order (models.py:149-155): one launch when the three members are the
+        // F(4,3) kernel's (conv_wino4_accum_kernel), else one by one
+        bool done = false;
+        if (nk == 3) {
+          const PackedWino* apw[3];
+          ConvArgs aas[3];
+          for (int j = 0; j < 3; ++j) {
+            int q = 0;
+            while (order[q] != j) ++q;
+            ConvArgs a = as[q];
+            unsigned fl = F_RES;
+            if (j > 0) fl |= F_ACC;
+            if (j == nk - 1) fl |= F_DIV;
+            set_out(a.out[0], XS, bs, ld, C, fl);
+            a.out[0].div = (float)nk;
+            set_res(a.out[0], cur[j], bs, ld);
+            aas[j] = a; apw[j] = pws[q];
+          }
+          const int ra = launch_conv_wino4_accum(apw, aas, B, st);
+          if (ra < 0) return ra;
+          done = ra == 0;
+        }
+        for (int j = 0; j < nk && !done; ++j) {
           int q = 0;
           while (order[q] != j) ++q;
           ConvArgs a = as[q];

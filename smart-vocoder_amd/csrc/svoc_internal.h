@@ -183,6 +183,7 @@ int pack_wino_named(PackedWino& pw, int Cin, int Cout, int K, const TensorTable&
 // eligible (alignment, odd length, masks, or fewer than min_tiles workgroups; min_tiles < 0: twice the CU count)
 int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles = -1);
 int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st);
+int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st);   // chain order k = 3, 7, 11
 
 // resblock_fused.hip: one ResBlock1 iteration (c1 -> lrelu -> c2 -> + x) in one kernel; returns 1 when not eligible
 void set_debug_stamp_buffer(long long* p);
