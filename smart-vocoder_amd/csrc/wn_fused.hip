@@ -30,6 +30,7 @@ struct WnArgs {
   int H; int ktaps; int nchunks; int npairs; int T;
   int xoff0; int xrow; int arow;
   int first; int last;
+  long long* dbg;                                      // diagnostics: [workgroup][8] cycle stamps of wave 0 (tools/wn_timeline.py)
 };
 
 __device__ __forceinline__ float wn_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
@@ -279,6 +280,9 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
   float* const red_mine = RED + (wave * 16) * 64 + lane;
   float* const red_peer = RED + ((kh ? pi : pi + p.npairs) * 16) * 64 + lane;
 
+  long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int i) { if (p.dbg) ts[i] = (long long)__builtin_readcyclecounter(); };
+  stamp(0);
   // ---- stage the x tile: all H channels, columns [t0 + xoff0, +xrow), zero outside [0, T)
   {
     const int R4 = p.xrow >> 2;
@@ -334,18 +338,22 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
     for (int i = 0; i < 16; ++i)
       acc[h][0][i] = kh ? 0.f : p.bias1[(2 * pi + h) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
   __syncthreads();
+  stamp(1);
   {
     const float4* wp4 = reinterpret_cast<const float4*>(p.wp1);
     const long long ab0 = (long long)(2 * pi) * p.ksg1 * 64 + lane;
     wn_gemm<NR>(acc, wp4, ab0, ab0 + (long long)p.ksg1 * 64, true, p.ksg1, XT, p.xrow, l31 - p.pad - p.xoff0, p.ktaps, p.dil,
                 ch_hi, hi, ch_lo);
   }
+  stamp(2);
   // exchange: this wave finishes registers [8*kh, 8*kh+8) of both tiles and hands the other 8 to its peer
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int q = 0; q < 8; ++q) red_mine[(h * 8 + q) * 64] = kh ? acc[h][0][q] : acc[h][0][8 + q];
+  stamp(7);
   __syncthreads();     // partials published; everybody is done reading the x tile -> its LDS is reused for acts
+  stamp(8);
   {
     const float* gb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
     const int m = l31;
@@ -363,6 +371,7 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
       AT[chn * p.arow + m] = gate_tanh_sigmoid(vA, vB);
     }
   }
+  stamp(9);
   // ---- phase B: res_skip 1x1 on the acts tile; tile pi = x part, tile npairs + pi = skip part (last layer: tile pi only)
   const bool two = !p.last;
 #pragma unroll
@@ -371,12 +380,14 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
     for (int i = 0; i < 16; ++i)
       acc[h][0][i] = (!kh && (h == 0 || two)) ? p.bias2[(h * p.npairs + pi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi] : 0.f;
   __syncthreads();     // acts tile complete, exchange area free again
+  stamp(3);
   {
     const float4* wp4 = reinterpret_cast<const float4*>(p.wp2);
     const long long ab0 = (long long)pi * p.ksg2 * 64 + lane;
     const long long ab1 = two ? (long long)(p.npairs + pi) * p.ksg2 * 64 + lane : ab0;
     wn_gemm<NR>(acc, wp4, ab0, ab1, two, p.ksg2, AT, p.arow, l31, 1, 1, ch_hi, hi, ch_lo);
   }
+  stamp(4);
   // exchange: kh=0 finishes tile 0 (residual part; on the last layer the only tile), kh=1 finishes tile 1 (skip part)
   if (two) {
 #pragma unroll
@@ -391,9 +402,17 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
 #pragma unroll
     for (int q = 0; q < 16; ++q) fin[q] = (kh ? acc[1][0][q] : acc[0][0][q]) + red_peer[q * 64];
   }
+  stamp(5);
+  auto dump = [&]() {
+    if (p.dbg && tid == 0) {
+      long long* d = p.dbg + 8 * (long long)(blockIdx.x + gridDim.x * blockIdx.z);
+      for (int i = 0; i < 6; ++i) d[i] = ts[i];
+      d[6] = (long long)__builtin_readcyclecounter(); d[7] = ((ts[7] - ts[2]) << 42) | ((ts[8] - ts[7]) << 21) | (ts[9] - ts[8]);
+    }
+  };
   // ---- epilogue (modules.py:168-175)
   const int t = t0 + l31;
-  if (t >= p.T) return;
+  if (t >= p.T) { dump(); return; }
   const float* mb = p.mask + (long long)b * p.mask_bs;
   const float mk = mb[t];
   const int row0 = pi * 32 + 4 * hi;
@@ -428,6 +447,7 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
       ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = v * mk;
     }
   }
+  dump();
 }
 
 // (A compile-time specialised copy of the K-split kernel - immediate-offset fragment reads, uniform-base weight stream, static
@@ -456,6 +476,7 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   a.wp2 = rs_l.wp.f(); a.bias2 = rs_l.bias.f(); a.ksg2 = rs_l.ksg_total;
   a.H = H; a.ktaps = in_l.ktaps; a.nchunks = H / KC; a.npairs = npairs; a.T = T;
   a.first = first; a.last = last;
+  a.dbg = debug_stamp_buffer();
   // narrow tiles when there are few columns: every CU should get a workgroup
   const int ncu = device_cu_count();
   {   // Short inputs: a fused layer is one workgroup per 32 columns carrying the whole K = H*k chain of every row pair
