@@ -10,6 +10,7 @@
 // (x-part w, skip-part w) feed the residual/skip epilogue.  acts never goes to HBM and one launch replaces two.
 // x is ping-ponged between two buffers by the caller: a tile reads a halo that its neighbours overwrite.
 #include "svoc_internal.h"
+#include "wino_common.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -251,11 +252,68 @@ __global__ void __launch_bounds__(512) wn_layer_fused_kernel(const WnArgs p) {
   }
 }
 
+// Compile-time form of wn_gemm for the K-split kernel's common geometry (H = 192: three 32-channel chunks per wave; row stride,
+// tap count and dilation fixed): fp32 MFMAs and VALU instructions exclude each other on a SIMD (tools/mfma_valu_probe.hip) and
+// the generic loop above issues one VALU instruction per MFMA (fragment addresses from a runtime row stride, 64-bit weight
+// pointers), which stretched phase A from 92k to 105k cycles (tools/wn_timeline.py).  Here the stream holds only MFMAs,
+// ds_read_b32 at immediate offsets, buffer loads with the group offset in an SGPR, waits and SALU.
+//   acc[2] += W[two 32-row tiles][3 chunks x KT taps x 32 channels] * B
+// `baddr`: LDS byte address of (row hi of the wave's first chunk, this lane's column for tap 0); `wofs0/1`: byte offsets of the
+// two row tiles' first k-step group of that chunk inside the packed image.
+typedef unsigned int wn_u32x4 __attribute__((ext_vector_type(4)));
+template <int ROWLEN, int KT, int DIL, bool TWO>
+__device__ __forceinline__ void wn_gemm_ct(f32x16 (&acc)[2][1], const float* wp, const int wofs0, const int wofs1, const unsigned baddr,
+                                           const unsigned wlane) {
+  constexpr int NCH = 3, NG = NCH * KT * 4;                // groups of four k-steps (8 channels of one tap)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7fffffff, 0x00020000);
+  auto wload = [&](float4& d, int soff) {
+    const wn_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wlane, soff, 0);
+    d = *reinterpret_cast<const float4*>(&t);
+  };
+  float4 a0[2], a1[2];
+  float fb[2][4];
+  auto request = [&](auto gc) {
+    constexpr int GI = decltype(gc)::value;
+    if constexpr (GI < NG) {
+      constexpr int CL = GI / (KT * 4), J = (GI / 4) % KT, KG = GI % 4;
+      constexpr int O = ((CL * 32 + 8 * KG) * ROWLEN + J * DIL) * 4;
+      fb[GI & 1][0] = wino_lds_rd<O>(baddr);
+      fb[GI & 1][1] = wino_lds_rd<O + 2 * ROWLEN * 4>(baddr);
+      fb[GI & 1][2] = wino_lds_rd<O + 4 * ROWLEN * 4>(baddr);
+      fb[GI & 1][3] = wino_lds_rd<O + 6 * ROWLEN * 4>(baddr);
+      wload(a0[GI & 1], wofs0 + GI * 1024);
+      if constexpr (TWO) wload(a1[GI & 1], wofs1 + GI * 1024);
+    }
+  };
+  auto group = [&](auto gc) {
+    constexpr int GI = decltype(gc)::value;
+    {
+      float(&b)[4] = fb[GI & 1];
+      if constexpr (GI + 1 < NG) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    }
+    const float4 av0 = a0[GI & 1], av1 = a1[GI & 1];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av0, s_), fb[GI & 1][s_], acc[0][0], 0, 0, 0);
+      if constexpr (TWO) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av1, s_), fb[GI & 1][s_], acc[1][0], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    request(std::integral_constant<int, GI + 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  request(std::integral_constant<int, 0>{});
+  request(std::integral_constant<int, 1>{});
+  wino_static_for<0, NG>(group);
+}
+
 // K-split variant for short inputs (one 32-column workgroup per CU at the headline config).  With one wave per row
 // pair a workgroup has H/32 = 6 waves on 4 SIMDs (2,2,1,1: the matrix pipes are 75 % used at best).  Here 2*npairs
 // waves run: wave (pi, kh) multiplies row pair pi over half kh of the input channels; partial accumulators are
 // exchanged through LDS so that each wave finishes HALF of the pair's outputs (gate: 8 of the 16 accumulator
 // registers; res_skip: kh=0 the residual tile, kh=1 the skip tile).  12 waves = 3 per SIMD, every phase balanced.
+// CT: compile-time streams (H = 192, k = 5, dilation 1: x rows of 40 floats, acts rows of 33); LAST: the stack's last layer
+template <bool CT, bool LAST>
 __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) {
   constexpr int NR = 1;
   constexpr int NA = 32;
@@ -342,6 +400,11 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
   {
     const float4* wp4 = reinterpret_cast<const float4*>(p.wp1);
     const long long ab0 = (long long)(2 * pi) * p.ksg1 * 64 + lane;
+    if constexpr (CT) {
+      const unsigned baddr = (unsigned)(size_t)XT + (unsigned)((ch_lo * KC + hi) * 40 + (l31 - p.pad - p.xoff0)) * 4u;
+      const int w0 = __builtin_amdgcn_readfirstlane(((2 * pi) * p.ksg1 + ch_lo * 5 * 4) * 1024);
+      wn_gemm_ct<40, 5, 1, true>(acc, p.wp1, w0, w0 + p.ksg1 * 1024, baddr, (unsigned)lane * 16u);
+    } else
     wn_gemm<NR>(acc, wp4, ab0, ab0 + (long long)p.ksg1 * 64, true, p.ksg1, XT, p.xrow, l31 - p.pad - p.xoff0, p.ktaps, p.dil,
                 ch_hi, hi, ch_lo);
   }
@@ -373,7 +436,7 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
   }
   stamp(9);
   // ---- phase B: res_skip 1x1 on the acts tile; tile pi = x part, tile npairs + pi = skip part (last layer: tile pi only)
-  const bool two = !p.last;
+  const bool two = CT ? !LAST : !p.last;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -385,6 +448,12 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
     const float4* wp4 = reinterpret_cast<const float4*>(p.wp2);
     const long long ab0 = (long long)pi * p.ksg2 * 64 + lane;
     const long long ab1 = two ? (long long)(p.npairs + pi) * p.ksg2 * 64 + lane : ab0;
+    if constexpr (CT) {
+      const unsigned baddr = (unsigned)(size_t)AT + (unsigned)((ch_lo * KC + hi) * 33 + l31) * 4u;
+      const int w0 = __builtin_amdgcn_readfirstlane((pi * p.ksg2 + ch_lo * 4) * 1024);
+      const int w1 = __builtin_amdgcn_readfirstlane(((p.npairs + pi) * p.ksg2 + ch_lo * 4) * 1024);
+      wn_gemm_ct<33, 1, 1, !LAST>(acc, p.wp2, w0, LAST ? w0 : w1, baddr, (unsigned)lane * 16u);
+    } else
     wn_gemm<NR>(acc, wp4, ab0, ab1, two, p.ksg2, AT, p.arow, l31, 1, 1, ch_hi, hi, ch_lo);
   }
   stamp(4);
@@ -507,8 +576,21 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
     snprintf(d, sizeof(d), "fusedWN H%-4d k%-2d d%-2d N%-7d B%-3d NA%d%s%s", H, in_l.ktaps, in_l.dil, T, B, NA, ksplit ? " ksplit" : "", last ? " last" : "");
     prof_idx = prof_begin(st, d, flops);
   }
-  if (ksplit) {
-    auto kern = wn_layer_fused_ks_kernel;
+  static const bool ct_on = !(getenv("SVOC_WN_CT") && atoi(getenv("SVOC_WN_CT")) == 0);
+  const bool ct = ct_on && ksplit && H == 192 && in_l.ktaps == 5 && in_l.dil == 1 && a.xrow == 40 && a.arow == 33 && a.nchunks == 6 &&
+                  (long long)in_l.mtiles * in_l.ksg_total * 1024 < (1LL << 31);
+  if (ksplit && ct) {
+    if (last) {
+      auto kern = wn_layer_fused_ks_kernel<true, true>;
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+      hipLaunchKernelGGL(kern, grid, dim3(2 * npairs * 64), lds, st, a);
+    } else {
+      auto kern = wn_layer_fused_ks_kernel<true, false>;
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+      hipLaunchKernelGGL(kern, grid, dim3(2 * npairs * 64), lds, st, a);
+    }
+  } else if (ksplit) {
+    auto kern = wn_layer_fused_ks_kernel<false, false>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, grid, dim3(2 * npairs * 64), lds, st, a);
   } else if (NR == 2) {

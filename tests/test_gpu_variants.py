@@ -13,6 +13,7 @@ listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run check
   SVOC_W4_PRIO=0                 F(4,3) producers at the consumers' priority
   SVOC_W4_ACCUM=0                the chains' last convolutions as three launches instead of one accumulate launch
   SVOC_WINO_WM=2                 2x2 wave layout (64-row tiles) for the Winograd kernels at C >= 128
+  SVOC_WN_CT=0                   generic (runtime-geometry) MFMA loops in the K-split WN layer kernel
   SVOC_WN_KSPLIT=0               6-wave WN layer kernel (one wave per row pair) instead of the 12-wave K-split one
   SVOC_KSPLIT=0 SVOC_WN_SMALL=0 SVOC_MRF_SMALL=0    short inputs on the throughput kernels (no K-split convolutions, fused WN
                                  layers, grouped MRF launches)
@@ -46,6 +47,7 @@ VARIANTS = {
     "mrf_accumulate_one_by_one": {"SVOC_W4_ACCUM": "0"},
     "winograd_2x2": {"SVOC_WINO_F4": "0", "SVOC_WINO_WM": "2"},
     "wn_no_ksplit": {"SVOC_WN_KSPLIT": "0"},
+    "wn_generic_loops": {"SVOC_WN_CT": "0"},
     "no_small_shape_kernels": {"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"},
     "no_graph": {"SVOC_GRAPH": "0"},
     "natural_tile_order": {"SVOC_XCD": "0"},
