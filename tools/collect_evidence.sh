@@ -21,6 +21,9 @@ python $R/tools/pmc_traffic.py /tmp/pr /tmp/pw $NK 2 > $O/${TAG}_pmc_hbm_traffic
 ( cd $R && python tools/latency_probe.py ) > $O/${TAG}_latency_by_shape.txt 2>&1
 
 
+( cd $R && for k in 3 7 11; do python tools/wino4_timeline.py 128 $k 1; done; python tools/wino4_timeline.py 128 11 3; python tools/wino4_timeline.py 256 11 1 ) > $O/${TAG}_winograd_f43_workgroup_stamps.txt 2>/dev/null
+( cd $R && python tools/wn_timeline.py 16 512 ) > $O/${TAG}_wn_layer_phase_stamps.txt 2>/dev/null
+( cd $R && python tools/wino_bench.py 128 32768; python tools/wino_bench.py 64 65536; python tools/wino_bench.py 256 4096 ) > $O/${TAG}_winograd_f43_per_conv.txt 2>/dev/null
 ls -la $O
 ( cd $R && SVOC_STREAMS=0 python tools/profile_infer.py 16 512 3 ) > $O/${TAG}_per_layer_event_profile_single_stream.txt 2>&1
 ( cd $R && python tools/profile_infer.py 1 200 5 ) > $O/${TAG}_per_layer_event_profile_1x200.txt 2>&1
