@@ -27,14 +27,12 @@
 #include "svoc_internal.h"
 
 #include <algorithm>
-#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
 namespace svoc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int ks_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned F_VECST = 1u << 16;   // internal: float4 stores legal for EPI_UPS
 
@@ -185,68 +183,43 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& p, const int bx, const
     if constexpr (KS) {
       if (wave_active) {
         // this wave's groups: (sub-chunk q, tap j) -> packed group ((ch + q) * ktaps + j) * 4 + wave, LDS rows
-        // q*32 + 8*wave + 2s + hi at column offset j*dil; one group ahead in two register sets (no copies).
-        // fp32 MFMAs and VALU instructions exclude each other on a SIMD, and a VALU instruction between two DEPENDENT MFMAs
-        // costs a whole MFMA slot (tools/mfma_valu_probe.hip): the weights come through buffer loads whose group offset is
-        // an SGPR (no 64-bit VALU address arithmetic), and a single-tile wave alternates between two accumulators from
-        // group to group, so that the few VALU instructions left (LDS fragment addresses) never sit on a dependent edge.
+        // q*32 + 8*wave + 2s + hi at column offset j*dil; one group ahead in registers
         const int nsub = min(sub_per_stage, p.nchunks - ch);
         const int ng = nsub * p.ktaps;
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
-        int wofs[MR];
+        const float* bpw = bp0 + 8 * wave * p.row_len;
+        float4 an[MR];
+        float bn[4][NR];
+        auto req = [&](int q, int j) {
+          const long long kg = ((long long)(ch + q) * p.ktaps + j) * 4 + wave;
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-          wofs[mr] = __builtin_amdgcn_readfirstlane((min(mt0 + mr, p.mtiles - 1) * p.ksg_total + ch * p.ktaps * 4 + wave) * 1024);
-        const float* bq = bp0 + 8 * wave * p.row_len;       // fragment base of the group to request next
-        const int rl2 = 2 * p.row_len;
-        const int step_tap = p.dil, step_chunk = KC * p.row_len - (p.ktaps - 1) * p.dil;
-        int jn = 0, gn = 0;                                 // tap / index of the group to request next
-        float4 a0[MR], a1[MR];
-        float b0[4][NR], b1[4][NR];
-        auto req = [&](float4(&an)[MR], float(&bn)[4][NR]) {
-#pragma unroll
-          for (int mr = 0; mr < MR; ++mr) {
-            const ks_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, wofs[mr] + gn * 4096, 0);
-            an[mr] = *reinterpret_cast<const float4*>(&t);
-          }
+          for (int mr = 0; mr < MR; ++mr) an[mr] = wp4[abase[mr] + kg * 64];
+          const float* bq = bpw + q * KC * p.row_len + j * p.dil;
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bq[s * rl2 + nr * 32];
-          ++gn;
-          if (++jn == p.ktaps) { jn = 0; bq += step_chunk; } else bq += step_tap;
+            for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bq[(2 * s) * p.row_len + nr * 32];
         };
-        constexpr bool DUAL = MR * NR == 1;
-        f32x16 acc2;
-        if constexpr (DUAL) {
+        req(0, 0);
+        int q = 0, j = 0;
+        for (int g = 0; g < ng; ++g) {
+          float4 ac[MR];
+          float bc[4][NR];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
-        }
-        auto mfmas = [&](const float4(&ac)[MR], const float(&bc)[4][NR], auto second) {
+          for (int mr = 0; mr < MR; ++mr) ac[mr] = an[mr];
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) bc[s][nr] = bn[s][nr];
+          if (++j == p.ktaps) { j = 0; ++q; }
+          if (g + 1 < ng) req(q, j);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
               const float av = pick4(ac[mr], s);
 #pragma unroll
-              for (int nr = 0; nr < NR; ++nr) {
-                if constexpr (DUAL && decltype(second)::value) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc2, 0, 0, 0);
-                else acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[mr][nr], 0, 0, 0);
-              }
+              for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[mr][nr], 0, 0, 0);
             }
-        };
-        req(a0, b0);
-        for (int g = 0; g < ng; g += 2) {
-          if (g + 1 < ng) req(a1, b1);
-          mfmas(a0, b0, std::false_type{});
-          if (g + 1 < ng) {
-            if (g + 2 < ng) req(a0, b0);
-            mfmas(a1, b1, std::true_type{});
-          }
-        }
-        if constexpr (DUAL) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[0][0][i] += acc2[i];
         }
       }
     } else
