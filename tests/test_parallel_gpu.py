@@ -103,3 +103,24 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["collective"] == "gather" and j["config"]["global_batch"] == 8
     assert j["value"] > 0 and j["scaling"] == "weak"
+
+
+def test_bench_single_gpu_line_schema():
+    """bench.py at N=1 on the timed configuration (16 x 512, 2 steps, no CPU leg): ONE JSON line with the contract's keys, the
+    roofline block with both fractions (direct-form `frac`, which the Winograd kernels may push above 1, and `frac_executed`,
+    which is bounded by the peak) and the library's launch statistics."""
+    cmd = [sys.executable, os.path.join(cases.ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["vs_baseline"] is None and "workload" in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert 0.0 < rf["frac_executed"] <= 1.0 and rf["frac_executed"] <= rf["frac"] + 1e-9
+    assert abs(rf["flop_per_step"] - 2568280.0 * j["config"]["samples_per_step"]) / rf["flop_per_step"] < 0.01      # SURVEY 8(d)
+    assert 0.5 < rf["executed_mfma_flop_fraction"] <= 1.0
