@@ -112,7 +112,7 @@ def test_every_kernel_switch_has_a_variant_run():
     # not kernel choices: sizes / thresholds of the plan cache, the variant-batch preset, diagnostics
     tunables = {"SVOC_GRAPH_MAX_FRAMES", "SVOC_GRAPH_MIN_SEEN", "SVOC_VARIANT_BATCH", "SVOC_DBG_WALL", "SVOC_DBG_DUMP", "SVOC_RB_LDS_MIN"}
     tested = set()
-    for env in V.VARIANTS.values():
+    for env, _slice in V.VARIANTS.values():
         tested |= set(env)
     assert read - tunables - tested == set(), f"switches without a variant run: {sorted(read - tunables - tested)}"
     assert tested - read == set(), f"variant runs of switches the library does not read: {sorted(tested - read)}"

@@ -645,8 +645,16 @@ def test_infer_long_form_tiling(M, net):
     mel = sw.synthetic_mel(4242, 1, Tn); eps = sw.synthetic_eps(4242, 1, Tn)
     ln = np.array([Tn], dtype=np.int64)
     o, *_ = net.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=0.667, eps=T(eps).cuda())
-    with torch.no_grad():
-        o_ref, *_ = O.infer(sdT(cases.full_model_weights()), T(mel), T(ln), T(eps), 0.667)
+    # the oracle's waveform is deterministic (seeded inputs and weights); the variant runs (tests/test_gpu_variants.py) call this
+    # test once per process, so it is computed once per box and kept in the temp directory
+    import os, tempfile
+    cache = os.path.join(tempfile.gettempdir(), f"svoc_oracle_longform_{Tn}_4242.npy")
+    if os.path.isfile(cache):
+        o_ref = T(np.load(cache))
+    else:
+        with torch.no_grad():
+            o_ref, *_ = O.infer(sdT(cases.full_model_weights()), T(mel), T(ln), T(eps), 0.667)
+        np.save(cache + ".tmp.npy", o_ref.numpy()); os.replace(cache + ".tmp.npy", cache)
     err = (o.cpu() - o_ref).numpy()
     rms, ref = float(np.sqrt((err ** 2).mean())), float(o_ref.pow(2).mean().sqrt())
     assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)

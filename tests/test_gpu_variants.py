@@ -31,35 +31,41 @@ import cases
 
 pytestmark = pytest.mark.gpu
 
-SLICE = ("test_infer_vs_reference_golden or test_resblock1 or test_wn or test_generator or test_coupling or "
-         "test_infer_long_form_tiling or test_small_shape_graph_replay or test_conv1d_winograd or test_dds or test_layer_norm")
+# slices of tests/test_gpu_parity.py per kind of switch (each variant runs in its own process: the library reads the
+# environment once); every slice reaches the kernels its switches select (the long-form and full-size cases are the ones
+# large enough for the grouped / fused / persistent kernels)
+DEC = ("test_conv1d_winograd or test_resblock1 or test_generator or test_infer_vs_reference_golden or test_infer_long_form_tiling")
+WNS = "test_wn or test_coupling or test_infer_vs_reference_golden or test_full_size_properties"
+SMALL = "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_generator or test_wn or test_resblock1"
+OFFG = "test_dds or test_layer_norm or test_convflow"
 
 VARIANTS = {
-    "unfused": {"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"},
-    "generic_fused_resblock": {"SVOC_FUSE_V": "1"},
-    "fused_c64": {"SVOC_FUSE64": "1"},
-    "single_stream": {"SVOC_STREAMS": "0"},
-    "ungrouped": {"SVOC_GROUP": "0"},
-    "no_winograd": {"SVOC_WINO": "0"},
-    "winograd_f23": {"SVOC_WINO_F4": "0"},
-    "winograd_f23_4wave": {"SVOC_WINO_F4": "0", "SVOC_WINO_WS": "0"},
-    "winograd_f43_equal_priority": {"SVOC_W4_PRIO": "0"},
-    "mrf_accumulate_one_by_one": {"SVOC_W4_ACCUM": "0"},
-    "winograd_2x2": {"SVOC_WINO_F4": "0", "SVOC_WINO_WM": "2"},
-    "wn_no_ksplit": {"SVOC_WN_KSPLIT": "0"},
-    "wn_generic_loops": {"SVOC_WN_CT": "0"},
-    "no_small_shape_kernels": {"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"},
-    "no_graph": {"SVOC_GRAPH": "0"},
-    "natural_tile_order": {"SVOC_XCD": "0"},
-    "layernorm_v1": {"SVOC_LN_V2": "0"},
+    "unfused": ({"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"}, DEC + " or " + WNS),
+    "generic_fused_resblock": ({"SVOC_FUSE_V": "1"}, DEC),
+    "fused_c64": ({"SVOC_FUSE64": "1"}, DEC),
+    "single_stream": ({"SVOC_STREAMS": "0"}, DEC),
+    "ungrouped": ({"SVOC_GROUP": "0"}, DEC),
+    "no_winograd": ({"SVOC_WINO": "0"}, DEC),
+    "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
+    "winograd_f23_4wave": ({"SVOC_WINO_F4": "0", "SVOC_WINO_WS": "0"}, DEC),
+    "winograd_f43_equal_priority": ({"SVOC_W4_PRIO": "0"}, DEC),
+    "mrf_accumulate_one_by_one": ({"SVOC_W4_ACCUM": "0"}, DEC),
+    "winograd_2x2": ({"SVOC_WINO_F4": "0", "SVOC_WINO_WM": "2"}, DEC),
+    "wn_no_ksplit": ({"SVOC_WN_KSPLIT": "0"}, WNS),
+    "wn_generic_loops": ({"SVOC_WN_CT": "0"}, WNS),
+    "no_small_shape_kernels": ({"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"}, SMALL),
+    "no_graph": ({"SVOC_GRAPH": "0"}, SMALL),
+    "natural_tile_order": ({"SVOC_XCD": "0"}, DEC),
+    "layernorm_v1": ({"SVOC_LN_V2": "0"}, OFFG),
 }
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_variant(name):
     e = dict(os.environ)
-    e.update(VARIANTS[name])
+    env, sl = VARIANTS[name]
+    e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(cases.ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
-                        "-m", "gpu", "-p", "no:cacheprovider", "-k", SLICE], env=e, cwd=cases.ROOT, stdout=subprocess.PIPE,
+                        "-m", "gpu", "-p", "no:cacheprovider", "-k", sl], env=e, cwd=cases.ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]
