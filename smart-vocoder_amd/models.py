@@ -358,6 +358,12 @@ class SynthesizerTrn(_HipModule):
             out[:, :, s * hop:e * hop] = o[:, :, (s - a) * hop:(e - a) * hop]
         return out
 
+    def stream(self, noise_scale=1, halo_frames=None):
+        """Incremental long-form inference: ``s = net.stream(noise_scale=.667)``, then ``wave = s.push(mel_chunk)``
+        as mel frames arrive and ``wave = s.flush()`` at the end; the concatenated pieces equal one ``infer`` over the whole
+        utterance (to fp32 summation order, as ``infer_chunked``).  See :class:`InferStream`."""
+        return InferStream(self, noise_scale=noise_scale, halo_frames=halo_frames)
+
     def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, eps=None):
         """reference models.py:341-349.  The reference never creates ``emb_g`` (models.py:305-314), so as there this
         raises AttributeError unless the caller attaches one (``net.emb_g = nn.Embedding(n_speakers, gin_channels)``)."""
@@ -371,3 +377,69 @@ class SynthesizerTrn(_HipModule):
         z_hat = self.flow(z_p, y_mask, g=g_tgt, reverse=True)
         o_hat = self.dec(z_hat * y_mask, g=g_tgt)
         return o_hat, y_mask, (z, z_p, z_hat)
+
+
+class InferStream:
+    """Feed-as-it-arrives front of ``SynthesizerTrn.infer`` (extension; the reference's only hook for partial decoding is
+    ``max_len``, models.py:338).  The path is not causal - every output sample depends on ``RECEPTIVE_FRAMES`` mel frames on either
+    side - so the stream keeps a halo of past frames, holds back the newest ``halo`` frames until their future context has
+    arrived, and runs ``infer`` on [halo | ready frames | halo]; only the samples of the ready frames are returned.  Nothing
+    but the halo is carried between calls (the library's workspaces are sized by the largest window seen).  ``push`` may return an
+    empty waveform while the look-ahead fills; ``flush`` emits what is left (the true end is zero-padded by the convolutions
+    exactly as in a one-shot call).  Every utterance of the batch advances in lock step (all frames of a chunk are valid)."""
+
+    def __init__(self, net, noise_scale=1, halo_frames=None):
+        self.net = net
+        self.noise_scale = noise_scale
+        self.halo = int(net.RECEPTIVE_FRAMES if halo_frames is None else halo_frames)
+        self.mel = None          # frames [start, end) of the utterance: left halo + everything not yet emitted
+        self.eps = None
+        self.start = 0           # utterance index of self.mel[:, :, 0]
+        self.emitted = 0         # frames whose samples have been returned
+
+    @property
+    def end(self):
+        return self.start + (0 if self.mel is None else self.mel.shape[2])
+
+    def _run(self, upto):
+        """samples of frames [emitted, upto) from one infer over [start, end)"""
+        hop = self.net.dec.hop
+        B, _, W = self.mel.shape
+        ln = torch.full((B,), W, dtype=torch.int64, device=self.mel.device)
+        o = self.net.infer(self.mel, ln, noise_scale=self.noise_scale, eps=self.eps)[0]
+        out = o[:, :, (self.emitted - self.start) * hop:(upto - self.start) * hop].clone()
+        self.emitted = upto
+        keep_from = max(self.start, self.emitted - self.halo)          # drop what can no longer influence future samples
+        if keep_from > self.start:
+            self.mel = self.mel[:, :, keep_from - self.start:].contiguous()
+            self.eps = self.eps[:, :, keep_from - self.start:].contiguous()
+            self.start = keep_from
+        return out
+
+    def push(self, mel, eps=None):
+        """mel [B, 80, t] (t >= 1 new frames), eps [B, inter_channels, t] or None (drawn) -> waveform [B, 1, n * hop], n >= 0"""
+        mel = N.f32(mel)
+        if eps is None:
+            eps = torch.randn(mel.shape[0], self.net.inter_channels, mel.shape[2], dtype=torch.float32, device=mel.device)
+        eps = N.f32(eps)
+        if self.mel is None:
+            self.mel, self.eps = mel, eps
+        else:
+            if mel.shape[0] != self.mel.shape[0]:
+                raise ValueError("the batch size of a stream is fixed by its first chunk")
+            self.mel = torch.cat([self.mel, mel], 2)
+            self.eps = torch.cat([self.eps, eps], 2)
+        upto = self.end - self.halo                                   # frames whose right context is complete
+        if upto <= self.emitted:
+            return torch.empty(mel.shape[0], 1, 0, dtype=torch.float32, device=mel.device)
+        return self._run(upto)
+
+    def flush(self):
+        """the samples of the frames still held back; the stream is empty afterwards"""
+        if self.mel is None or self.end <= self.emitted:
+            dev = self.net._dev()
+            return torch.empty(0 if self.mel is None else self.mel.shape[0], 1, 0, dtype=torch.float32, device=dev)
+        out = self._run(self.end)
+        self.mel = self.eps = None
+        self.start = self.emitted
+        return out
