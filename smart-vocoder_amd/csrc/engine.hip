@@ -361,6 +361,7 @@ struct Generator {
   PackedConv conv_pre;
   std::unique_ptr<PackedConv> cond;
   std::vector<std::unique_ptr<PackedConv>> ups;
+  std::vector<std::unique_ptr<PackedCtWino>> ups_w;       // F(4,2) form of the same upsampler where convt_wino.hip serves the shape
   std::vector<std::unique_ptr<ResBlock>> rbs;
   DevBuf conv_post_w;
   int post_C = 0;
@@ -409,6 +410,11 @@ struct Generator {
       if (k < u || ((k - u) % 2) != 0) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "generator: upsample kernel %d / rate %d not supported", k, u);
       ups.emplace_back(new PackedConv());
       SVOC_TRY(pack_conv_named(*ups.back(), us, tab, prefix + "ups." + std::to_string(i), st));
+      ups_w.emplace_back(nullptr);
+      if (convt_wino_supported(us.Cin, us.Cout, k, u, us.tpad)) {
+        ups_w.back().reset(new PackedCtWino());
+        SVOC_TRY(pack_convt_wino_named(*ups_w.back(), us.Cin, us.Cout, k, u, us.tpad, tab, prefix + "ups." + std::to_string(i), st));
+      }
       ch /= 2;
       hop *= u;
       for (int j = 0; j < c.n_kernels; ++j) {
@@ -599,7 +605,12 @@ struct Generator {
       if (use_streams) { R = bufs[r]; XS = bufs[r ^ 1]; X = bufs[2]; }
       else { R = bufs[r]; X = bufs[(r + 1) & 3]; XS = bufs[(r + 2) & 3]; }
       const int Lo = L * u, ldo = stage_ld(Lo), cho = ch / 2;
-      {   // lrelu(0.1) -> ConvTranspose1d as polyphase GEMM (models.py:147-148)
+      int ups_done = 1;
+      if (ups_w[i]) {   // lrelu(0.1) -> ConvTranspose1d, Winograd F(4,2) over the polyphase filters (models.py:147-148)
+        ups_done = launch_convt_wino(*ups_w[i], R, (long long)ch * ld, ld, 0.1f, X, (long long)cho * ldo, ldo, B, L, st);
+        if (ups_done < 0) return ups_done;
+      }
+      if (ups_done == 1) {   // ... as the direct polyphase GEMM
         ConvArgs a = mk_args();
         set_in(a, R, (long long)ch * ld, ld, L);
         a.pre_slope = 0.1f;
@@ -1323,10 +1334,17 @@ int svoc_conv_transpose1d(void* stream, const float* x, const float* weight_v, c
     SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_conv_transpose1d: bad arguments");
   SVOC_GUARD_BEGIN
   hipStream_t st = as_stream(stream);
+  const int Lo = L * stride;
+  if (convt_wino_supported(Cin, Cout, kernel_size, stride, (kernel_size - stride) / 2)) {
+    PackedCtWino pw;
+    SVOC_TRY(pack_convt_wino(pw, Cin, Cout, kernel_size, stride, (kernel_size - stride) / 2, weight_v, weight_g, bias, st));
+    const int r = launch_convt_wino(pw, x, (long long)Cin * L, L, pre_slope, y, (long long)Cout * Lo, Lo, B, L, st);
+    if (r < 0) return r;
+    if (r == 0) { SVOC_HIP(hipStreamSynchronize(st)); return SVOC_OK; }
+  }
   PackedConv pc;
   PackSpec sp{}; sp.Cin = Cin; sp.Cout = Cout; sp.K = kernel_size; sp.transposed = true; sp.stride = stride; sp.tpad = (kernel_size - stride) / 2;
   SVOC_TRY(pack_conv(pc, sp, weight_v, weight_g, bias, st));
-  const int Lo = L * stride;
   ConvArgs a = mk_args();
   set_in(a, x, (long long)Cin * L, L, L);
   a.pre_slope = pre_slope;

@@ -185,6 +185,21 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
 int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st);
 int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st);   // chain order k = 3, 7, 11
 
+// convt_wino.hip: Winograd F(4,2) form of the polyphase transposed convolution (upsamplers k = 2 s: s = 8 or 2)
+struct PackedCtWino {
+  DevBuf wp, bias;
+  int Cin = 0, Cout = 0, S = 0, tpad = 0, nchunks = 0, mtiles = 0;
+  double flops_per_col = 0;       // algorithmic 2*MAC per INPUT column
+};
+bool convt_wino_supported(int Cin, int Cout, int K, int stride, int tpad);
+int pack_convt_wino(PackedCtWino& pw, int Cin, int Cout, int K, int stride, int tpad, const float* w_or_v, const float* g,
+                    const float* bias, hipStream_t st);
+int pack_convt_wino_named(PackedCtWino& pw, int Cin, int Cout, int K, int stride, int tpad, const TensorTable& tab,
+                          const std::string& prefix, hipStream_t st);
+// 1 = not eligible (alignment, or fewer than two workgroups per CU)
+int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, int x_ld, float pre_slope, float* y, long long y_bs,
+                      int y_ld, int B, int Lin, hipStream_t st);
+
 // resblock_fused.hip: one ResBlock1 iteration (c1 -> lrelu -> c2 -> + x) in one kernel; returns 1 when not eligible
 void set_debug_stamp_buffer(long long* p);
 long long* debug_stamp_buffer();   // misc_kernels.hip: device buffer for per-workgroup cycle stamps, or nullptr

@@ -210,6 +210,33 @@ def test_conv_transpose_geometries(M, k, s):
     assert rc != 0       # (k+1) - s has the other parity
 
 
+@pytest.mark.parametrize("ci,co,k,s,L,B", [(128, 64, 16, 8, 1000, 16), (128, 64, 16, 8, 1020, 17), (64, 32, 16, 8, 4096, 9),
+                                          (512, 256, 16, 8, 128, 16), (128, 64, 4, 2, 4000, 16), (64, 64, 4, 2, 8188, 9)])
+def test_conv_transpose_winograd(M, ci, co, k, s, L, B):
+    """The upsamplers' F(4,2) kernel (convt_wino.hip): k = 2 s, stride 8 and 2, shapes large enough to pass its two-workgroups-
+    per-CU gate (checked through the executed-flop counter: 5/8 of the algorithmic count); ragged last window tiles, the extra
+    column q = L, both edges."""
+    import ctypes, os
+    if os.environ.get("SVOC_CT_WINO") == "0":
+        pytest.skip("SVOC_CT_WINO=0: the F(4,2) kernel is switched off")
+    N = M.native
+    seed = 7700 + ci + 3 * L + s
+    v = T(cases.rnd(seed, "v", (ci, co, k), 1.0 / np.sqrt(ci * k / s)))
+    g = T((0.5 + sw.uniform01(seed, "g", ci)).astype(np.float32)).reshape(ci, 1, 1)
+    bias = T(cases.rnd(seed, "b", (co,), 0.1))
+    x = T(cases.rnd(seed, "x", (B, ci, L), 1.0))
+    w = O.fold_weight_norm(v, g)
+    ref = torch.nn.functional.conv_transpose1d(torch.nn.functional.leaky_relu(x, 0.1), w, bias, stride=s, padding=(k - s) // 2)
+    xc, vc, gc, bc = x.cuda(), v.cuda(), g.cuda(), bias.cuda()
+    y = torch.full((B, co, L * s), float("nan"), device="cuda")
+    N.stats_reset()
+    N.check(N.lib().svoc_conv_transpose1d(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), N.ptr(y), B, ci, co, L, k, s,
+                                          ctypes.c_float(0.1)))
+    st = N.stats_get()
+    assert st["conv_flops"] > 0 and abs(st["executed_flops"] / st["conv_flops"] - 5.0 / 8.0) < 1e-6, st
+    check(f"convT F(4,2) k{k} s{s} ci{ci} L{L}", y, ref)
+
+
 @pytest.mark.parametrize("name", list(cases.UPS_CASES))
 def test_conv_transpose(M, name):
     import ctypes
