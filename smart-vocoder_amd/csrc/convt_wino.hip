@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     by_ = t / p.B;                                         // tiles that share a row block's weights (up to 1.3 MB) are neighbours
     w0_ = (tl - t * p.ntn) * Geo::NWT;
     bz_ = t - by_ * p.B;
+    // a row's column tiles in an order rotated by t: with a power-of-two tile count a workgroup would otherwise meet the same
+    // column tile in every round, and the eight that own the left edge (slower staging: bounds per element) finish last
+    w0_ = (int)((unsigned)(w0_ / Geo::NWT + t) % (unsigned)p.ntn) * Geo::NWT;
   };
 
   if (wave >= 4) {
@@ -86,12 +89,14 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     const long long ldb = (long long)p.x_ld * 4;
     const float slope = p.pre_slope;
     unsigned goff[SPW];
+    int gcol[SPW];
     float* rdst[SPW];
 #pragma unroll
     for (int u = 0; u < SPW; ++u) {
       const int it = min(lane + 64 * u, NGW - 1);
       const int row = RPW * pw_ + it / R4, g4 = it % R4;
       goff[u] = (unsigned)(row * p.x_ld + 4 * g4) * 4u;
+      gcol[u] = 4 * g4;
       rdst[u] = raw + row * RAW + 4 * g4;
     }
     const float* tsrc[TPW];
@@ -105,12 +110,24 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     }
     float4 v[SPW];
     int w0 = 0, bz = 0, by = 0;
-    auto issue = [&](const char* xb_, int xs_, bool interior_, int st_) {
+    // staging modes: 0 = the raw tile lies inside the row; 1 = it crosses an end of a row whose length is a multiple of four
+    // (16-byte groups are then entirely inside or outside: a select per group); 2 = general (bounds per element)
+    const bool whole = (Lin & 3) == 0;
+    auto mode_of = [&](int xs_) -> int { return (xs_ >= 0 && xs_ + RAW <= Lin) ? 0 : (whole ? 1 : 2); };
+    auto issue = [&](const char* xb_, int xs_, int mode_, int st_) {
       const char* cb = xb_ + (long long)st_ * KS * ldb;
-      if (interior_) {
+      if (mode_ == 0) {
         const char* ct = cb + (long long)xs_ * 4;
 #pragma unroll
         for (int u = 0; u < SPW; ++u) v[u] = *reinterpret_cast<const float4*>(ct + goff[u]);
+      } else if (mode_ == 1) {
+        const unsigned lim = (unsigned)(Lin - 4);
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+          const int tg = xs_ + gcol[u];
+          const unsigned off = (unsigned)tg <= lim ? goff[u] + (unsigned)(xs_ * 4) : goff[u] - (unsigned)(gcol[u] * 4);      // outside: column 0 of the row (dropped on arrival)
+          v[u] = *reinterpret_cast<const float4*>(cb + off);
+        }
       } else {
         int l_ = lane;
         asm volatile("" : "+v"(l_));
@@ -125,18 +142,29 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     locate(v0, w0, bz, by);
     {
       const int xs = 4 * w0 - 4;
-      issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs, xs >= 0 && xs + RAW <= Lin, 0);
+      issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs, mode_of(xs), 0);
     }
     int ti = 0, ch = 0;
     for (int s_ = 0; s_ < nstages; ++s_) {
       const int xs_start = 4 * w0 - 4;
-      const bool interior = xs_start >= 0 && xs_start + RAW <= Lin;
+      const int mode = mode_of(xs_start);
       const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
-      if (interior) {
+      if (mode == 0) {
 #pragma unroll
         for (int u = 0; u < SPW; ++u) {
           if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
             float4 q = v[u];
+            wino_lrelu4(q, slope);
+            *reinterpret_cast<float4*>(rdst[u]) = q;
+          }
+        }
+      } else if (mode == 1) {
+        const unsigned lim = (unsigned)(Lin - 4);
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+          if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
+            float4 q = v[u];
+            if ((unsigned)(xs_start + gcol[u]) > lim) q = make_float4(0.f, 0.f, 0.f, 0.f);
             wino_lrelu4(q, slope);
             *reinterpret_cast<float4*>(rdst[u]) = q;
           }
@@ -166,7 +194,7 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
       if (nchn == nst) { nchn = 0; ++nti; if (nti < my_tiles) locate(v0 + nti * stride, w0n, bzn, byn); }
       if (s_ + 1 < nstages) {
         const int xsn = 4 * w0n - 4;
-        issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= Lin, nchn);
+        issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, mode_of(xsn), nchn);
       }
       float* const pb = pl + (s_ & 1) * PLF;
 #pragma unroll
@@ -388,6 +416,50 @@ __global__ void ct_scale_kernel(const float* __restrict__ v, const float* __rest
   if (threadIdx.x == 0) scale[i] = g[i] / sqrtf(red[0]);
 }
 
+// The column q = Lin (the last `pad` samples of every row: only the x[q - 1] tap is inside the input) when Lin % 4 == 0: the
+// window tiles then cover q = 0 .. Lin - 1 exactly and one more tile per row for a single column would cost 1/16 .. 1/4 of the
+// launch (513 columns at the first upsampler).  y[b][o][S Lin - pad + r] = bias[o] + sum_c g0[c][o][r] lrelu(x[b][c][Lin - 1]),
+// r < pad; g0 = 2 U0 is read back from the image.  One workgroup per (four row tiles, utterance); wave k takes the chunks
+// k, k + 16, ...; a lane one of the 64 tail rows.
+template <int S>
+__global__ void __launch_bounds__(1024) convt_tail_kernel(const CtArgs p, const int Cin) {
+  __shared__ float xl[1024];
+  __shared__ float red[16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bz = blockIdx.y;
+  const float* xb = p.x + (long long)bz * p.x_bs + (p.Lin - 1);
+  for (int c = tid; c < Cin; c += 1024) {
+    const float v = xb[(long long)c * p.x_ld];
+    xl[c] = fmaxf(v, v * p.pre_slope);
+  }
+  __syncthreads();
+  const int mt = blockIdx.x * 4 + (lane >> 4), tr = lane & 15;
+  const int rl = S == 8 ? (tr >> 2) * 8 + (tr & 3) : 2 * tr;      // row of the tile: phases r < pad
+  float acc = 0.f;
+  if (mt < p.mtiles) {
+    for (int ch = wave; ch < p.nchunks; ch += 16) {
+      const float* w = p.wp + ((long long)(mt * p.nchunks + ch) * 5) * 1024 + rl * 4;      // slot 0: U0 = g0 / 2
+      const float* xc = xl + ch * KC;
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 u = *reinterpret_cast<const float4*>(w + kg * 256 + h * 128);
+          acc += u.x * xc[8 * kg + h] + u.y * xc[8 * kg + 2 + h] + u.z * xc[8 * kg + 4 + h] + u.w * xc[8 * kg + 6 + h];
+        }
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && mt < p.mtiles) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    const int row = mt * 32 + rl, o = row / S, r = row - o * S;
+    p.y[(long long)bz * p.y_bs + (long long)o * p.y_ld + (p.Lout - (S == 8 ? 4 : 1) + r)] = 2.f * t + p.bias[o];
+  }
+}
+
 bool convt_wino_enabled() {
   static const bool on = !(getenv("SVOC_CT_WINO") && atoi(getenv("SVOC_CT_WINO")) == 0);
   return on;
@@ -449,7 +521,9 @@ int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, in
   a.x = x; a.x_bs = x_bs; a.x_ld = x_ld; a.Lin = Lin; a.pre_slope = pre_slope;
   a.wp = pw.wp.f(); a.bias = pw.bias.f(); a.nchunks = pw.nchunks; a.mtiles = pw.mtiles;
   a.y = y; a.y_bs = y_bs; a.y_ld = y_ld; a.Lout = Lin * pw.S;
-  const int nw = (Lin + 1 + 3) / 4;                        // windows over the columns q = 0 .. Lin
+  static const bool tail_on = !(getenv("SVOC_CT_TAIL") && atoi(getenv("SVOC_CT_TAIL")) == 0);
+  const bool tail = tail_on && (Lin & 3) == 0 && pw.Cin <= 1024;     // the column q = Lin by convt_tail_kernel, the windows cover 0 .. Lin - 1
+  const int nw = (Lin + (tail ? 0 : 1) + 3) / 4;          // windows over the columns q = 0 .. Lin
   a.ntn = (nw + CtGeo::NWT - 1) / CtGeo::NWT;
   a.gy = pw.mtiles / 4; a.B = B;
   a.xcd = xcd_mapping_enabled();
@@ -466,6 +540,11 @@ int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, in
   }
   const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
   const size_t lds = (size_t)CtGeo::LDS_BYTES;
+  if (tail) {
+    const dim3 tg((unsigned)((pw.mtiles + 3) / 4), (unsigned)B);
+    if (pw.S == 8) hipLaunchKernelGGL(convt_tail_kernel<8>, tg, dim3(1024), 0, st, a, pw.Cin);
+    else hipLaunchKernelGGL(convt_tail_kernel<2>, tg, dim3(1024), 0, st, a, pw.Cin);
+  }
   if (pw.S == 8) {
     auto kern = convt_wino_kernel<8>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));

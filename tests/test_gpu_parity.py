@@ -211,7 +211,7 @@ def test_conv_transpose_geometries(M, k, s):
 
 
 @pytest.mark.parametrize("ci,co,k,s,L,B", [(128, 64, 16, 8, 1000, 16), (128, 64, 16, 8, 1020, 17), (64, 32, 16, 8, 4096, 9),
-                                          (512, 256, 16, 8, 128, 16), (128, 64, 4, 2, 4000, 16), (64, 64, 4, 2, 8188, 9)])
+                                          (512, 256, 16, 8, 256, 16), (128, 64, 4, 2, 4000, 16), (64, 64, 4, 2, 8188, 9)])
 def test_conv_transpose_winograd(M, ci, co, k, s, L, B):
     """The upsamplers' F(4,2) kernel (convt_wino.hip): k = 2 s, stride 8 and 2, shapes large enough to pass its two-workgroups-
     per-CU gate (checked through the executed-flop counter: 5/8 of the algorithmic count); ragged last window tiles, the extra
@@ -663,6 +663,21 @@ def test_generator_mixed_dilation_orders_vs_oracle(M):
         ref = O.generator(sdT(sd), x, prefix="", resblock="1", resblock_kernel_sizes=c["rks"], resblock_dilation_sizes=rds,
                           upsample_rates=c["ur"], upsample_kernel_sizes=c["uks"])
     check("generator mixed dilations", y, ref, 5e-5, 1e-4)
+
+
+def test_generator_winograd_upsamplers_vs_oracle(M):
+    """Stride-8 and stride-2 upsamplers inside the decoder at a shape that passes the F(4,2) kernel's gate, with an input length
+    that is NOT a multiple of four (row stride != length; the window tiles then carry the column q = L themselves) at the first
+    upsampler and one that is (the separate tail launch) at the second."""
+    c = dict(initial_channel=32, resblock="1", rks=[3, 7], rds=[[1, 3, 5], [1, 3, 5]], ur=[8, 2], uic=256, uks=[16, 4], gin=0)
+    sd = sw.fill_state_dict(cases.generator_shapes(c), 7723, 1.0)
+    m = load(M.models.Generator(c["initial_channel"], c["resblock"], c["rks"], c["rds"], c["ur"], c["uic"], c["uks"], gin_channels=0), sd)
+    x = T(cases.rnd(7723, "x", (20, 32, 403), 1.0))
+    y = m(x.cuda())
+    with torch.no_grad():
+        ref = O.generator(sdT(sd), x, prefix="", resblock="1", resblock_kernel_sizes=c["rks"], resblock_dilation_sizes=c["rds"],
+                          upsample_rates=c["ur"], upsample_kernel_sizes=c["uks"])
+    check("generator F(4,2) upsamplers", y, ref, 5e-5, 1e-4)
 
 
 def test_infer_long_form_tiling(M, net):

@@ -2,7 +2,7 @@
 # F(4,2) upsampler kernel against the direct polyphase kernel inside one GPU call: parity slice, bench both ways.
 tag=${1:-ct}
 out=gpurun_out/$tag; mkdir -p $out
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "conv_transpose or test_generator or infer_vs or c2_full" > $out/pytest.txt 2>&1
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "conv_transpose or test_generator or infer_vs or c2_full or variant_batch or shard" > $out/pytest.txt 2>&1
 tail -5 $out/pytest.txt
 for v in 1 0; do
   for i in 1 2; do
