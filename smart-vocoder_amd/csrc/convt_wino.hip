@@ -39,9 +39,14 @@ struct CtArgs {
   unsigned flags;                                         // row block's weights are neighbours.  flags bit 8: producers at s_setprio 3
 };
 
+// NRT = row tiles per workgroup: 4 (128 rows x 32 windows; a stage = 64 channels) or 2 (64 rows x 64 windows, the consumers as
+// 2 row tiles x 2 column halves; a stage = 32 channels - the planes of 64 windows x 64 channels x 2 sets would not fit)
+template <int NRT>
 struct CtGeo {
-  static constexpr int KS = 2 * KC;                       // channels per stage (two weight chunks)
-  static constexpr int NWT = 32;                          // windows per tile (= 128 columns q)
+  static constexpr int NCT = 4 / NRT;
+  static constexpr int CPS = NRT == 4 ? 2 : 1;            // weight chunks per stage
+  static constexpr int KS = CPS * KC;                     // channels per stage
+  static constexpr int NWT = 32 * NCT;                    // windows per tile (= 4 NWT columns q)
   static constexpr int PQ = NWT;                          // plane row stride
   static constexpr int RAW = 4 * NWT + 4;                 // raw tile columns: from 4 w0 - 4 (d0 of window w0 is raw[3])
   static constexpr int NPL = 5, NACC = 5, WSLOTS = 5, NSTEP = 5 * 4;
@@ -52,9 +57,10 @@ struct CtGeo {
 };
 
 // S = stride (8: k = 16, pad 4; 2: k = 4, pad 1)
-template <int S>
+template <int S, int NRT>
 __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, const int total) {
-  using Geo = CtGeo;
+  using Geo = CtGeo<NRT>;
+  constexpr int CPS = Geo::CPS;
   constexpr int KS = Geo::KS, PQ = Geo::PQ, RAW = Geo::RAW, PLANE = Geo::PLANE, PLF = Geo::PLF, NSTEP = Geo::NSTEP, WSLOTS = Geo::WSLOTS;
   constexpr int RPW = KS / 4;
   extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -66,7 +72,7 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Lin = p.Lin;
-  const int nst = p.nchunks / 2;                           // stages per tile (host: nchunks even)
+  const int nst = p.nchunks / CPS;                         // stages per tile (host: nchunks even)
   const int my_tiles = (total - v0 + stride - 1) / stride;
   const int nstages = my_tiles * nst;
   auto locate = [&](int v, int& w0_, int& bz_, int& by_) {
@@ -219,10 +225,11 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     return;
   }
 
-  // =================================================================== consumer: row tile `wave` of the 128-row block
+  // =================================================================== consumer: row tile rt of the block, column group cg
   const int l31 = lane & 31, hi = lane >> 5;
+  const int rt = NRT == 4 ? wave : (wave & 1), cg = NRT == 4 ? 0 : (wave >> 1);
   const unsigned pbase = (unsigned)(size_t)pl;
-  const unsigned baddr0 = pbase + (unsigned)(hi * PQ + l31) * 4u;
+  const unsigned baddr0 = pbase + (unsigned)(hi * PQ + 32 * cg + l31) * 4u;
   const unsigned wlane = (unsigned)lane * 16u;
   f32x16 M[5];
   float4 a[2][4];
@@ -234,13 +241,14 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
       dst[kg] = *reinterpret_cast<const float4*>(&t);
     }
   };
-  // one 32-channel chunk (chunk CC of the stage): 20 steps of four MFMAs
-  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto cc) {
-    constexpr int CC = decltype(cc)::value;
+  // one 32-channel chunk: 20 steps of four MFMAs.  CC = parity of the chunk (which weight register set its first slot is in),
+  // PC = its position in the stage's planes
+  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto cc, auto pc) {
+    constexpr int CC = decltype(cc)::value, PC = decltype(pc)::value;
     float fb[2][4];
     auto request = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
-      if constexpr (T < NSTEP) wino_frag<PQ, (T / 4) * PLANE + CC * KC * PQ, T % 4, 0>(fb[T & 1], baddr);
+      if constexpr (T < NSTEP) wino_frag<PQ, (T / 4) * PLANE + PC * KC * PQ, T % 4, 0>(fb[T & 1], baddr);
     };
     auto step = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
@@ -265,14 +273,16 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     request(std::integral_constant<int, 1>{});
     wino_static_for<0, NSTEP>(step);
   };
-  // Weight register sets: slot ws of chunk CC of a stage lives in set (CC + ws) & 1 (five slots per chunk: the first slot of the
-  // second chunk continues the alternation; a stage = two chunks = ten slots, so every stage starts in set 0).
+  // Weight register sets: slot ws of a chunk of parity CC lives in set (CC + ws) & 1 (five slots per chunk: the first slot of the
+  // next chunk continues the alternation; chunks go in pairs = ten slots, so every pair starts in set 0).
   auto wtile = [&](int mt_) -> int { return __builtin_amdgcn_readfirstlane(mt_ * p.nchunks * WSLOTS * 4096); };
   const unsigned ylb = (unsigned)p.y_ld * 4u;
+  float bv[16];
+  int bias_mt = -1;
   for (int ti = 0; ti < my_tiles; ++ti) {
     int w0, bz, by;
     locate(v0 + ti * stride, w0, bz, by);
-    const int mt = by * 4 + wave;
+    const int mt = by * NRT + rt;
     const bool row_ok = mt < p.mtiles;
     const int mtc = row_ok ? mt : p.mtiles - 1;
     const int wt = wtile(mtc);
@@ -282,32 +292,42 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
       for (int q = 0; q < 5; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) M[q][i] = 0.f;
+      if (mtc != bias_mt) {                                // (kept across the tiles of one row block: the loads' latency is exposed)
+        bias_mt = mtc;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = mtc * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-        M[1][i] = p.bias[row / S];
+        for (int i = 0; i < 16; ++i) bv[i] = p.bias[(mtc * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi) / S];
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) M[1][i] = bv[i];
     }
     int wnext_tile = -1;
     if (ti + 1 < my_tiles) {
       int w0n, bzn, byn;
       locate(v0 + (ti + 1) * stride, w0n, bzn, byn);
-      const int mtn = byn * 4 + wave;
+      const int mtn = byn * NRT + rt;
       wnext_tile = wtile(mtn < p.mtiles ? mtn : p.mtiles - 1);
     }
-    for (int st_ = 0; st_ < nst; ++st_) {
-      const int s_ = ti * nst + st_;
-      __syncthreads();
-      const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
-      const int wa = wt + (st_ * 2) * WSLOTS * 4096;
-      mfma_chunk(baddr0 + off, wa, wa + WSLOTS * 4096, std::integral_constant<int, 0>{});
-      const int wnext = st_ + 1 < nst ? wa + 2 * WSLOTS * 4096 : wnext_tile;
-      mfma_chunk(baddr0 + off, wa + WSLOTS * 4096, wnext, std::integral_constant<int, 1>{});
+    for (int cp = 0; cp < p.nchunks; cp += 2) {            // chunk pairs
+      const int wa = wt + cp * WSLOTS * 4096;
+      const int wnext = cp + 2 < p.nchunks ? wa + 2 * WSLOTS * 4096 : wnext_tile;
+      if constexpr (CPS == 2) {
+        const int s_ = ti * nst + (cp >> 1);
+        __syncthreads();
+        const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
+        mfma_chunk(baddr0 + off, wa, wa + WSLOTS * 4096, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        mfma_chunk(baddr0 + off, wa + WSLOTS * 4096, wnext, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+      } else {
+        const int s_ = ti * nst + cp;
+        __syncthreads();
+        mfma_chunk(baddr0 + (unsigned)((s_ & 1) * PLF) * 4u, wa, wa + WSLOTS * 4096, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        __syncthreads();
+        mfma_chunk(baddr0 + (unsigned)(((s_ + 1) & 1) * PLF) * 4u, wa + WSLOTS * 4096, wnext, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+      }
     }
     // ---- output transform + polyphase scatter
     if (!row_ok) continue;
     char* const yb = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs);
-    const int qc = 4 * (w0 + l31);                         // this lane's first column q (then +1, +2, +3)
+    const int qc = 4 * (w0 + 32 * cg + l31);               // this lane's first column q (then +1, +2, +3)
     if constexpr (S == 8) {
       // rows of quad Q: output channel 4 mt + Q, phases r = 4 hi .. 4 hi + 3: samples n = 8 q + 4 hi - 4 .. + 3
 #pragma unroll
@@ -467,7 +487,7 @@ bool convt_wino_enabled() {
 bool convt_wino_supported(int Cin, int Cout, int K, int stride, int tpad) {
   if (!convt_wino_enabled()) return false;
   if (!((stride == 8 && K == 16 && tpad == 4) || (stride == 2 && K == 4 && tpad == 1))) return false;
-  return Cin % (2 * KC) == 0 && (Cout * stride) % 128 == 0;
+  return Cin % (2 * KC) == 0 && (Cout * stride) % 64 == 0;
 }
 
 int pack_convt_wino(PackedCtWino& pw, int Cin, int Cout, int K, int stride, int tpad, const float* w_or_v, const float* g,
@@ -509,13 +529,22 @@ int pack_convt_wino_named(PackedCtWino& pw, int Cin, int Cout, int K, int stride
   return pack_convt_wino(pw, Cin, Cout, K, stride, tpad, src->data, w ? nullptr : g->data, b ? b->data : nullptr, st);
 }
 
+template <int S, int NRT>
+static int ct_launch_one(const CtArgs& a, unsigned grid, int total, hipStream_t st) {
+  static_assert(CtGeo<NRT>::LDS_BYTES <= 160 * 1024, "tile does not fit");
+  auto kern = convt_wino_kernel<S, NRT>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)CtGeo<NRT>::LDS_BYTES, st, a, total);
+  return SVOC_OK;
+}
+
 // x [B][Cin][x_ld] (lrelu(pre_slope) applied while staging) -> y [B][Cout][y_ld], Lout = Lin * S.  1 = not eligible.
 int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, int x_ld, float pre_slope, float* y, long long y_bs,
                       int y_ld, int B, int Lin, hipStream_t st) {
   if (B <= 0 || Lin <= 0 || !pw.wp.p) return 1;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (x_ld & 3) || (x_bs & 3)) return 1;
   if ((reinterpret_cast<uintptr_t>(y) & 15) || (y_ld & 3) || (y_bs & 3)) return 1;
-  if ((long long)CtGeo::KS * x_ld * 4 >= (1LL << 31)) return 1;
+  if ((long long)2 * KC * x_ld * 4 >= (1LL << 31)) return 1;
   if (!(pre_slope > 0.f && pre_slope <= 1.f)) return 1;     // the staging's leaky relu is max(x, slope x)
   CtArgs a;
   a.x = x; a.x_bs = x_bs; a.x_ld = x_ld; a.Lin = Lin; a.pre_slope = pre_slope;
@@ -524,8 +553,10 @@ int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, in
   static const bool tail_on = !(getenv("SVOC_CT_TAIL") && atoi(getenv("SVOC_CT_TAIL")) == 0);
   const bool tail = tail_on && (Lin & 3) == 0 && pw.Cin <= 1024;     // the column q = Lin by convt_tail_kernel, the windows cover 0 .. Lin - 1
   const int nw = (Lin + (tail ? 0 : 1) + 3) / 4;          // windows over the columns q = 0 .. Lin
-  a.ntn = (nw + CtGeo::NWT - 1) / CtGeo::NWT;
-  a.gy = pw.mtiles / 4; a.B = B;
+  const int nrt = pw.mtiles % 4 == 0 ? 4 : 2;             // 128-row blocks, or 64 rows x twice the windows
+  const int nwt = 32 * (4 / nrt);
+  a.ntn = (nw + nwt - 1) / nwt;
+  a.gy = pw.mtiles / nrt; a.B = B;
   a.xcd = xcd_mapping_enabled();
   a.flags = 0x100u;
   const long long total = (long long)a.ntn * a.gy * B;
@@ -539,21 +570,15 @@ int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, in
     prof_idx = prof_begin(st, d, flops);
   }
   const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
-  const size_t lds = (size_t)CtGeo::LDS_BYTES;
   if (tail) {
     const dim3 tg((unsigned)((pw.mtiles + 3) / 4), (unsigned)B);
     if (pw.S == 8) hipLaunchKernelGGL(convt_tail_kernel<8>, tg, dim3(1024), 0, st, a, pw.Cin);
     else hipLaunchKernelGGL(convt_tail_kernel<2>, tg, dim3(1024), 0, st, a, pw.Cin);
   }
-  if (pw.S == 8) {
-    auto kern = convt_wino_kernel<8>;
-    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, (int)total);
-  } else {
-    auto kern = convt_wino_kernel<2>;
-    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, (int)total);
-  }
+  int rc = SVOC_OK;
+  if (pw.S == 8) rc = nrt == 4 ? ct_launch_one<8, 4>(a, grid, (int)total, st) : ct_launch_one<8, 2>(a, grid, (int)total, st);
+  else rc = nrt == 4 ? ct_launch_one<2, 4>(a, grid, (int)total, st) : ct_launch_one<2, 2>(a, grid, (int)total, st);
+  if (rc < 0) { prof_end(st, prof_idx); return rc; }
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;

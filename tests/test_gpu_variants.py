@@ -20,6 +20,8 @@ listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run check
   SVOC_GRAPH=0                   short inputs as direct launches (no captured hipGraph plans)
   SVOC_XCD=0                     natural workgroup -> tile order instead of the XCD-aware one
   SVOC_LN_V2=0                   round-1 LayerNorm / DDSConv tile kernel
+  SVOC_CT_WINO=0                 upsamplers on the direct polyphase kernel instead of the Winograd F(4,2) one (convt_wino.hip)
+  SVOC_CT_TAIL=0                 F(4,2) upsamplers: the column q = L inside the window tiles (no separate tail launch)
 """
 import os
 import subprocess
@@ -38,6 +40,7 @@ DEC = ("test_conv1d_winograd or test_resblock1 or test_generator or test_infer_v
 WNS = "test_wn or test_coupling or test_infer_vs_reference_golden or test_full_size_properties"
 SMALL = "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_generator or test_wn or test_resblock1"
 OFFG = "test_dds or test_layer_norm or test_convflow"
+UPS = "test_conv_transpose or test_generator or test_infer_vs_reference_golden or test_c2_full_size_vs_oracle"
 
 VARIANTS = {
     "unfused": ({"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"}, DEC + " or " + WNS),
@@ -57,6 +60,8 @@ VARIANTS = {
     "no_graph": ({"SVOC_GRAPH": "0"}, SMALL),
     "natural_tile_order": ({"SVOC_XCD": "0"}, DEC),
     "layernorm_v1": ({"SVOC_LN_V2": "0"}, OFFG),
+    "upsamplers_direct": ({"SVOC_CT_WINO": "0"}, UPS),
+    "upsamplers_f42_no_tail_launch": ({"SVOC_CT_TAIL": "0"}, UPS),
 }
 
 
