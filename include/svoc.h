@@ -257,6 +257,10 @@ int svoc_melspec_create(svoc_melspec** out, int n_fft, int hop_length, int win_l
 int svoc_melspec_frames(svoc_melspec* h, int64_t n_samples);      /* frames produced for a waveform of n_samples */
 /* y [B, n_samples] -> spec [B, n_fft/2+1, frames] = sqrt(re^2 + im^2 + 1e-6) (reflect pad (n_fft-hop)/2, center=False) */
 int svoc_melspec_spectrogram(svoc_melspec* h, void* stream, const float* y, int B, int n_samples, float* spec);
+/* ABI 4: the same with torch.stft's center flag (mel_processing.py:66-67 forwards it): center != 0 frames the signal after a
+ * second reflect padding of n_fft/2 on both sides, as torch.stft(center=True, pad_mode='reflect') does; center == 0 is the call above */
+int svoc_melspec_frames_center(svoc_melspec* h, int64_t n_samples, int center);
+int svoc_melspec_spectrogram_center(svoc_melspec* h, void* stream, const float* y, int B, int n_samples, int center, float* spec);
 /* spec [B, n_fft/2+1, F] -> mel [B, n_mels, F] = log(clamp(mel_basis @ spec, 1e-5)) */
 int svoc_melspec_mel(svoc_melspec* h, void* stream, const float* spec, int B, int n_frames, float* mel);
 int svoc_mel_filterbank(int sampling_rate, int n_fft, int n_mels, double fmin, double fmax, float* out_host);

@@ -47,11 +47,11 @@ def mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None):
     return (w * enorm[:, None]).astype(np.float32)
 
 
-def spectrogram(y, n_fft, hop, win):
-    """mel_processing.py:51-70 with center=False"""
+def spectrogram(y, n_fft, hop, win, center=False):
+    """mel_processing.py:51-70 (center is forwarded to torch.stft, :66-67)"""
     pad = int((n_fft - hop) / 2)
     y = torch.nn.functional.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
-    s = torch.stft(y, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win, dtype=y.dtype), center=False,
+    s = torch.stft(y, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win, dtype=y.dtype), center=center,
                    pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
     s = torch.view_as_real(s)
     return torch.sqrt(s.pow(2).sum(-1) + 1e-6)
@@ -62,5 +62,5 @@ def spec_to_mel(spec, n_fft, n_mels, sr, fmin, fmax):
     return torch.log(torch.clamp(torch.matmul(basis, spec), min=1e-5))
 
 
-def mel_spectrogram(y, n_fft, n_mels, sr, hop, win, fmin, fmax):
-    return spec_to_mel(spectrogram(y, n_fft, hop, win), n_fft, n_mels, sr, fmin, fmax)
+def mel_spectrogram(y, n_fft, n_mels, sr, hop, win, fmin, fmax, center=False):
+    return spec_to_mel(spectrogram(y, n_fft, hop, win, center), n_fft, n_mels, sr, fmin, fmax)

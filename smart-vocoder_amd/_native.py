@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVOC_LIB selects another build of the same library (A/B comparisons of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("SVOC_LIB") or os.path.join(_HERE, "csrc", "libsvoc_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 
@@ -96,6 +96,8 @@ SIGNATURES = {
     "svoc_melspec_create": (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, C.c_double, C.c_double]),
     "svoc_melspec_frames": (_I, [_P, _L]),
     "svoc_melspec_spectrogram": (_I, [_P, _P, _P, _I, _I, _P]),
+    "svoc_melspec_frames_center": (_I, [_P, _L, _I]),
+    "svoc_melspec_spectrogram_center": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "svoc_melspec_mel": (_I, [_P, _P, _P, _I, _I, _P]),
     "svoc_mel_filterbank": (_I, [_I, _I, _I, C.c_double, C.c_double, _P]),
     "svoc_melspec_destroy": (None, [_P]),

@@ -94,17 +94,22 @@ struct MelSpec {
     return SVOC_OK;
   }
 
-  int frames(long long Lw) const { const long long Lp = Lw + 2LL * pad; return Lp < n_fft ? 0 : (int)((Lp - n_fft) / hop + 1); }
+  int frames(long long Lw, int center = 0) const {
+    const long long Lp = Lw + 2LL * pad + (center ? 2LL * (n_fft / 2) : 0);
+    return Lp < n_fft ? 0 : (int)((Lp - n_fft) / hop + 1);
+  }
 
-  // y [B][Lw] in [-1,1] -> spec [B][nbins][F]
-  int spectrogram(hipStream_t st, const float* y, int B, int Lw, float* spec) {
+  // y [B][Lw] in [-1,1] -> spec [B][nbins][F]; center: torch.stft(center=True)'s second reflect padding of n_fft / 2
+  int spectrogram(hipStream_t st, const float* y, int B, int Lw, float* spec, int center = 0) {
     if (Lw <= pad) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "melspec: waveform shorter than the reflect padding");
-    const int F = frames(Lw);
+    const int pad2 = center ? n_fft / 2 : 0;
+    if (center && Lw + 2LL * pad <= pad2) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "melspec: padded waveform shorter than the centre padding");
+    const int F = frames(Lw, center);
     if (F <= 0) return SVOC_OK;
     const int nblk = F + q - 1, ld = round_up(nblk, 4);
     const long long per = (long long)hop * ld;
     SVOC_TRY(ws.ensure((size_t)per * B * sizeof(float)));
-    SVOC_TRY(k_frame_blocks(st, y, B, Lw, pad, hop, ws.f(), per, ld, nblk));
+    SVOC_TRY(k_frame_blocks(st, y, B, Lw, pad, pad2, hop, ws.f(), per, ld, nblk));
     ConvArgs a = mel_args();
     a.x = ws.f(); a.x_bs = per; a.x_ld = ld; a.Lin = nblk;
     a.Ncols = F;
@@ -146,6 +151,12 @@ int svoc_melspec_frames(svoc_melspec* h, int64_t n_samples) { return h ? h->m.fr
 int svoc_melspec_spectrogram(svoc_melspec* h, void* stream, const float* y, int B, int n_samples, float* spec) {
   if (!h || !y || !spec || B <= 0 || n_samples <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_melspec_spectrogram: bad arguments");
   try { return h->m.spectrogram(as_stream(stream), y, B, n_samples, spec); }
+  catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
+}
+int svoc_melspec_frames_center(svoc_melspec* h, int64_t n_samples, int center) { return h ? h->m.frames(n_samples, center) : 0; }
+int svoc_melspec_spectrogram_center(svoc_melspec* h, void* stream, const float* y, int B, int n_samples, int center, float* spec) {
+  if (!h || !y || !spec || B <= 0 || n_samples <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_melspec_spectrogram_center: bad arguments");
+  try { return h->m.spectrogram(as_stream(stream), y, B, n_samples, spec, center ? 1 : 0); }
   catch (const std::exception& e) { ::svoc::set_error("exception: %s", e.what()); return SVOC_ERR_NOMEM; }
 }
 int svoc_melspec_mel(svoc_melspec* h, void* stream, const float* spec, int B, int n_frames, float* mel) {

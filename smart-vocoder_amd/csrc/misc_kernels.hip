@@ -300,16 +300,20 @@ int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, floa
 
 // Reflect-pad the waveform by `pad` on both sides (mel_processing.py:63) and lay it out as xt[b][c][t] =
 // padded[t*hop + c]: frames of n_fft = q*hop samples become a q-tap convolution over t with hop input channels.
-__global__ void frame_blocks_kernel(const float* __restrict__ y, int Lw, int pad, int hop, float* __restrict__ xt,
+// pad2 > 0: torch.stft's own center=True padding (n_fft / 2, reflect) around the once-padded signal (mel_processing.py:66-67).
+__global__ void frame_blocks_kernel(const float* __restrict__ y, int Lw, int pad, int pad2, int hop, float* __restrict__ xt,
                                     long long xt_bs, int xt_ld, int nblocks) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = blockIdx.y, b = blockIdx.z;
   if (t >= nblocks) return;
-  const long long Lp = (long long)Lw + 2 * pad;
+  const long long L1 = (long long)Lw + 2 * pad, Lp = L1 + 2 * pad2;
   const long long i = (long long)t * hop + c;
   float v = 0.f;
   if (i < Lp) {
-    long long s = i - pad;
+    long long j = i - pad2;                  // index into the once-padded signal
+    if (j < 0) j = -j;
+    if (j >= L1) j = 2 * (L1 - 1) - j;
+    long long s = j - pad;
     if (s < 0) s = -s;                       // reflect (no edge repeat)
     if (s >= Lw) s = 2LL * (Lw - 1) - s;
     s = s < 0 ? 0 : (s >= Lw ? Lw - 1 : s);
@@ -317,9 +321,9 @@ __global__ void frame_blocks_kernel(const float* __restrict__ y, int Lw, int pad
   }
   xt[(long long)b * xt_bs + (long long)c * xt_ld + t] = v;
 }
-int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int hop, float* xt, long long xt_bs, int xt_ld, int nblocks) {
+int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int pad2, int hop, float* xt, long long xt_bs, int xt_ld, int nblocks) {
   if (B <= 0 || nblocks <= 0) return SVOC_OK;
-  hipLaunchKernelGGL(frame_blocks_kernel, dim3((nblocks + 255) / 256, hop, B), dim3(256), 0, st, y, Lw, pad, hop, xt, xt_bs, xt_ld, nblocks);
+  hipLaunchKernelGGL(frame_blocks_kernel, dim3((nblocks + 255) / 256, hop, B), dim3(256), 0, st, y, Lw, pad, pad2, hop, xt, xt_bs, xt_ld, nblocks);
   SVOC_HIP(hipGetLastError());
   stats_add_other();
   return SVOC_OK;
@@ -341,7 +345,7 @@ int k_fill(hipStream_t st, float* p, size_t n, float v) {
 
 extern "C" {
 const char* svoc_last_error(void) { return svoc::last_error(); }
-int svoc_abi_version(void) { return 3; }
+int svoc_abi_version(void) { return 4; }
 const char* svoc_build_arch(void) { return "gfx950"; }
 int svoc_stats_reset(void) { svoc::stats_reset(); return SVOC_OK; }
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches) {

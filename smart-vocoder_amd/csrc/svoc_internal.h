@@ -223,7 +223,7 @@ int k_copy2d(hipStream_t st, const float* src, long long s_bs, int s_ld, float* 
 int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
                 int C, int T);
 int k_fill(hipStream_t st, float* p, size_t n, float v);
-int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int hop, float* xt, long long xt_bs, int xt_ld, int nblocks);
+int k_frame_blocks(hipStream_t st, const float* y, int B, int Lw, int pad, int pad2, int hop, float* xt, long long xt_bs, int xt_ld, int nblocks);
 
 // stats / profiler
 bool prof_enabled();

@@ -63,17 +63,18 @@ def _check_range(y):
 
 
 def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False):
-    """y [B, samples] in [-1, 1] -> magnitude spectrogram [B, n_fft/2+1, frames] (reference mel_processing.py:51-70)."""
-    if center:
-        raise NotImplementedError("center=True is not used by the reference and not built")
+    """y [B, samples] in [-1, 1] -> magnitude spectrogram [B, n_fft/2+1, frames] (reference mel_processing.py:51-70).
+    `center` is torch.stft's flag, forwarded as the reference does (mel_processing.py:66-67): True frames the signal after a
+    second reflect padding of n_fft/2."""
     y, src = _to_gpu(y)
     _check_range(y)
     B, Lw = y.shape
     h = _handle(n_fft, hop_size, win_size, 80, sampling_rate, 0.0, None, y.device)
-    F = N.lib().svoc_melspec_frames(h.h, Lw)
+    c = 1 if center else 0
+    F = N.lib().svoc_melspec_frames_center(h.h, Lw, c)
     spec = torch.empty(B, n_fft // 2 + 1, F, dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
-        N.check(N.lib().svoc_melspec_spectrogram(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, N.ptr(spec)))
+        N.check(N.lib().svoc_melspec_spectrogram_center(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, c, N.ptr(spec)))
     return spec.to(src)
 
 
@@ -92,17 +93,16 @@ def spec_to_mel_torch(spec, n_fft, num_mels, sampling_rate, fmin, fmax):
 
 def mel_spectrogram_torch(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
     """reference mel_processing.py:85-112"""
-    if center:
-        raise NotImplementedError("center=True is not used by the reference and not built")
     y, src = _to_gpu(y)
     _check_range(y)
     B, Lw = y.shape
     h = _handle(n_fft, hop_size, win_size, num_mels, sampling_rate, fmin, fmax, y.device)
-    F = N.lib().svoc_melspec_frames(h.h, Lw)
+    c = 1 if center else 0
+    F = N.lib().svoc_melspec_frames_center(h.h, Lw, c)
     spec = torch.empty(B, n_fft // 2 + 1, F, dtype=torch.float32, device=y.device)
     mel = torch.empty(B, num_mels, F, dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
-        N.check(N.lib().svoc_melspec_spectrogram(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, N.ptr(spec)))
+        N.check(N.lib().svoc_melspec_spectrogram_center(h.h, N.stream_ptr(y.device), N.ptr(y), B, Lw, c, N.ptr(spec)))
         N.check(N.lib().svoc_melspec_mel(h.h, N.stream_ptr(y.device), N.ptr(spec), B, F, N.ptr(mel)))
     return mel.to(src)
 

@@ -65,6 +65,23 @@ def test_spectrogram_and_mel_vs_oracle(B, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,n", [(2, 22050), (1, 1024), (3, 4096 + 5)])
+def test_spectrogram_center_true(B, n):
+    """center=True (mel_processing.py:66-67 forwards the flag to torch.stft): a second reflect padding of n_fft/2 around the
+    manually padded signal, n/hop + 1 + ... frames; against torch.stft itself."""
+    from smart_vocoder_amd import mel_processing as MP
+    y = torch.from_numpy(_audio(13, B, n))
+    spec = MP.spectrogram_torch(y.cuda(), 1024, 22050, 256, 1024, center=True).cpu()
+    ref = MO.spectrogram(y, 1024, 256, 1024, center=True)
+    assert spec.shape == ref.shape and spec.shape[2] == MO.spectrogram(y, 1024, 256, 1024).shape[2] + 4
+    err = (spec - ref).abs().max().item()
+    assert err <= 2e-4 * max(1.0, ref.abs().max().item()), err
+    mel = MP.mel_spectrogram_torch(y.cuda(), 1024, 80, 22050, 256, 1024, 0.0, None, center=True).cpu()
+    mref = MO.mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0.0, None, center=True)
+    assert (mel - mref).abs().max().item() <= 2e-3
+
+
+@pytest.mark.gpu
 def test_notebook_flow_wav_to_audio():
     """inference.ipynb cell 4 end to end on the GPU: audio -> spectrogram_torch -> spec_to_mel_torch -> infer"""
     from smart_vocoder_amd import mel_processing as MP, models
