@@ -30,6 +30,14 @@ namespace svoc {
 
 typedef unsigned int ct_u32x4 __attribute__((ext_vector_type(4)));
 
+// shader-clock stamp kept in scalar registers (the stamped build; __builtin_readcyclecounter() inside the consumer loop made
+// the register allocator spill 800 bytes per lane)
+__device__ __forceinline__ long long ct_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return (long long)t;
+}
+
 struct CtArgs {
   const float* x; long long x_bs; int x_ld; int Lin;      // input [B][Cin][x_ld], valid columns [0, Lin)
   float pre_slope;
@@ -37,14 +45,20 @@ struct CtArgs {
   float* y; long long y_bs; int y_ld; int Lout;           // output [B][Cout][y_ld], Lout = Lin * s
   int ntn; int gy; int B; int xcd;                        // tile id = (row block * B + batch) * ntn + column tile: tiles that share a
   unsigned flags;                                         // row block's weights are neighbours.  flags bit 8: producers at s_setprio 3
+  long long* dbg;                                         // optional [workgroups][16] stamps (svoc_debug_set_stamp_buffer)
 };
 
-// NRT = row tiles per workgroup: 4 (128 rows x 32 windows; a stage = 64 channels) or 2 (64 rows x 64 windows, the consumers as
-// 2 row tiles x 2 column halves; a stage = 32 channels - the planes of 64 windows x 64 channels x 2 sets would not fit)
+// NRT = row tiles per workgroup: 4 (128 rows x 32 windows; a stage = 64 channels), 2 (64 rows x 64 windows, the consumers as
+// 2 row tiles x 2 column halves; a stage = 32 channels - the planes of 64 windows x 64 channels x 2 sets would not fit), or 8
+// (256 rows x 32 windows: EIGHT consumer waves, two per SIMD, on the same planes - twelve waves of <= 168 registers.  The
+// producers only get VALU issue slots in the gaps of their SIMD's MFMA stream; what they have not finished when the stream
+// ends is what the consumers wait for at the stage barrier (tools/ct_timeline.py: 2.4-2.9k of 13k cycles per stage with one
+// consumer per SIMD).  Twice the MFMAs over the same planes halve that share.)
 template <int NRT>
 struct CtGeo {
-  static constexpr int NCT = 4 / NRT;
-  static constexpr int CPS = NRT == 4 ? 2 : 1;            // weight chunks per stage
+  static constexpr int NCT = NRT == 2 ? 2 : 1;
+  static constexpr int NCW = NRT == 8 ? 8 : 4;            // consumer waves
+  static constexpr int CPS = NRT == 2 ? 1 : 2;            // weight chunks per stage
   static constexpr int KS = CPS * KC;                     // channels per stage
   static constexpr int NWT = 32 * NCT;                    // windows per tile (= 4 NWT columns q)
   static constexpr int PQ = NWT;                          // plane row stride
@@ -57,8 +71,8 @@ struct CtGeo {
 };
 
 // S = stride (8: k = 16, pad 4; 2: k = 4, pad 1)
-template <int S, int NRT>
-__global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, const int total) {
+template <int S, int NRT, bool DBG>
+__global__ void __launch_bounds__(NRT == 8 ? 768 : 512) convt_wino_kernel(const CtArgs p, const int total) {
   using Geo = CtGeo<NRT>;
   constexpr int CPS = Geo::CPS;
   constexpr int KS = Geo::KS, PQ = Geo::PQ, RAW = Geo::RAW, PLANE = Geo::PLANE, PLF = Geo::PLF, NSTEP = Geo::NSTEP, WSLOTS = Geo::WSLOTS;
@@ -86,9 +100,9 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     w0_ = (int)((unsigned)(w0_ / Geo::NWT + t) % (unsigned)p.ntn) * Geo::NWT;
   };
 
-  if (wave >= 4) {
+  if (wave >= Geo::NCW) {
     // ================================================================= producer
-    const int pw_ = wave - 4;
+    const int pw_ = wave - Geo::NCW;
     if (p.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
     constexpr int R4 = RAW / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
     constexpr int NIW = RPW * Geo::NWT, TPW = (NIW + 63) / 64;
@@ -151,7 +165,12 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
       issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs, mode_of(xs), 0);
     }
     int ti = 0, ch = 0;
+    long long pc_all0 = 0, pc_bar = 0;
+    if constexpr (DBG) pc_all0 = ct_clock();
+    long long pc_ld = 0, pc_st = 0, pc_tr = 0;
     for (int s_ = 0; s_ < nstages; ++s_) {
+      long long q0 = 0, q1 = 0, q2 = 0;
+      if constexpr (DBG) { q0 = ct_clock(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q1 = ct_clock(); pc_ld += q1 - q0; }
       const int xs_start = 4 * w0 - 4;
       const int mode = mode_of(xs_start);
       const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
@@ -196,6 +215,7 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
           }
         }
       }
+      if constexpr (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); q2 = ct_clock(); pc_st += q2 - q1; }
       int nti = ti, nchn = ch + 1, w0n = w0, bzn = bz, byn = by;
       if (nchn == nst) { nchn = 0; ++nti; if (nti < my_tiles) locate(v0 + nti * stride, w0n, bzn, byn); }
       if (s_ + 1 < nstages) {
@@ -219,31 +239,40 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
           o[4 * PLANE] = __builtin_fmaf(-2.f, v3, d4 - d2);                      // 2 d1 - d2 - 2 d3 + d4
         }
       }
+      long long pb0 = 0;
+      if constexpr (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pb0 = ct_clock(); pc_tr += pb0 - q2; }
       __syncthreads();
+      if constexpr (DBG) pc_bar += ct_clock() - pb0;
       ti = nti; ch = nchn; w0 = w0n; bz = bzn; by = byn;
+    }
+    if constexpr (DBG) if (tid == 64 * Geo::NCW) {                   // producer wave 0: total cycles, cycles waiting at the stage barriers
+      long long* d = p.dbg + 16 * (long long)v0;
+      d[8] = ct_clock() - pc_all0; d[9] = pc_bar; d[12] = pc_ld; d[13] = pc_st; d[14] = pc_tr;      // waiting for the global loads, staging, issue + transform
     }
     return;
   }
 
   // =================================================================== consumer: row tile rt of the block, column group cg
   const int l31 = lane & 31, hi = lane >> 5;
-  const int rt = NRT == 4 ? wave : (wave & 1), cg = NRT == 4 ? 0 : (wave >> 1);
+  const int rt = NRT == 2 ? (wave & 1) : wave, cg = NRT == 2 ? (wave >> 1) : 0;
   const unsigned pbase = (unsigned)(size_t)pl;
   const unsigned baddr0 = pbase + (unsigned)(hi * PQ + 32 * cg + l31) * 4u;
   const unsigned wlane = (unsigned)lane * 16u;
   f32x16 M[5];
   float4 a[2][4];
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
+  auto wload1 = [&](float4& dst, int soff, auto kg_c) {
+    const ct_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane + decltype(kg_c)::value * 1024, soff, 0);
+    dst = *reinterpret_cast<const float4*>(&t);
+  };
   auto wload4 = [&](float4 (&dst)[4], int soff) {
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      const ct_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane + kg * 1024, soff, 0);
-      dst[kg] = *reinterpret_cast<const float4*>(&t);
-    }
+    wload1(dst[0], soff, std::integral_constant<int, 0>{}); wload1(dst[1], soff, std::integral_constant<int, 1>{});
+    wload1(dst[2], soff, std::integral_constant<int, 2>{}); wload1(dst[3], soff, std::integral_constant<int, 3>{});
   };
   // one 32-channel chunk: 20 steps of four MFMAs.  CC = parity of the chunk (which weight register set its first slot is in),
   // PC = its position in the stage's planes
-  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto cc, auto pc) {
+  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext_, auto cc, auto pc) {
+    const int wnext = wnext_ >= 0 ? wnext_ : 0;          // after the last tile: harmless loads of the image's first slots
     constexpr int CC = decltype(cc)::value, PC = decltype(pc)::value;
     float fb[2][4];
     auto request = [&](auto tc) {
@@ -253,10 +282,6 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     auto step = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
       constexpr int WS = T / 4, KG = T % 4;
-      if constexpr (KG == 0) {
-        if constexpr (WS + 1 < WSLOTS) wload4(a[(CC + WS + 1) & 1], wa + (WS + 1) * 4096);
-        else if (wnext >= 0) wload4(a[(CC + 1) & 1], wnext);
-      }
       {
         float(&b)[4] = fb[T & 1];
         if constexpr (T + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
@@ -266,6 +291,10 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
 #pragma unroll
       for (int s = 0; s < 4; ++s) M[WS] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[WS], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // the k-group just used is refilled with the same k-group of the slot TWO ahead (same register set): the load has
+      // 32 MFMAs = ~2000 cycles to arrive (one slot ahead, ~1000, left the stream waiting on L2 for ~12 % of its time)
+      if constexpr (WS + 2 < WSLOTS) wload1(a[(CC + WS) & 1][KG], wa + (WS + 2) * 4096, std::integral_constant<int, KG>{});
+      else wload1(a[(CC + WS) & 1][KG], wnext + (WS + 2 - WSLOTS) * 4096, std::integral_constant<int, KG>{});
       request(std::integral_constant<int, T + 2>{});
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -279,6 +308,8 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
   const unsigned ylb = (unsigned)p.y_ld * 4u;
   float bv[16];
   int bias_mt = -1;
+  long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0, wall0 = 0;      // diagnostics (stamped build): consumer wave 0
+  if constexpr (DBG) { cyc_all0 = ct_clock(); wall0 = (long long)wall_clock64(); }
   for (int ti = 0; ti < my_tiles; ++ti) {
     int w0, bz, by;
     locate(v0 + ti * stride, w0, bz, by);
@@ -286,7 +317,7 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
     const bool row_ok = mt < p.mtiles;
     const int mtc = row_ok ? mt : p.mtiles - 1;
     const int wt = wtile(mtc);
-    if (ti == 0) wload4(a[0], wt);
+    if (ti == 0) { wload4(a[0], wt); wload4(a[1], wt + 4096); }
     {   // rows 32 mt + 8 Q + 4 hi + j belong to output channel (32 mt) / S + ... : the bias of an accumulator row starts in M1
 #pragma unroll
       for (int q = 0; q < 5; ++q)
@@ -307,25 +338,36 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
       const int mtn = byn * NRT + rt;
       wnext_tile = wtile(mtn < p.mtiles ? mtn : p.mtiles - 1);
     }
+    long long c_prev = 0;
     for (int cp = 0; cp < p.nchunks; cp += 2) {            // chunk pairs
       const int wa = wt + cp * WSLOTS * 4096;
       const int wnext = cp + 2 < p.nchunks ? wa + 2 * WSLOTS * 4096 : wnext_tile;
+      long long c0 = 0, c1 = 0;                            // (stamps: a stream ends where the next barrier wait or the epilogue begins)
       if constexpr (CPS == 2) {
         const int s_ = ti * nst + (cp >> 1);
+        if constexpr (DBG) c0 = ct_clock();
         __syncthreads();
+        if constexpr (DBG) c1 = ct_clock();
         const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
         mfma_chunk(baddr0 + off, wa, wa + WSLOTS * 4096, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         mfma_chunk(baddr0 + off, wa + WSLOTS * 4096, wnext, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        if constexpr (DBG) { cyc_bar += c1 - c0; if (c_prev) cyc_mf += c0 - c_prev; c_prev = c1; }
       } else {
         const int s_ = ti * nst + cp;
+        if constexpr (DBG) c0 = ct_clock();
         __syncthreads();
+        if constexpr (DBG) c1 = ct_clock();
         mfma_chunk(baddr0 + (unsigned)((s_ & 1) * PLF) * 4u, wa, wa + WSLOTS * 4096, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (DBG) { cyc_bar += c1 - c0; if (c_prev) cyc_mf += c0 - c_prev; c_prev = c1; }      // (the pair's second barrier wait counts as stream time)
         __syncthreads();
         mfma_chunk(baddr0 + (unsigned)(((s_ + 1) & 1) * PLF) * 4u, wa + WSLOTS * 4096, wnext, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
       }
     }
     // ---- output transform + polyphase scatter
     if (!row_ok) continue;
+    const int LoutE = p.Lout;
+    long long ce0 = 0;
+    if constexpr (DBG) { ce0 = ct_clock(); cyc_mf += ce0 - c_prev; }
     char* const yb = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs);
     const int qc = 4 * (w0 + 32 * cg + l31);               // this lane's first column q (then +1, +2, +3)
     if constexpr (S == 8) {
@@ -347,7 +389,7 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int n = 8 * (qc + i) + 4 * hi - 4;
-          if (n >= 0 && n + 3 < p.Lout) *reinterpret_cast<float4*>(yrow + (long long)n * 4) = yv[i];
+          if (n >= 0 && n + 3 < LoutE) *reinterpret_cast<float4*>(yrow + (long long)n * 4) = yv[i];
         }
       }
     } else {
@@ -368,7 +410,7 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
         for (int c = 0; c < 2; ++c) {                      // the quad's two channels: rows 2 c (phase 0), 2 c + 1 (phase 1)
           float* const yrow = reinterpret_cast<float*>(yb + (size_t)(16 * mt + 4 * Q + 2 * hi + c) * ylb);
           const int n0 = 2 * qc - 1;                       // eight consecutive samples n0 .. n0 + 7: (i, phase) = (0,0) (0,1) (1,0) ...
-          if (n0 >= 0 && n0 + 7 < p.Lout) {
+          if (n0 >= 0 && n0 + 7 < LoutE) {
             yrow[n0] = yv[0][2 * c];
             *reinterpret_cast<float4*>(yrow + n0 + 1) = make_float4(yv[0][2 * c + 1], yv[1][2 * c], yv[1][2 * c + 1], yv[2][2 * c]);
             *reinterpret_cast<float2*>(yrow + n0 + 5) = make_float2(yv[2][2 * c + 1], yv[3][2 * c]);
@@ -379,12 +421,18 @@ __global__ void __launch_bounds__(512, 2) convt_wino_kernel(const CtArgs p, cons
 #pragma unroll
               for (int ph = 0; ph < 2; ++ph) {
                 const int n = n0 + 2 * i + ph;
-                if (n >= 0 && n < p.Lout) yrow[n] = yv[i][2 * c + ph];
+                if (n >= 0 && n < LoutE) yrow[n] = yv[i][2 * c + ph];
               }
           }
         }
       }
     }
+    if constexpr (DBG) cyc_epi += ct_clock() - ce0;
+  }
+  if constexpr (DBG) if (tid == 0) {      // [workgroup][16]: 0 tiles, 1 total cycles, 2 barrier waits, 3 MFMA streams, 4 epilogues, 5 marker, 8/9 producer
+    long long* d = p.dbg + 16 * (long long)v0;
+    d[0] = my_tiles; d[1] = ct_clock() - cyc_all0; d[2] = cyc_bar; d[3] = cyc_mf; d[4] = cyc_epi; d[5] = 5;
+    d[10] = wall0; d[11] = (long long)wall_clock64();     // 100 MHz constant clock
   }
 }
 
@@ -532,9 +580,15 @@ int pack_convt_wino_named(PackedCtWino& pw, int Cin, int Cout, int K, int stride
 template <int S, int NRT>
 static int ct_launch_one(const CtArgs& a, unsigned grid, int total, hipStream_t st) {
   static_assert(CtGeo<NRT>::LDS_BYTES <= 160 * 1024, "tile does not fit");
-  auto kern = convt_wino_kernel<S, NRT>;
+  if (a.dbg) {                                             // stamped build (tools/ct_timeline.py)
+    auto kern = convt_wino_kernel<S, NRT, true>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (CtGeo<NRT>::NCW + 4)), (size_t)CtGeo<NRT>::LDS_BYTES, st, a, total);
+    return SVOC_OK;
+  }
+  auto kern = convt_wino_kernel<S, NRT, false>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)CtGeo<NRT>::LDS_BYTES, st, a, total);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (CtGeo<NRT>::NCW + 4)), (size_t)CtGeo<NRT>::LDS_BYTES, st, a, total);
   return SVOC_OK;
 }
 
@@ -553,14 +607,19 @@ int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, in
   static const bool tail_on = !(getenv("SVOC_CT_TAIL") && atoi(getenv("SVOC_CT_TAIL")) == 0);
   const bool tail = tail_on && (Lin & 3) == 0 && pw.Cin <= 1024;     // the column q = Lin by convt_tail_kernel, the windows cover 0 .. Lin - 1
   const int nw = (Lin + (tail ? 0 : 1) + 3) / 4;          // windows over the columns q = 0 .. Lin
-  const int nrt = pw.mtiles % 4 == 0 ? 4 : 2;             // 128-row blocks, or 64 rows x twice the windows
-  const int nwt = 32 * (4 / nrt);
+  // 256-row blocks (eight consumers) where they leave two workgroups per CU, else 128-row blocks, or 64 rows x twice the windows
+  static const bool nrt8_on = !(getenv("SVOC_CT_ROWS256") && atoi(getenv("SVOC_CT_ROWS256")) == 0);
+  const long long min_tiles = 2LL * device_cu_count();
+  int nrt = pw.mtiles % 4 == 0 ? 4 : 2;
+  if (nrt8_on && pw.mtiles % 8 == 0 && (long long)((nw + 31) / 32) * (pw.mtiles / 8) * variant_batch(B) >= min_tiles) nrt = 8;
+  const int nwt = nrt == 2 ? 64 : 32;
   a.ntn = (nw + nwt - 1) / nwt;
   a.gy = pw.mtiles / nrt; a.B = B;
   a.xcd = xcd_mapping_enabled();
   a.flags = 0x100u;
+  a.dbg = debug_stamp_buffer();
   const long long total = (long long)a.ntn * a.gy * B;
-  if (total > 0x7fffffffLL || total * variant_batch(B) / B < 2LL * device_cu_count()) return 1;      // short inputs: the generic kernel
+  if (total > 0x7fffffffLL || total * variant_batch(B) / B < min_tiles) return 1;      // short inputs: the generic kernel
   const double flops = pw.flops_per_col * (double)B * (double)Lin;
   stats_add_conv(flops, 1, flops * 5.0 / 8.0);
   int prof_idx = -1;
@@ -576,8 +635,8 @@ int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, in
     else hipLaunchKernelGGL(convt_tail_kernel<2>, tg, dim3(1024), 0, st, a, pw.Cin);
   }
   int rc = SVOC_OK;
-  if (pw.S == 8) rc = nrt == 4 ? ct_launch_one<8, 4>(a, grid, (int)total, st) : ct_launch_one<8, 2>(a, grid, (int)total, st);
-  else rc = nrt == 4 ? ct_launch_one<2, 4>(a, grid, (int)total, st) : ct_launch_one<2, 2>(a, grid, (int)total, st);
+  if (pw.S == 8) rc = nrt == 8 ? ct_launch_one<8, 8>(a, grid, (int)total, st) : (nrt == 4 ? ct_launch_one<8, 4>(a, grid, (int)total, st) : ct_launch_one<8, 2>(a, grid, (int)total, st));
+  else rc = nrt == 8 ? ct_launch_one<2, 8>(a, grid, (int)total, st) : (nrt == 4 ? ct_launch_one<2, 4>(a, grid, (int)total, st) : ct_launch_one<2, 2>(a, grid, (int)total, st));
   if (rc < 0) { prof_end(st, prof_idx); return rc; }
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());

@@ -22,6 +22,7 @@ listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run check
   SVOC_LN_V2=0                   round-1 LayerNorm / DDSConv tile kernel
   SVOC_CT_WINO=0                 upsamplers on the direct polyphase kernel instead of the Winograd F(4,2) one (convt_wino.hip)
   SVOC_CT_TAIL=0                 F(4,2) upsamplers: the column q = L inside the window tiles (no separate tail launch)
+  SVOC_CT_ROWS256=0              F(4,2) upsamplers: 128-row blocks (four consumer waves) where 256-row blocks would be used
 """
 import os
 import subprocess
@@ -62,6 +63,7 @@ VARIANTS = {
     "layernorm_v1": ({"SVOC_LN_V2": "0"}, OFFG),
     "upsamplers_direct": ({"SVOC_CT_WINO": "0"}, UPS),
     "upsamplers_f42_no_tail_launch": ({"SVOC_CT_TAIL": "0"}, UPS),
+    "upsamplers_f42_128_row_blocks": ({"SVOC_CT_ROWS256": "0"}, UPS),
 }
 
 
