@@ -22,6 +22,8 @@ python $R/tools/pmc_traffic.py /tmp/pr /tmp/pw $NK 2 > $O/${TAG}_pmc_hbm_traffic
 
 
 ( cd $R && for k in 3 7 11; do python tools/wino4_timeline.py 128 $k 1; done; python tools/wino4_timeline.py 128 11 3; python tools/wino4_timeline.py 256 11 1 ) > $O/${TAG}_winograd_f43_workgroup_stamps.txt 2>/dev/null
+( cd $R && for sh in "512 256 16 8 512" "256 128 16 8 4096" "128 64 4 2 32768" "64 32 4 2 65536"; do python tools/ct_timeline.py $sh; done; SVOC_CT_ROWS256=0 python tools/ct_timeline.py 512 256 16 8 512; SVOC_CT_ROWS256=0 python tools/ct_timeline.py 256 128 16 8 4096 ) > $O/${TAG}_upsampler_f42_workgroup_stamps.txt 2>/dev/null
+( cd $R && for v in 1 0; do SVOC_CT_WINO=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1; done ) > $O/${TAG}_bench_upsamplers_f42_vs_direct.txt
 ( cd $R && python tools/wn_timeline.py 16 512 ) > $O/${TAG}_wn_layer_phase_stamps.txt 2>/dev/null
 ( cd $R && python tools/wino_bench.py 128 32768; python tools/wino_bench.py 64 65536; python tools/wino_bench.py 256 4096 ) > $O/${TAG}_winograd_f43_per_conv.txt 2>/dev/null
 ls -la $O
