@@ -196,7 +196,7 @@ int pack_convt_wino(PackedCtWino& pw, int Cin, int Cout, int K, int stride, int 
                     const float* bias, hipStream_t st);
 int pack_convt_wino_named(PackedCtWino& pw, int Cin, int Cout, int K, int stride, int tpad, const TensorTable& tab,
                           const std::string& prefix, hipStream_t st);
-// 1 = not eligible (alignment, or fewer than two workgroups per CU)
+// 1 = not eligible (alignment, or fewer workgroups than half the CUs)
 int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, int x_ld, float pre_slope, float* y, long long y_bs,
                       int y_ld, int B, int Lin, hipStream_t st);
 

@@ -215,8 +215,8 @@ def test_conv_transpose_geometries(M, k, s):
                                           (64, 32, 4, 2, 16384, 9), (64, 8, 16, 8, 8192, 16), (128, 24, 16, 8, 2048, 22), (256, 128, 16, 8, 1024, 16),
                                           (128, 128, 4, 2, 4096, 17)])
 def test_conv_transpose_winograd(M, ci, co, k, s, L, B):
-    """The upsamplers' F(4,2) kernel (convt_wino.hip): k = 2 s, stride 8 and 2, shapes large enough to pass its two-workgroups-
-    per-CU gate (checked through the executed-flop counter: 5/8 of the algorithmic count); ragged last window tiles, the extra
+    """The upsamplers' F(4,2) kernel (convt_wino.hip): k = 2 s, stride 8 and 2, shapes large enough to pass its
+    workgroup-count gate (checked through the executed-flop counter: 5/8 of the algorithmic count); ragged last window tiles, the extra
     column q = L, both edges; 256-row blocks (eight consumer
     waves), 128-row blocks and 64-row blocks (two row tiles x two column halves)."""
     import ctypes, os
