@@ -293,13 +293,16 @@ int svoc_conv1d(void* stream, const float* x, const float* weight_v, const float
                 const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation,
                 float pre_slope);
 /* The same operation for kernel_size 3 / 7 / 11, dilation 1 / 3 / 5, Cin >= 64, channel counts multiples of 32 and
- * L % 4 == 0, computed in Winograd F(2,3) form (csrc/conv_wino.hip): what the decoder's C = 128 / 256 stages run.
+ * L % 4 == 0, computed in Winograd form (F(4,3), csrc/conv_wino4.hip; F(2,3), csrc/conv_wino.hip, with SVOC_WINO_F4=0): what the
+ * decoder's C >= 64 stages run.
  * Unit-test entry; returns SVOC_ERR_UNSUPPORTED for other shapes. */
 int svoc_conv1d_winograd(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias,
                          const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation,
                          float pre_slope);
 /* F.leaky_relu -> weight-normed ConvTranspose1d(k, stride, padding=(k-stride)//2) (models.py:125-127, 147-148):
- * x [B,Cin,L], weight_v [Cin,Cout,k], weight_g [Cin,1,1] or NULL, y [B,Cout,L*stride] */
+ * x [B,Cin,L], weight_v [Cin,Cout,k], weight_g [Cin,1,1] or NULL, y [B,Cout,L*stride].  k = 2 * stride with stride 8 or 2,
+ * Cin % 64 == 0, Cout * stride % 64 == 0, L % 4 == 0 and at least half as many tiles as CUs: Winograd F(4,2) over the polyphase
+ * filters (csrc/convt_wino.hip, what the decoder's upsamplers run); otherwise the direct polyphase GEMM (csrc/conv_mfma.hip). */
 int svoc_conv_transpose1d(void* stream, const float* x, const float* weight_v, const float* weight_g,
                           const float* bias, float* y, int B, int Cin, int Cout, int L, int kernel_size, int stride,
                           float pre_slope);
