@@ -314,7 +314,7 @@ def main():
                            "winograd_form_floor_ms": stats["executed_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "direct_form_floor_ms": stats["conv_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group)_kernel (Winograd F(4,3), C>=64 ResBlock convolutions), conv_mfma_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel (fallbacks: conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group)_kernel (Winograd F(4,3), C>=64 ResBlock convolutions), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel (fallbacks: conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
                            "note": "achieved/frac = algorithmic direct-form 2*MAC of the convolutions (SURVEY.md 8d) / time: with the Winograd F(2,3) kernels "
                                    "(which issue 1/2, 4/7, 6.5/11 of those multiply-adds for k=3/7/11 in F(4,3) form) the direct-form peak is NOT a bound on it; "
                                    "achieved_executed/frac_executed = 2*MAC the matrix pipe really issued (counted per launch by the library) / time, "

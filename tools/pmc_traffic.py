@@ -17,10 +17,15 @@ def load(path):
 
 rd, rn = load(sys.argv[1]); wr, wn = load(sys.argv[2])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-def is_model(n): return any(k in n for k in ("conv_mfma", "conv_group", "conv_ksplit", "conv_wino", "resblock_fused", "wn_layer_fused", "conv_post", "copy2d", "sequence_mask"))
-# only the last `steps` inference steps: count GEMM-family dispatches per step from the tail
+def is_model(n): return any(k in n for k in ("conv_mfma", "conv_group", "conv_ksplit", "conv_wino", "convt_wino", "convt_tail", "resblock_fused", "wn_layer_fused", "conv_post", "copy2d", "sequence_mask"))
+# only the last `steps` inference steps: a step starts at its sequence_mask dispatch (as tools/timeline.py cuts the trace); the
+# third argument (kernels per step) is only the fallback when the trace holds no such dispatch
 def tail(by, names, per_step):
-    ids = [i for i in sorted(by) if is_model(names[i])]
+    ids = sorted(by)
+    marks = [k for k, i in enumerate(ids) if "sequence_mask" in names[i]]
+    if len(marks) >= steps:
+        return ids[marks[-steps]:]
+    ids = [i for i in ids if is_model(names[i])]
     return ids[-per_step * steps:]
 per_step = int(sys.argv[3])
 rid = tail(rd, rn, per_step); wid = tail(wr, wn, per_step)
@@ -32,7 +37,7 @@ def wbytes(c):
     n64, tot = c.get("TCC_EA0_WRREQ_64B_sum", 0), c.get("TCC_EA0_WRREQ_sum", 0)
     return 64 * n64 + 32 * max(0.0, tot - n64)
 R = sum(rbytes(rd[i]) for i in rid) / steps; W = sum(wbytes(wr[i]) for i in wid) / steps
-gemm = lambda n: any(k in n for k in ("conv_mfma", "conv_group", "conv_ksplit", "conv_wino", "resblock_fused", "wn_layer_fused"))
+gemm = lambda n: any(k in n for k in ("conv_mfma", "conv_group", "conv_ksplit", "conv_wino", "convt_wino", "resblock_fused", "wn_layer_fused"))
 Rg = sum(rbytes(rd[i]) for i in rid if gemm(rn[i])) / steps; Wg = sum(wbytes(wr[i]) for i in wid if gemm(wn[i])) / steps
 ng = sum(1 for i in rid if gemm(rn[i])) / steps
 print(json.dumps({"hbm_read_bytes_per_step": R, "hbm_write_bytes_per_step": W, "gemm_family_read_bytes_per_step": Rg,
