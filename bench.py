@@ -129,6 +129,40 @@ def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     return best, rep
 
 
+def live_hbm_traffic(B, T, timeout_s=150):
+    """Two child runs of this script under `rocprofv3 --pmc` (read-request counters, then write-request counters: separate passes,
+    no tracing beside them), 2 steps each; returns (HBM bytes of the GEMM-family kernels per step, description)."""
+    import shutil, subprocess, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        raise RuntimeError("rocprofv3 not found")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    base = tempfile.mkdtemp(prefix="svoc_pmc_", dir="/tmp")
+    try:
+        dirs = []
+        for tag, counters in (("rd", pmc_traffic.READ_COUNTERS), ("wr", pmc_traffic.WRITE_COUNTERS)):
+            d = os.path.join(base, tag)
+            cmd = [prof, "--pmc", *counters, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--batch", str(B), "--frames", str(T), "--no-cpu-baseline", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                raise RuntimeError(f"rocprofv3 pass {tag} exit {r.returncode}: {r.stdout[-200:].decode(errors='replace')}")
+            dirs.append(d)
+        tj = pmc_traffic.traffic(dirs[0], dirs[1], 0, 2)
+        if tj["gemm_family_launches_per_step"] < 1:
+            raise RuntimeError("no GEMM-family dispatches in the counter traces")
+        return (tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"],
+                f"LIVE: two `rocprofv3 --pmc` child runs of bench.py after the timed region ({', '.join(pmc_traffic.READ_COUNTERS)} | "
+                f"{', '.join(pmc_traffic.WRITE_COUNTERS)}; 2 steps each, {tj['dispatches_counted_per_step']:.0f} dispatches per step; "
+                f"whole step {((tj['hbm_read_bytes_per_step'] + tj['hbm_write_bytes_per_step']) / 1e9):.1f} GB)")
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +171,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=512, help="mel frames per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic passes (rocprofv3 --pmc child runs of this script)")
     ap.add_argument("--allow-no-collective", action="store_true", help="N>1: do not fail when neither gather nor all_gather works")
     args = ap.parse_args()
 
@@ -339,20 +374,32 @@ def main():
                 "achieved": dom["tflops"], "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 "executed_mfma_flop_fraction": executed, "mfma_pipe_frac": dom["tflops"] * executed / FP32_MFMA_PEAK_TFLOPS,
                 "measured": "hipEventRecord around every launch on the launch stream (library event profiler), after the timed region"}
-        # HBM traffic of the same workload from PMC counters: they cannot be read from inside this process, so the figure
-        # comes from the committed rocprofv3 --pmc passes of THIS round's code (tools/pmc_traffic.py); older files are ignored.
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND_TAG}*_pmc_hbm_traffic.json")))
-        if tfiles and B == 16 and T == 512:
+        # HBM traffic of the same workload from PMC counters.  They cannot be read from inside this process: at N=1 two child runs
+        # of this script (2 steps, no CPU leg) are made under `rocprofv3 --pmc`, read- and write-request counters in separate
+        # passes as MI355X_MICROARCH.md prescribes, and summed per step by tools/pmc_traffic.py.  If the profiler is missing, fails
+        # or times out, the figure is taken from this round's committed passes instead and labelled OFFLINE.
+        step_bytes, tsrc = None, None
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)      # never nest profilers
+        if world == 1 and not args.no_pmc and not under_profiler and B == 16 and T == 512:
             try:
-                tj = json.load(open(tfiles[-1]))
-                step_bytes = tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"]
-                res["roofline"]["traffic"] = step_bytes / max(1.0, res["roofline"]["gemm_launches_per_step"])
-                res["roofline"]["traffic_unit"] = "HBM bytes per GEMM-family launch (mean over gemm_launches_per_step), OFFLINE measurement"
-                res["roofline"]["traffic_bytes_per_step"] = step_bytes
-                res["roofline"]["traffic_source"] = f"offline: profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*, separate passes)"
-            except Exception:   # noqa: BLE001
-                pass
+                step_bytes, tsrc = live_hbm_traffic(B, T)
+            except Exception as e:   # noqa: BLE001
+                res["roofline"]["traffic_live_error"] = f"{type(e).__name__}: {e}"[:300]
+        if step_bytes is None:
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND_TAG}*_pmc_hbm_traffic.json")))
+            if tfiles and B == 16 and T == 512:
+                try:
+                    tj = json.load(open(tfiles[-1]))
+                    step_bytes = tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"]
+                    tsrc = f"OFFLINE: profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*, separate passes)"
+                except Exception:   # noqa: BLE001
+                    pass
+        if step_bytes is not None:
+            res["roofline"]["traffic"] = step_bytes / max(1.0, res["roofline"]["gemm_launches_per_step"])
+            res["roofline"]["traffic_unit"] = "HBM bytes per GEMM-family launch (mean over gemm_launches_per_step)"
+            res["roofline"]["traffic_bytes_per_step"] = step_bytes
+            res["roofline"]["traffic_source"] = tsrc
         fail = None
         if world == 1 and not args.no_cpu_baseline:
             keep = {}

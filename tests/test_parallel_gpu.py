@@ -108,7 +108,7 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
 def test_bench_single_gpu_line_schema():
     """bench.py at N=1 on the timed configuration (16 x 512, 2 steps, no CPU leg): ONE JSON line with the contract's keys, the
     roofline block with both fractions (direct-form `frac`, which the Winograd kernels may push above 1, and `frac_executed`,
-    which is bounded by the peak) and the library's launch statistics."""
+    which is bounded by the peak), the library's launch statistics and the HBM traffic of the step (live PMC passes)."""
     cmd = [sys.executable, os.path.join(cases.ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -124,3 +124,6 @@ def test_bench_single_gpu_line_schema():
     assert 0.0 < rf["frac_executed"] <= 1.0 and rf["frac_executed"] <= rf["frac"] + 1e-9
     assert abs(rf["flop_per_step"] - 2568280.0 * j["config"]["samples_per_step"]) / rf["flop_per_step"] < 0.01
     assert 0.5 < rf["executed_mfma_flop_fraction"] <= 1.0
+    # HBM traffic: live rocprofv3 --pmc child runs (or, should the profiler fail on the box, this round's committed passes)
+    assert rf["traffic"] is not None and rf["traffic_source"].startswith(("LIVE", "OFFLINE")), rf
+    assert 2e10 < rf["traffic_bytes_per_step"] < 8e10, rf["traffic_bytes_per_step"]

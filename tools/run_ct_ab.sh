@@ -6,7 +6,7 @@ timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "conv_tran
 tail -5 $out/pytest.txt
 for v in 1 0; do
   for i in 1 2; do
-    SVOC_CT_WINO=$v timeout 300 python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $out/bench_ct${v}_$i.json
+    SVOC_CT_WINO=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-pmc 2>/dev/null | tail -1 > $out/bench_ct${v}_$i.json
     python - <<PY
 import json; d=json.load(open("$out/bench_ct${v}_$i.json")); print("CT_WINO=$v", d["ms_per_step"], d.get("parity"))
 PY

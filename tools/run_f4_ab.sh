@@ -10,8 +10,8 @@ SVOC_WINO_F4=0 timeout 300 python tools/wino_bench.py 2>/dev/null > $O/wino_benc
 paste $O/wino_bench_f2.txt $O/wino_bench_f4.txt | awk '{print $1,$4,$5,$6, $(NF/2-1), $(NF/2), "|", $(NF/2+1), $(NF-1), $NF}'
 for k in 3 7 11; do timeout 120 python tools/wino4_timeline.py 128 $k 1 2>/dev/null; done | tee $O/wino4_timeline.txt
 timeout 120 python tools/wino4_timeline.py 256 11 1 2>/dev/null | tee -a $O/wino4_timeline.txt
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_f4.json 2> $O/bench_f4.err
-SVOC_WINO_F4=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_f2.json 2> $O/bench_f2.err
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc > $O/bench_f4.json 2> $O/bench_f4.err
+SVOC_WINO_F4=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc > $O/bench_f2.json 2> $O/bench_f2.err
 python - <<PY
 import json
 for t in ("f2","f4"):
