@@ -238,6 +238,13 @@ def test_conv_transpose_winograd(M, ci, co, k, s, L, B):
     st = N.stats_get()
     assert st["conv_flops"] > 0 and abs(st["executed_flops"] / st["conv_flops"] - 5.0 / 8.0) < 1e-6, st
     check(f"convT F(4,2) k{k} s{s} ci{ci} L{L}", y, ref)
+    if L == 1000:   # no activation in front (slope 1) and another slope
+        for slope in (1.0, 0.25):
+            ref2 = torch.nn.functional.conv_transpose1d(torch.nn.functional.leaky_relu(x, slope), w, bias, stride=s, padding=(k - s) // 2)
+            y.fill_(float("nan"))
+            N.check(N.lib().svoc_conv_transpose1d(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), N.ptr(y), B, ci, co, L, k, s,
+                                                  ctypes.c_float(slope)))
+            check(f"convT F(4,2) slope {slope}", y, ref2)
 
 
 @pytest.mark.parametrize("name", list(cases.UPS_CASES))
