@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""fp32 error of candidate Winograd / Cook-Toom forms F(m, r) against the direct form (numpy, CPU): matrices built exactly (fractions)
+from the interpolation points, checked for exactness in float64, then run in float32 on random windows.  Design input for the
+choice of forms (DESIGN.md "Candidates for round 4"); not part of the product path.   python tools/wino_numerics.py"""
+import numpy as np
+from fractions import Fraction as F
+def cook_toom(m, r, pts):
+    # F(m,r): n = m+r-1 points (last = infinity). Returns AT (m x n), G (n x r), BT (n x n) in float64, correlation form.
+    n = m + r - 1
+    assert len(pts) == n - 1
+    # polynomial-evaluation matrices
+    def V(rows, cols):  # rows: points, evaluate poly of degree cols-1
+        M = [[F(p) ** j for j in range(cols)] for p in pts]
+        M.append([F(0)] * (cols - 1) + [F(1)])
+        return M
+    A = V(n, m)      # n x m
+    G = V(n, r)      # n x r
+    # scale G rows by 1/prod(p_i - p_j)
+    for i, p in enumerate(pts):
+        d = F(1)
+        for j, q in enumerate(pts):
+            if i != j: d *= (F(p) - F(q))
+        G[i] = [g / d for g in G[i]]
+    # B^T from interpolation: linear-convolution algorithm transposed -> correlation: Y = A^T [(G g) * (B^T d)]
+    # B^T = inverse-transpose relation: rows are coefficients of M(x)/(x-p_i) etc.  Build by solving: for all d, g the identity holds.
+    # Use the known construction: B^T[i] = coefficients of prod_{j!=i}(x - p_j) (degree n-2... padded), last row = prod_j (x - p_j)
+    import numpy.polynomial.polynomial as P
+    BT = []
+    for i, p in enumerate(pts):
+        c = [F(1)]
+        for j, q in enumerate(pts):
+            if i != j:
+                c = [ (c[k-1] if k>0 else F(0)) - F(q) * (c[k] if k < len(c) else F(0)) for k in range(len(c)+1)]
+        BT.append(c + [F(0)] * (n - len(c)))
+    c = [F(1)]
+    for q in pts:
+        c = [ (c[k-1] if k>0 else F(0)) - F(q) * (c[k] if k < len(c) else F(0)) for k in range(len(c)+1)]
+    BT.append(c)
+    f = lambda M: np.array([[float(x) for x in row] for row in M])
+    return f(A).T, f(G), f(BT)
+def check(m, r, pts, N=200000, seed=0):
+    AT, G, BT = cook_toom(m, r, pts)
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((N, m + r - 1)); g = rng.standard_normal((N, r)) / np.sqrt(r)
+    ref = np.stack([(d[:, i:i + r] * g).sum(1) for i in range(m)], 1)
+    y64 = ((g @ G.T) * (d @ BT.T)) @ AT.T
+    e64 = np.abs(y64 - ref).max()
+    d32, g32 = d.astype(np.float32), g.astype(np.float32)
+    U = (g32 @ G.T.astype(np.float32)); Vv = (d32 @ BT.T.astype(np.float32))
+    y32 = ((U * Vv) @ AT.T.astype(np.float32))
+    dir32 = np.stack([(d32[:, i:i + r] * g32).sum(1, dtype=np.float32) for i in range(m)], 1)
+    rms = lambda a: float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
+    return e64, rms(y32 - ref) / rms(ref), rms(dir32 - ref) / rms(ref)
+for name, m, r, pts in (("F(2,3)", 2, 3, [0, 1, -1]), ("F(4,3)", 4, 3, [0, 1, -1, 2, -2]), ("F(2,5)", 2, 5, [0, 1, -1, 2, -2]),
+                        ("F(2,5) halves", 2, 5, [0, 1, -1, F(1, 2), F(-1, 2)]), ("F(4,5)", 4, 5, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)]),
+                        ("F(6,3)", 6, 3, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)])):
+    e64, w, dr = check(m, r, pts)
+    print(f"{name:14s} exactness (f64 max err) {e64:.1e}   fp32 rel-RMS: winograd {w:.2e}   direct {dr:.2e}   ratio {w / dr:.1f}")
