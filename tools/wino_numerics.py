@@ -56,3 +56,37 @@ for name, m, r, pts in (("F(2,3)", 2, 3, [0, 1, -1]), ("F(4,3)", 4, 3, [0, 1, -1
                         ("F(6,3)", 6, 3, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)])):
     e64, w, dr = check(m, r, pts)
     print(f"{name:14s} exactness (f64 max err) {e64:.1e}   fp32 rel-RMS: winograd {w:.2e}   direct {dr:.2e}   ratio {w / dr:.1f}")
+
+
+def conv_level(m, r, pts, C=192, Co=64, T=512, seed=1):
+    """One convolution Co x C x r over T columns ('same' padding) in F(m, r) form with fp32 transforms, products and channel
+    accumulation, against the fp32 direct form; reference = float64 direct."""
+    AT, G, BT = cook_toom(m, r, pts)
+    n = m + r - 1
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((C, T)); w = rng.standard_normal((Co, C, r)) / np.sqrt(C * r)
+    pad = (r - 1) // 2
+    Tp = ((T + m - 1) // m) * m
+    xp = np.zeros((C, Tp + r - 1)); xp[:, pad:pad + T] = x
+    ref = np.zeros((Co, Tp))
+    for t in range(r):
+        ref += np.einsum("oc,ct->ot", w[:, :, t], xp[:, t:t + Tp])
+    x32, w32 = xp.astype(np.float32), w.astype(np.float32)
+    d32 = np.zeros((Co, Tp), np.float32)
+    for t in range(r):
+        d32 += np.einsum("oc,ct->ot", w32[:, :, t], x32[:, t:t + Tp]).astype(np.float32)
+    nw = Tp // m
+    win = np.stack([x32[:, m * q:m * q + n] for q in range(nw)], 1)            # [C, nw, n]
+    V = np.einsum("pj,cqj->pcq", BT.astype(np.float32), win).astype(np.float32)   # [n, C, nw]
+    U = np.einsum("pj,ocj->poc", G.astype(np.float32), w32).astype(np.float32)   # [n, Co, C]
+    M = np.einsum("poc,pcq->poq", U, V).astype(np.float32)                        # the GEMMs, fp32 accumulation
+    y = np.einsum("ip,poq->oqi", AT.astype(np.float32), M).astype(np.float32).reshape(Co, Tp)
+    rms = lambda a: float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
+    return rms(y - ref) / rms(ref), rms(d32 - ref) / rms(ref)
+
+
+print("\none convolution, C = 192 input channels, 64 output rows, 512 columns (fp32 transforms / products / accumulation):")
+for name, m, r, pts in (("F(4,3)", 4, 3, [0, 1, -1, 2, -2]), ("F(2,5)", 2, 5, [0, 1, -1, 2, -2]),
+                        ("F(4,5)", 4, 5, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)]), ("F(6,3)", 6, 3, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)])):
+    w_, d_ = conv_level(m, r, pts)
+    print(f"{name:14s} fp32 rel-RMS: winograd {w_:.2e}   direct {d_:.2e}   ratio {w_ / d_:.1f}")
