@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_SAMPLE = 2568280.0          # 2*MAC of the 184 convolutions per output sample
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 SAMPLE_RATE = 22050
-ROUND_TAG = "r03"                     # only PMC traffic files of this round's code are quoted
+ROUND_TAG = "r04"                     # only PMC traffic files of this round's code are quoted
 
 
 def _cpu_info():
@@ -102,6 +102,8 @@ def cpu_baseline(sd_np, seed, keep=None):
                 sample=f"16x512 frames (the bench workload, whole batch), 1 warm-up + best of 3 = {rec['c2']['best_s']:.2f} s; "
                        f"{cores} of {avail} host threads (best of an 8/16/32/64 probe), torch {torch.__version__} fp32 oneDNN",
                 cpu_model=model, physical_cores=phys, logical_cpus=avail, c1_1x200=rec["c1"], c2_16x512=rec["c2"],
+                cores_note=f"SURVEY.md 8(d) asks for all physical cores ({phys}); {cores} threads measured FASTER than more in the probe "
+                           "(oneDNN's small convolutions stop scaling), so the best thread count is the one reported",
                 protocol="SURVEY.md 8(d): 1 warm-up + best of 3, C1 and C2", wall_s=round(time.perf_counter() - t_all, 1))
 
 
@@ -129,9 +131,44 @@ def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     return best, rep
 
 
+MFMA_FLOP = 4096.0                   # 2*MAC of one v_mfma_f32_32x32x2_f32 (the only MFMA opcode in the library: 32 x 32 x 2 x 2)
+
+
+def other_configs(net, dev):
+    """The other single-GPU configurations of BASELINE.json, timed after the timed region so that every one of them carries a
+    driver-run number: C1 1 x 200 (the reference notebook's shape: latency), C3 32 x 512, C5 8 x 4096 (long form).  Same protocol
+    as the headline: inputs resident in HBM, 2 untimed calls (the second captures the replay plan where the shape qualifies),
+    then K back-to-back `infer` calls between HIP events on the launch stream."""
+    from cases import sw
+    out = {}
+    for tag, B, T, K in (("c1_1x200", 1, 200, 20), ("c3_32x512", 32, 512, 5), ("c5_8x4096", 8, 4096, 4)):
+        mel = torch.from_numpy(sw.synthetic_mel(1000 + len(out), B, T)).to(dev)
+        eps = torch.from_numpy(sw.synthetic_eps(1000 + len(out), B, T)).to(dev)
+        ln = torch.full((B,), T, dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            for _ in range(3):
+                o = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(K):
+                o = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        n = o.numel()
+        out[tag] = {"ms_per_step": ms, "samples_per_s": n / (ms * 1e-3), "real_time_factor": n / (ms * 1e-3) / SAMPLE_RATE, "steps": K,
+                    "finite": bool(torch.isfinite(o).all())}
+        del mel, eps, o
+    out["note"] = ("SynthesizerTrn.infer, synthetic mels, full lengths; c3 is the batch-32 configuration (the reference's infer takes no "
+                   "speaker embedding: models.py:331-339; the g-conditioned modules are covered by the parity tests)")
+    return out
+
+
 def live_hbm_traffic(B, T, timeout_s=150):
-    """Two child runs of this script under `rocprofv3 --pmc` (read-request counters, then write-request counters: separate passes,
-    no tracing beside them), 2 steps each; returns (HBM bytes of the GEMM-family kernels per step, description)."""
+    """Three child runs of this script under `rocprofv3 --pmc` on the DEFAULT launch plan (read-request counters, write-request
+    counters, SQ_INSTS_MFMA: separate passes, no tracing beside them), 2 steps each; returns (HBM bytes of the GEMM-family kernels
+    per step, description, MFMA instructions per step as the hardware counted them)."""
     import shutil, subprocess, tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
@@ -144,10 +181,10 @@ def live_hbm_traffic(B, T, timeout_s=150):
     base = tempfile.mkdtemp(prefix="svoc_pmc_", dir="/tmp")
     try:
         dirs = []
-        for tag, counters in (("rd", pmc_traffic.READ_COUNTERS), ("wr", pmc_traffic.WRITE_COUNTERS)):
+        for tag, counters in (("rd", pmc_traffic.READ_COUNTERS), ("wr", pmc_traffic.WRITE_COUNTERS), ("mfma", ["SQ_INSTS_MFMA"])):
             d = os.path.join(base, tag)
             cmd = [prof, "--pmc", *counters, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "2", "--warmup", "1", "--batch", str(B), "--frames", str(T), "--no-cpu-baseline", "--no-pmc"]
+                   "--steps", "2", "--warmup", "1", "--batch", str(B), "--frames", str(T), "--no-cpu-baseline", "--no-pmc", "--no-other-configs"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
             if r.returncode != 0:
                 raise RuntimeError(f"rocprofv3 pass {tag} exit {r.returncode}: {r.stdout[-200:].decode(errors='replace')}")
@@ -155,10 +192,11 @@ def live_hbm_traffic(B, T, timeout_s=150):
         tj = pmc_traffic.traffic(dirs[0], dirs[1], 0, 2)
         if tj["gemm_family_launches_per_step"] < 1:
             raise RuntimeError("no GEMM-family dispatches in the counter traces")
+        mfma = pmc_traffic.counter_per_step(dirs[2], "SQ_INSTS_MFMA", 2)
         return (tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"],
-                f"LIVE: two `rocprofv3 --pmc` child runs of bench.py after the timed region ({', '.join(pmc_traffic.READ_COUNTERS)} | "
-                f"{', '.join(pmc_traffic.WRITE_COUNTERS)}; 2 steps each, {tj['dispatches_counted_per_step']:.0f} dispatches per step; "
-                f"whole step {((tj['hbm_read_bytes_per_step'] + tj['hbm_write_bytes_per_step']) / 1e9):.1f} GB)")
+                f"LIVE: `rocprofv3 --pmc` child runs of bench.py after the timed region ({', '.join(pmc_traffic.READ_COUNTERS)} | "
+                f"{', '.join(pmc_traffic.WRITE_COUNTERS)} | SQ_INSTS_MFMA; 2 steps each, {tj['dispatches_counted_per_step']:.0f} dispatches per step; "
+                f"whole step {((tj['hbm_read_bytes_per_step'] + tj['hbm_write_bytes_per_step']) / 1e9):.1f} GB)", mfma)
     finally:
         shutil.rmtree(base, ignore_errors=True)
 
@@ -172,6 +210,7 @@ def main():
     ap.add_argument("--frames", type=int, default=512, help="mel frames per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic passes (rocprofv3 --pmc child runs of this script)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C1 / C3 / C5 timings after the timed region")
     ap.add_argument("--allow-no-collective", action="store_true", help="N>1: do not fail when neither gather nor all_gather works")
     args = ap.parse_args()
 
@@ -338,51 +377,55 @@ def main():
             "real_time_factor": value / SAMPLE_RATE / world,
             "samples_per_s_per_gpu": value / world,
         }
-        # Roofline.  Headline (`achieved`/`frac`): the fp32-MFMA implicit-GEMM family as a whole = algorithmic FLOPs of every
-        # GEMM launch of the timed region (counted by the library, 2*MAC) over the device time of the region, HIP events on
-        # the launch stream (conservative: the region includes the few % of non-GEMM kernels).  `dominant_kernel`: the
-        # single kernel with the largest share, per-launch, measured live after the timed region.
-        res["roofline"] = {"bound": "mfma", "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS,
-                           "achieved_executed": exec_tflops, "frac_executed": exec_tflops / FP32_MFMA_PEAK_TFLOPS,
+        # Roofline.  `achieved` / `frac` (round 4): 2*MAC the matrix pipe really ISSUED in the timed region - counted per launch by
+        # the library (the Winograd kernels issue a fixed share of the direct form's multiply-adds) and checked against the hardware's
+        # SQ_INSTS_MFMA count below - over the device time of the region (HIP events on the launch stream; conservative: the region
+        # includes the few % of non-GEMM kernels).  Bounded by the FP32 MFMA peak.  `achieved_direct_form` / `frac_direct_form` price
+        # the ALGORITHMIC direct-form FLOPs of SURVEY.md 8(d) (2 568 280 per sample) over the same time: a statement about time to
+        # solution that the peak does not bound (Winograd arithmetic does the same convolutions with fewer multiply-adds).
+        res["roofline"] = {"bound": "mfma", "achieved": exec_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": exec_tflops / FP32_MFMA_PEAK_TFLOPS,
+                           "achieved_direct_form": conv_tflops, "frac_direct_form": conv_tflops / FP32_MFMA_PEAK_TFLOPS,
                            "executed_mfma_flop_fraction": stats["executed_flops"] / max(1.0, stats["conv_flops"]),
+                           "executed_flop_per_step": stats["executed_flops"] / args.steps,
+                           "executed_flops_pmc": None,
                            "winograd_form_floor_ms": stats["executed_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "direct_form_floor_ms": stats["conv_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group)_kernel (Winograd F(4,3), C>=64 ResBlock convolutions), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, resblock_fused_ct_kernel, wn_layer_fused(_ks)_kernel (fallbacks: conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
-                           "note": "achieved/frac = algorithmic direct-form 2*MAC of the convolutions (SURVEY.md 8d) / time: with the Winograd F(2,3) kernels "
-                                   "(which issue 1/2, 4/7, 6.5/11 of those multiply-adds for k=3/7/11 in F(4,3) form) the direct-form peak is NOT a bound on it; "
-                                   "achieved_executed/frac_executed = 2*MAC the matrix pipe really issued (counted per launch by the library) / time, "
-                                   "bounded by the peak; winograd_form_floor_ms = executed FLOPs of one step at 157.3 TFLOP/s",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group|_accum)_kernel (Winograd F(4,3), every ResBlock convolution of the decoder), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, wn_layer_fused(_ks)_kernel (fallbacks: resblock_fused_ct_kernel, conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
+                           "note": "achieved/frac = executed 2*MAC / time (<= peak). Shares of the direct form's multiply-adds issued per kernel size k=3/7/11: "
+                                   "F(4,3) (default) 1/2, 4/7, 6.5/11; F(2,3) (fall-back) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8; everything else 1. "
+                                   "achieved_direct_form/frac_direct_form = algorithmic direct-form 2*MAC (SURVEY.md 8d) / time, NOT bounded by the peak; "
+                                   "winograd_form_floor_ms = executed FLOPs of one step at 157.3 TFLOP/s",
                            "gemm_launches_per_step": stats["conv_launches"] / args.steps,
                            "convolutions_per_step": stats["convolutions"] / args.steps,
                            "small_kernel_launches_per_step": stats["other_launches"] / args.steps,
                            "flop_per_step": stats["conv_flops"] / args.steps,
                            "gpu_ms_per_step_rank0": gpu_ms / args.steps}
         if dom:
-            # Winograd form: the launch computes the same convolutions (same algorithmic 2*MAC) while
-            # issuing (6.5 + 4 + 1.5) / (11 + 7 + 3) of them as MFMAs (F(4,3); F(2,3): (8 + 5 + 2) / 21), so `achieved`
-            # (algorithmic) may exceed the direct-form MFMA peak; `mfma_pipe_frac` prices the multiply-adds the matrix
-            # pipe really executed
+            # the launch with the largest share of the step.  achieved / frac = the multiply-adds its MFMAs really executed
+            # ((6.5 + 4 + 1.5) / (11 + 7 + 3) of the direct form in F(4,3); F(2,3): (8 + 5 + 2) / 21) over its launch time
             executed = 12.0 / 21.0 if dom["wino4"] else (15.0 / 21.0 if dom["wino"] else 1.0)
             res["roofline"]["dominant_kernel"] = {
                 "name": ("conv_wino4_group_kernel<1,4> " if dom["wino4"] else
                          (("conv_wino_group_kernel<1> " if os.environ.get("SVOC_WINO_WS") == "0" else "conv_wino_ws_group_kernel<1> ")
                           if dom["wino"] else "conv_group_kernel<2,2,2,2> ")) + dom["desc"],
                 "launches_measured": dom["n"], "avg_launch_us": dom["mean_us"],
-                "flop_per_launch": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6,
-                "achieved": dom["tflops"], "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                "executed_mfma_flop_fraction": executed, "mfma_pipe_frac": dom["tflops"] * executed / FP32_MFMA_PEAK_TFLOPS,
+                "flop_per_launch_direct_form": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6,
+                "flop_per_launch": dom["tflops"] * 1e12 * dom["mean_us"] * 1e-6 * executed,
+                "achieved": dom["tflops"] * executed, "frac": dom["tflops"] * executed / FP32_MFMA_PEAK_TFLOPS,
+                "achieved_direct_form": dom["tflops"], "frac_direct_form": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "executed_mfma_flop_fraction": executed,
                 "measured": "hipEventRecord around every launch on the launch stream (library event profiler), after the timed region"}
         # HBM traffic of the same workload from PMC counters.  They cannot be read from inside this process: at N=1 two child runs
         # of this script (2 steps, no CPU leg) are made under `rocprofv3 --pmc`, read- and write-request counters in separate
         # passes as MI355X_MICROARCH.md prescribes, and summed per step by tools/pmc_traffic.py.  If the profiler is missing, fails
         # or times out, the figure is taken from this round's committed passes instead and labelled OFFLINE.
-        step_bytes, tsrc = None, None
+        step_bytes, tsrc, mfma_insts = None, None, None
         under_profiler = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)      # never nest profilers
         if world == 1 and not args.no_pmc and not under_profiler and B == 16 and T == 512:
             try:
-                step_bytes, tsrc = live_hbm_traffic(B, T)
+                step_bytes, tsrc, mfma_insts = live_hbm_traffic(B, T)
             except Exception as e:   # noqa: BLE001
                 res["roofline"]["traffic_live_error"] = f"{type(e).__name__}: {e}"[:300]
         if step_bytes is None:
@@ -395,11 +438,22 @@ def main():
                     tsrc = f"OFFLINE: profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc TCC_EA0_RDREQ_*/WRREQ_*, separate passes)"
                 except Exception:   # noqa: BLE001
                     pass
+        if mfma_insts is not None:
+            # hardware check of the library's bookkeeping: SQ_INSTS_MFMA of one step of the DEFAULT plan x 4096 FLOP per
+            # v_mfma_f32_32x32x2_f32 (includes the padding of ragged tiles, which the library's counter leaves out)
+            res["roofline"]["executed_flops_pmc"] = mfma_insts * MFMA_FLOP
+            res["roofline"]["executed_flops_pmc_over_library"] = mfma_insts * MFMA_FLOP / max(1.0, stats["executed_flops"] / args.steps)
+            res["roofline"]["frac_pmc"] = mfma_insts * MFMA_FLOP / (gpu_ms / args.steps * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
         if step_bytes is not None:
             res["roofline"]["traffic"] = step_bytes / max(1.0, res["roofline"]["gemm_launches_per_step"])
             res["roofline"]["traffic_unit"] = "HBM bytes per GEMM-family launch (mean over gemm_launches_per_step)"
             res["roofline"]["traffic_bytes_per_step"] = step_bytes
             res["roofline"]["traffic_source"] = tsrc
+        if world == 1 and B == 16 and T == 512 and not args.no_other_configs and not under_profiler:
+            try:
+                res["other_configs"] = other_configs(net, dev)
+            except Exception as e:   # noqa: BLE001
+                res["other_configs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         fail = None
         if world == 1 and not args.no_cpu_baseline:
             keep = {}

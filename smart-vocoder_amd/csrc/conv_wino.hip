@@ -947,6 +947,7 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
 
 // conv_wino4.hip: the F(4,3) form
 bool wino4_enabled();
+bool wino4_c32_enabled();
 int wino4_slots(int K);
 int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
@@ -956,6 +957,8 @@ int wino4_launch_accum(const WinoGroup& g, int NRT, long long total, hipStream_t
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
+  // Cin = Cout = 32 (round 4): only the F(4,3) form with one row tile per workgroup (conv_wino4.hip, NRT = 1)
+  if (Cin == 32 && Cout == 32) return on && wino4_c32_enabled() && (dil == 1 || dil == 3 || dil == 5) && (K == 3 || K == 7 || K == 11);
   return on && (dil == 1 || dil == 3 || dil == 5) && (K == 3 || K == 7 || K == 11) && Cin >= 64 && (Cin % KC) == 0 && (Cout % 32) == 0;
 }
 
@@ -978,7 +981,8 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
   hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_or_v, g ? scale.f() : nullptr,
                      pw.wp.f(), Cin, Cout, K, pw.nchunks, pw.slots, total);
   hipLaunchKernelGGL(wino_bias_kernel, dim3((pw.mtiles * 32 + 255) / 256), dim3(256), 0, st, bias, pw.bias.f(), Cout, pw.mtiles * 32);
-  if (wino4_enabled() && pw.mtiles % 2 == 0 && (pw.nchunks & 1) == 0) {   // F(4,3) image: 64- or 128-row blocks, even chunk counts
+  // F(4,3) image: 64- or 128-row blocks with even chunk counts, or the single 32 x 32 block of the last MRF stage
+  if (wino4_enabled() && ((pw.mtiles % 2 == 0 && (pw.nchunks & 1) == 0) || (pw.mtiles == 1 && pw.nchunks == 1))) {
     const long long total4 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K) * 4 * 256;
     SVOC_TRY(pw.wp4.ensure((size_t)(total4 + 1024) * sizeof(float)));
     SVOC_HIP(hipMemsetAsync(pw.wp4.f() + total4, 0, 1024 * sizeof(float), st));
@@ -1094,7 +1098,7 @@ static double wino_exec_ratio(int K) { const int G = (K + 1) / 4; return (2.0 * 
 
 // F(4,3) form (conv_wino4.hip): four-row-tile blocks; dilation 1 additionally needs 16-byte aligned rows of a length that is a multiple of four
 static double wino4_exec_ratio(int K) { const int G = (K + 1) / 4; return (1.5 * G + (G - 1)) / (double)K; }
-static int wino4_nc(const PackedWino& pw) { return pw.mtiles % 4 == 0 ? 4 : 2; }      // row tiles per workgroup: 128- or 64-row blocks
+static int wino4_nc(const PackedWino& pw) { return pw.mtiles % 4 == 0 ? 4 : (pw.mtiles == 1 ? 1 : 2); }      // row tiles per workgroup: 128-, 64- or 32-row blocks
 static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const WinoArgs& w, WinoArgs& w4) {
   if (!wino4_enabled() || !pw.wp4.p || !(dil == 1 || dil == 3 || dil == 5) || (dil == 1 && (a.Ncols & 3))) return false;
   const EpiOut& o = a.out[0];
@@ -1122,6 +1126,7 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
   const double flops = pw.flops_per_col * (double)B * (double)a.Ncols;
   WinoArgs w4;
   const bool f4 = wino4_args(pw, a, dil, w, w4);
+  if (!f4 && pw.mtiles < 2) return 1;                       // C = 32 exists in F(4,3) form only
   stats_add_conv(flops, 1, flops * (f4 ? wino4_exec_ratio(pw.K) : wino_exec_ratio(pw.K)));
   int prof_idx = -1;
   if (prof_enabled()) {
@@ -1216,7 +1221,8 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     else l = dil == 1 ? wino_lds<1, 2>(K) : (dil == 3 ? wino_lds<3, 2>(K) : wino_lds<5, 2>(K));
     lds = std::max(lds, l);
   }
-  if (total / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
+  if (!f4 && pws[0]->mtiles < 2) return 1;                  // C = 32 exists in F(4,3) form only
+  if ((f4 ? total4 : total) / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
   for (int i = n; i < 3; ++i) { g.end[i] = 0x7fffffff; g.k[i] = 3; }
   stats_add_conv(flops, n, f4 ? exec4 : exec_flops);
   int prof_idx = -1;

@@ -42,13 +42,21 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // pipe: profiles/r03_f_winograd_f43_c64_null.txt).  Channels per stage KS: 32 (one weight chunk); 64 for k = 3 with NRT = 4
 // (only 96 MFMAs per chunk and consumer: two chunks per stage; the plane sets of k = 7 / 11 would not fit twice); with NRT = 2
 // the planes are twice as wide, so k = 7 / 11 stage 16 channels = half a weight chunk (k-groups {0,1} or {2,3} of every slot).
+// NRT = 1 (round 4: C = 32, the last MRF stage): 1 x 4 consumers, 32 rows x 128 windows = 512 outputs per workgroup tile; one row
+// tile feeds on planes four column tiles wide, so a stage is 16 channels (k = 3: k-groups {0,1} / {2,3}) or 8 channels (k = 7 / 11:
+// one k-group of every slot, four stages per weight chunk) - 48 / 64 / 104 MFMAs per stage and consumer.
 template <int K, int D, int NRT = 4>
 struct W4Geo {
   static constexpr int NCT = 4 / NRT;                     // column tiles (of 32 windows) per workgroup
-  static constexpr int KS = NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32);   // channels per stage
+  static constexpr int KS = NRT == 1 ? (K == 3 ? 16 : 8) : (NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32));   // channels per stage
   static constexpr int CPS = KS >= KC ? KS / KC : 1;      // weight chunks per stage
   static constexpr int HALVES = KS < KC ? KC / KS : 1;    // stages per weight chunk
   static constexpr int KGS = KS < KC ? KS / 8 : 4;        // k-groups (of 8 channels = 4 k-steps) per stage and chunk
+  // Weight registers: a slot of a stage is KGS float4 per lane = 4 KGS MFMAs.  With KGS = 4 the next slot is requested one slot
+  // (1024 cycles of MFMAs) ahead in the other of two register sets; with KGS = 2 / 1 one slot is only 512 / 256 cycles - less than a
+  // loaded L2 round trip (round 4: 77-84 cycles per MFMA in the C = 32 streams) - so those run a ring of four sets, three slots ahead.
+  static constexpr int NSET = KGS == 4 ? 2 : 4;
+  static constexpr int PD = NSET - 1;                     // slots ahead
   static constexpr int G = (K + 1) / 4;                   // three-tap groups at tap offsets 0, 4, 8
   static constexpr int ND = G - 1;                        // left-over single taps (3, 7)
   static constexpr int PADT = (K - 1) / 2;                // padding in taps (columns: PADT * D)
@@ -73,7 +81,10 @@ struct W4Geo {
   static constexpr int PLANE = KS * PQ;
   static constexpr int PLF = NPL * PLANE;                 // floats per plane set
   static constexpr int RAW_FLOATS = KS * RAW;
-  static constexpr int LDS_BYTES = (RAW_FLOATS + 2 * PLF) * 4;
+  // plane sets: two (producers one stage ahead); three where they fit (NRT = 1, k = 7 / 11: the producers run two stages ahead, so
+  // that they work through the consumers' epilogue and a late stage does not stall the streams)
+  static constexpr int NPS = (NRT == 1 && (RAW_FLOATS + 3 * PLF) * 4 <= 160 * 1024) ? 3 : 2;
+  static constexpr int LDS_BYTES = (RAW_FLOATS + NPS * PLF) * 4;
   // step t of a chunk: which weight slot, plane, column (in windows) and accumulator
   static constexpr bool tap(int t) { return t >= NGS; }
   static constexpr int tr(int t) { return ((t - NGS) % (4 * KGS)) / KGS; }               // tap steps: output index r
@@ -91,6 +102,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQ = Geo::PQ, RAW = Geo::RAW, WSLOTS = Geo::WSLOTS;
   constexpr int NWT = Geo::NWT, NCT = Geo::NCT, XOFF = Geo::XOFF, NE = Geo::NE, LEAD = Geo::LEAD, PLANE = Geo::PLANE, PLF = Geo::PLF;
   constexpr int NSTEP = Geo::NSTEP, NACC = Geo::NACC, CPS = Geo::CPS, KS = Geo::KS, RPW = KS / 4, HALVES = Geo::HALVES, KGS = Geo::KGS;
+  constexpr int NSET = Geo::NSET, PD = Geo::PD, NPS = Geo::NPS;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* const raw = wl;                                   // [KC][RAW], producers only
   float* const pl = wl + Geo::RAW_FLOATS;                  // two plane sets of PLF floats
@@ -196,6 +208,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     retarget(ph0, lead0);
     issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs0, xs0 >= 0 && xs0 + RAW <= L, 0);
     int ti = 0, ch = 0;                                    // stage s = (tile ti, stage ch of the tile)
+    int pset = 0;
     long long pc_all0 = 0, pc_bar = 0;
     if constexpr (DBG) pc_all0 = (long long)__builtin_readcyclecounter();
     for (int s_ = 0; s_ < nstages; ++s_) {
@@ -238,7 +251,8 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       if (nchn == nst) { nchn = 0; ++nti; if (nti < my_tiles) { locate(v0 + nti * stride, w0n, bzn, byn); origin(w0n, xsn, ph0n, leadn); } }
       if (s_ + 1 < nstages) issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= L, nchn);
       // ---- transform own rows into plane set s & 1 (LDS operations of one wave execute in order: no barrier needed)
-      float* const pb = pl + (s_ & 1) * PLF;
+      float* const pb = pl + (NPS == 2 ? (s_ & 1) : pset) * PLF;
+      if constexpr (NPS == 3) pset = pset == 2 ? 0 : pset + 1;
 #pragma unroll
       for (int u = 0; u < TPW; ++u) {
         if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
@@ -268,11 +282,14 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       }
       long long pb0 = 0;
       if constexpr (DBG) pb0 = (long long)__builtin_readcyclecounter();
-      __syncthreads();                                     // B_s: plane set s & 1 complete
+      // B_s: plane set s & 1 complete.  Three sets: the barrier behind stage s is B_{s-1} (the consumers then start stage s - 1
+      // while stage s + 1 is produced into the set they left before B_{s-1}); B_{last} follows the loop
+      if (NPS == 2 || s_ > 0) __syncthreads();
       if constexpr (DBG) pc_bar += (long long)__builtin_readcyclecounter() - pb0;
       if (nti != ti) retarget(ph0n, leadn);                // the next stage belongs to another tile
       ti = nti; ch = nchn; w0 = w0n; bz = bzn; by = byn; xs0 = xsn; ph0 = ph0n; lead0 = leadn;
     }
+    if constexpr (NPS == 3) __syncthreads();
     if constexpr (DBG) if (tid == 256) {                   // producer wave 0: total cycles, cycles spent waiting at the stage barriers
       long long* d = p.dbg + 16 * (long long)(p.dbg_base + v0);
       d[8] = (long long)__builtin_readcyclecounter() - pc_all0; d[9] = pc_bar;
@@ -282,13 +299,13 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
 
   // =================================================================== consumer: row tile rt, column tile ct of the workgroup
   const int l31 = lane & 31, hi = lane >> 5;
-  const int rt = NRT == 4 ? wave : (wave & 1), ct = NRT == 4 ? 0 : (wave >> 1);
+  const int rt = NRT == 4 ? wave : (NRT == 2 ? (wave & 1) : 0), ct = NRT == 4 ? 0 : (NRT == 2 ? (wave >> 1) : wave);
   const int uu = ct * 32 + l31;                            // this lane's window inside the workgroup tile
   const unsigned pbase = (unsigned)(size_t)pl;
   const unsigned baddr0 = pbase + (unsigned)(hi * PQ + uu) * 4u;
   const unsigned wlane = (unsigned)lane * 16u;
   f32x16 M[NACC];
-  float4 a[2][KGS];
+  float4 a[NSET][KGS];
   // MFMA stream of one 32-channel chunk (chunk CC of the stage: plane rows 32 CC ..) or of half HF of a chunk (KS = 16): NSTEP steps of four MFMAs, fragment
   // reads two steps ahead in two register sets, the next weight slot's four float4 requested at the first step of each slot
   // Weights stream through buffer loads: descriptor base = packed image, SGPR offset = (row tile, chunk, slot), VGPR offset =
@@ -302,14 +319,15 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   };
   auto wload4 = [&](float4 (&dst)[KGS], int soff, auto hf) {       // the KGS k-groups of half HF of a slot
     constexpr int K0 = decltype(hf)::value * KGS;
-    wload(dst[0], soff, std::integral_constant<int, K0>{}); wload(dst[1], soff, std::integral_constant<int, K0 + 1>{});
+    wload(dst[0], soff, std::integral_constant<int, K0>{});
+    if constexpr (KGS >= 2) wload(dst[1], soff, std::integral_constant<int, K0 + 1>{});
     if constexpr (KGS == 4) { wload(dst[2], soff, std::integral_constant<int, K0 + 2>{}); wload(dst[3], soff, std::integral_constant<int, K0 + 3>{}); }
   };
   // wa / wnext: byte offsets of the chunk's / the following chunk's slot 0 inside the image (wnext < 0: none)
-  // wnext belongs to half NHF (the other half of the same chunk when HALVES == 2 and HF == 0, else half 0 of the next chunk)
+  // wnext belongs to part NHF (the next part of the same chunk while HF + 1 < HALVES, else part 0 of the next chunk)
   auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto par, auto cc, auto hf) {
     constexpr int PAR = decltype(par)::value, CC = decltype(cc)::value, HF = decltype(hf)::value;
-    constexpr int NHF = (HALVES == 2 && HF == 0) ? 1 : 0;
+    constexpr int NHF = HF + 1 < HALVES ? HF + 1 : 0;
     float fb[2][4];
     auto request = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
@@ -318,16 +336,16 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     auto step = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
       constexpr int WS = Geo::wslot(T), KG = Geo::kgi(T);
-      if constexpr (Geo::slot_first(T)) {
-        if constexpr (WS + 1 < WSLOTS) wload4(a[(PAR + WS + 1) & 1], wa + (WS + 1) * 4096, hf);
-        else if (wnext >= 0) wload4(a[(PAR + WS + 1) & 1], wnext, std::integral_constant<int, NHF>{});
+      if constexpr (Geo::slot_first(T)) {                 // request slot WS + PD (of this stage, else of the stage / tile that follows)
+        if constexpr (WS + PD < WSLOTS) wload4(a[(PAR + WS + PD) % NSET], wa + (WS + PD) * 4096, hf);
+        else if (wnext >= 0) wload4(a[(PAR + WS + PD) % NSET], wnext + (WS + PD - WSLOTS) * 4096, std::integral_constant<int, NHF>{});
       }
       {
         float(&b)[4] = fb[T & 1];
         if constexpr (T + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
       }
-      const float4 av = a[(PAR + WS) & 1][KG];
+      const float4 av = a[(PAR + WS) % NSET][KG];
       constexpr int AC = Geo::acc(T);
 #pragma unroll
       for (int s = 0; s < 4; ++s) M[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[AC], 0, 0, 0);
@@ -364,6 +382,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       *reinterpret_cast<float*>(q + 8 * D) = v.z; *reinterpret_cast<float*>(q + 12 * D) = v.w;
     }
   };
+  int cset = 0;                                            // three plane sets: set of the next stage
   long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0;     // diagnostics (stamped build): consumer wave 0 of each workgroup
   long long wall0 = 0;
   if constexpr (DBG) { cyc_all0 = (long long)__builtin_readcyclecounter(); wall0 = (long long)wall_clock64(); }
@@ -387,7 +406,10 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     const bool row_ok = mt < p.mtiles;
     const int mtc = row_ok ? mt : p.mtiles - 1;
     const int wt = wtile(mtc);
-    if (ti == 0) wload4(a[0], wt, std::integral_constant<int, 0>{});
+    if (ti == 0) {
+      wload4(a[0], wt, std::integral_constant<int, 0>{});
+      if constexpr (PD > 1) { wload4(a[1], wt + 4096, std::integral_constant<int, 0>{}); wload4(a[2], wt + 2 * 4096, std::integral_constant<int, 0>{}); }
+    }
     {   // the bias starts in M1: y0 and y2 contain M1 + M2, y1 and y3 contain M1 - M2, so all four outputs receive it once
       const float* bias = p.bias + mtc * 32 + 4 * hi;
 #pragma unroll
@@ -418,11 +440,12 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
 #pragma unroll
         for (int r = 0; r < 8; ++r) rvA[r] = ldq(rbase + (size_t)(8 * (r >> 2)) * rlb + ro4[r & 3]);
       }
-      const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
+      const unsigned off = (unsigned)((NPS == 2 ? (s_ & 1) : cset) * PLF) * 4u;
+      if constexpr (NPS == 3) cset = cset == 2 ? 0 : cset + 1;
       constexpr auto c0_ = std::integral_constant<int, 0>{};
-      if constexpr (HALVES == 2) {                         // half a chunk per stage: the same slots again for the second half
-        const int wa = wt + (st_ >> 1) * WSLOTS * 4096;
-        const int wnext = HF == 0 ? wa : (st_ + 1 < nst ? wa + WSLOTS * 4096 : wnext_tile);
+      if constexpr (HALVES > 1) {                          // a part of a chunk per stage: the same slots again for the next part
+        const int wa = wt + (st_ / HALVES) * WSLOTS * 4096;
+        const int wnext = HF + 1 < HALVES ? wa : (st_ + 1 < nst ? wa + WSLOTS * 4096 : wnext_tile);
         mfma_chunk(baddr0 + off, wa, wnext, par, c0_, hf);
       } else if constexpr (CPS == 1) {
         const int wa = wt + st_ * WSLOTS * 4096;
@@ -437,12 +460,18 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       }
       if constexpr (DBG) { cyc_bar += c1 - c0; cyc_mf += (long long)__builtin_readcyclecounter() - c1; }
     };
-    // the register set of a stage's first slot alternates when a stage has an odd number of slots (k = 7); stages come in
-    // pairs then (nch is even: host), as they do when a chunk is two stages
-    if constexpr (HALVES == 2) {
-      for (int st_ = 0; st_ < nst; st_ += 2) {
+    // the register set of a stage's first slot advances by the stage's slot count (mod NSET): the stage loop is unrolled over U
+    // stages, U * WSLOTS a multiple of NSET, so that every round (and every tile: nst is a multiple of U, host) starts in set 0
+    if constexpr (HALVES > 1) {
+      constexpr int U = (HALVES * WSLOTS) % NSET == 0 ? HALVES : 2 * HALVES;
+      static_assert((U * WSLOTS) % NSET == 0 && U <= 4, "weight ring does not close");
+      for (int st_ = 0; st_ < nst; st_ += U) {
         stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        stage(st_ + 1, std::integral_constant<int, WSLOTS & 1>{}, std::integral_constant<int, 1>{});
+        stage(st_ + 1, std::integral_constant<int, WSLOTS % NSET>{}, std::integral_constant<int, 1 % HALVES>{});
+        if constexpr (U == 4) {
+          stage(st_ + 2, std::integral_constant<int, (2 * WSLOTS) % NSET>{}, std::integral_constant<int, 2 % HALVES>{});
+          stage(st_ + 3, std::integral_constant<int, (3 * WSLOTS) % NSET>{}, std::integral_constant<int, 3 % HALVES>{});
+        }
       }
     } else if constexpr ((WSLOTS & 1) == 0) {
       for (int st_ = 0; st_ < nst; ++st_) stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -649,6 +678,11 @@ bool wino4_enabled() {
   static const bool on = !(getenv("SVOC_WINO_F4") && atoi(getenv("SVOC_WINO_F4")) == 0);      // SVOC_WINO_F4=0: the F(2,3) kernels
   return on;
 }
+// SVOC_W4_C32=0: the C = 32 stage keeps the fused direct-form ResBlock kernel (resblock_fused.hip)
+bool wino4_c32_enabled() {
+  static const bool on = wino4_enabled() && !(getenv("SVOC_W4_C32") && atoi(getenv("SVOC_W4_C32")) == 0);
+  return on;
+}
 template <int K, int D, int NRT>
 static size_t wino4_lds() { return (size_t)W4Geo<K, D, NRT>::LDS_BYTES; }
 // column tiles per row: a tile is 32 * (4 / NRT) consecutive windows; a row of L outputs has D * ceil(L / 4D) windows
@@ -678,7 +712,7 @@ static int wino4_launch_one(const WinoArgs& w, long long total, hipStream_t st) 
 }
 int wino4_launch(const WinoArgs& w, int K, int D, int NRT, long long total, hipStream_t st) {
   int rc = 1;
-#define SVOC_W4(KK, DD) if (K == KK && D == DD) rc = NRT == 4 ? wino4_launch_one<KK, DD, 4>(w, total, st) : wino4_launch_one<KK, DD, 2>(w, total, st);
+#define SVOC_W4(KK, DD) if (K == KK && D == DD) rc = NRT == 4 ? wino4_launch_one<KK, DD, 4>(w, total, st) : (NRT == 2 ? wino4_launch_one<KK, DD, 2>(w, total, st) : wino4_launch_one<KK, DD, 1>(w, total, st));
   SVOC_W4(3, 1) SVOC_W4(7, 1) SVOC_W4(11, 1) SVOC_W4(3, 3) SVOC_W4(7, 3) SVOC_W4(11, 3) SVOC_W4(3, 5) SVOC_W4(7, 5) SVOC_W4(11, 5)
 #undef SVOC_W4
   return rc;
@@ -703,11 +737,12 @@ static int wino4_launch_accum_n(const WinoGroup& g, long long total, hipStream_t
 }
 // members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each)
 int wino4_launch_accum(const WinoGroup& g, int NRT, long long total, hipStream_t st) {
-  return NRT == 4 ? wino4_launch_accum_n<4>(g, total, st) : wino4_launch_accum_n<2>(g, total, st);
+  return NRT == 4 ? wino4_launch_accum_n<4>(g, total, st) : (NRT == 2 ? wino4_launch_accum_n<2>(g, total, st) : wino4_launch_accum_n<1>(g, total, st));
 }
 int wino4_launch_group(const WinoGroup& g, int D, int NRT, long long total, hipStream_t st) {
   if (NRT == 4) return D == 1 ? wino4_launch_group_d<1, 4>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 4>(g, total, st) : wino4_launch_group_d<5, 4>(g, total, st));
-  return D == 1 ? wino4_launch_group_d<1, 2>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 2>(g, total, st) : wino4_launch_group_d<5, 2>(g, total, st));
+  if (NRT == 2) return D == 1 ? wino4_launch_group_d<1, 2>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 2>(g, total, st) : wino4_launch_group_d<5, 2>(g, total, st));
+  return D == 1 ? wino4_launch_group_d<1, 1>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 1>(g, total, st) : wino4_launch_group_d<5, 1>(g, total, st));
 }
 
 }  // namespace svoc

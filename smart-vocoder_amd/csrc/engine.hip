@@ -146,7 +146,7 @@ struct ResBlock {
       const std::string n1 = prefix + (kind == 1 ? "convs1." : "convs.") + std::to_string(i);
       SVOC_TRY(pack_conv_named(*c1.back(), sp, tab, n1, st));
       w1.emplace_back(nullptr);
-      if (C >= 64 && wino_supported(C, C, K, dil[i])) {        // C = 32 runs the fused kernel instead
+      if (wino_supported(C, C, K, dil[i])) {                   // C = 32: F(4,3) only (round 4), else the fused direct kernel
         w1.back().reset(new PackedWino());
         SVOC_TRY(pack_wino_named(*w1.back(), C, C, K, tab, n1, st));
       }
@@ -155,7 +155,7 @@ struct ResBlock {
         c2.emplace_back(new PackedConv());
         SVOC_TRY(pack_conv_named(*c2.back(), s2, tab, prefix + "convs2." + std::to_string(i), st));
         w2.emplace_back(nullptr);
-        if (C >= 64 && wino_supported(C, C, K, 1)) {
+        if (wino_supported(C, C, K, 1)) {
           w2.back().reset(new PackedWino());
           SVOC_TRY(pack_wino_named(*w2.back(), C, C, K, tab, prefix + "convs2." + std::to_string(i), st));
         }
@@ -453,7 +453,14 @@ struct Generator {
     // C = 32: the fused ResBlock kernel (conv-by-conv execution is HBM-bound there).  C = 64: measured faster conv by
     // conv in Winograd form (grouped launches, 8.4 ms per step) than fused in direct form (9.9 ms); SVOC_FUSE64=1 = fused
     static const bool fuse64 = getenv("SVOC_FUSE64") && atoi(getenv("SVOC_FUSE64")) != 0;
-    if (fuse && (C == 32 || (C == 64 && fuse64))) return false;
+    // C = 32 (round 4): conv by conv in F(4,3) form with one row tile per workgroup (SVOC_W4_C32=0: the fused kernel)
+    bool c32_wino = C == 32 && nk == 3;
+    for (int j = 0; j < nk && c32_wino; ++j) {
+      const ResBlock& rb = *rbs[stage * nk + j];
+      for (int it = 0; it < rb.ND && c32_wino; ++it)
+        c32_wino = rb.kind == 1 && rb.w1[it] && rb.w1[it]->wp4.p && rb.w2[it] && rb.w2[it]->wp4.p;
+    }
+    if (fuse && ((C == 32 && !c32_wino) || (C == 64 && fuse64))) return false;
     const ResBlock& r0 = *rbs[stage * nk];
     for (int j = 0; j < nk; ++j) {
       const ResBlock& rb = *rbs[stage * nk + j];
@@ -628,8 +635,9 @@ struct Generator {
       {
         static const bool on = !(getenv("SVOC_MRF_SMALL") && atoi(getenv("SVOC_MRF_SMALL")) == 0);
         const int mtl = cho / 32, wm = (mtl >= 4 && mtl % 4 == 0) ? 4 : 2;
-        const long long tiles = (long long)cfg.n_kernels * variant_batch(B) * ((Lo + (wm == 4 ? 63 : 127)) / (wm == 4 ? 64 : 128)) * ((mtl + wm - 1) / wm);
-        small_stage = on && tiles < 2LL * device_cu_count();
+        long long tiles = (long long)cfg.n_kernels * variant_batch(B) * ((Lo + (wm == 4 ? 63 : 127)) / (wm == 4 ? 64 : 128)) * ((mtl + wm - 1) / wm);
+        if (mtl == 1) tiles = (long long)cfg.n_kernels * variant_batch(B) * ((Lo + 511) / 512);    // F(4,3), one row tile: 512 outputs per workgroup tile
+        small_stage = on && (tiles < 2LL * device_cu_count() || (mtl == 1 && (Lo & 3)));
       }
       if (use_streams && !small_stage && mrf_grouped(i, cho)) {
         // MRF with the chains' step-i convolutions grouped into single launches (conv_group_kernel)
@@ -848,7 +856,10 @@ struct Synth {
   }
   struct PlanKey {
     int B = 0, T = 0, Td = 0; float noise = 0; bool has_eps = false, want_zp = false;
-    bool operator==(const PlanKey& o) const { return B == o.B && T == o.T && Td == o.Td && noise == o.noise && has_eps == o.has_eps && want_zp == o.want_zp; }
+    int vb = 0;                         // variant_batch(B) at capture: the kernel variants are frozen into the graph
+    bool operator==(const PlanKey& o) const {
+      return B == o.B && T == o.T && Td == o.Td && noise == o.noise && has_eps == o.has_eps && want_zp == o.want_zp && vb == o.vb;
+    }
   };
   struct Plan {
     unsigned long long fp = 0;
@@ -879,7 +890,7 @@ struct Synth {
   ~Synth() { plans.clear(); retired.clear(); if (cap_st) (void)hipStreamDestroy(cap_st); }
 
   static long long graph_max_frames() {
-    static const long long v = getenv("SVOC_GRAPH_MAX_FRAMES") ? atoll(getenv("SVOC_GRAPH_MAX_FRAMES")) : 32768;
+    static const long long v = getenv("SVOC_GRAPH_MAX_FRAMES") ? std::min(std::max(atoll(getenv("SVOC_GRAPH_MAX_FRAMES")), 0LL), 1LL << 22) : 32768;
     static const bool on = !(getenv("SVOC_GRAPH") && atoi(getenv("SVOC_GRAPH")) == 0);
     return on ? v : 0;
   }
@@ -888,7 +899,7 @@ struct Synth {
   struct Stage { int64_t* len; float* mel; float* eps; };
   int stage_ptrs(Stage& sp) {
     const size_t F = (size_t)graph_max_frames();
-    const size_t len_b = round_up((int)(F * sizeof(int64_t)), 256);
+    const size_t len_b = (F * sizeof(int64_t) + 255) / 256 * 256;     // B <= B * T <= F entries
     SVOC_TRY(plan_stage.ensure(len_b + F * (size_t)(cfg.n_mel + cfg.inter_channels) * sizeof(float)));
     sp.len = reinterpret_cast<int64_t*>(plan_stage.p);
     sp.mel = reinterpret_cast<float*>(static_cast<char*>(plan_stage.p) + len_b);
@@ -933,6 +944,9 @@ struct Synth {
     std::unique_ptr<Plan> p = std::move(plans[i]);
     plans.erase(plans.begin() + i);
     ++plan_evictions;
+    // an evicted shape has to earn its plan again (two more sights): with more hot shapes than MAX_PLANS every call would
+    // otherwise evict + capture + instantiate, which costs more than direct launches
+    for (auto& q : counters) if (q.seen > 0 && q.key == p->key) q.seen = 0;
     if (!p->idle()) retired.push_back(std::move(p));
   }
   void reap_retired() {
@@ -994,6 +1008,7 @@ struct Synth {
     const int Td = (max_len > 0 && max_len < T) ? max_len : T;
     const bool want_zp = z_p != nullptr;
     PlanKey key; key.B = B; key.T = T; key.Td = Td; key.noise = noise_scale; key.has_eps = eps != nullptr; key.want_zp = want_zp;
+    key.vb = variant_batch(B);
     if (Plan* pl = plan_for(key, st)) {
       Stage sp;
       SVOC_TRY(stage_ptrs(sp));

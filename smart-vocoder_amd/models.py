@@ -231,6 +231,26 @@ class Generator(_HipModule):
             l.remove_weight_norm()
 
 
+def decoder_receptive_frames(resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates, upsample_kernel_sizes):
+    """Half-width of the Generator's receptive field in mel frames (reference models.py:115-160): conv_pre (k 7) + per stage the
+    transposed convolution's taps and the widest ResBlock chain (ResBlock1: every dilated conv is followed by an undilated one,
+    modules.py:190-207; ResBlock2: dilated convs only, modules.py:235-240), each divided by the stage's rate, + conv_post (k 7);
+    rounded up, plus two frames of margin.  Frames past an utterance's end closer than this still reach samples inside it, so
+    length-bucketed shards keep that many (parallel.infer_sharded)."""
+    import math
+    frames, rate = 3.0, 1
+    for u, ku in zip(upsample_rates, upsample_kernel_sizes):
+        frames += math.ceil(ku / (2.0 * u)) / rate          # input samples either side that one output sample of the upsampler sees
+        rate *= u
+        widest = 0
+        for k, dils in zip(resblock_kernel_sizes, resblock_dilation_sizes):
+            w = sum((k - 1) * d // 2 + ((k - 1) // 2 if str(resblock) == "1" else 0) for d in dils)
+            widest = max(widest, w)
+        frames += widest / rate
+    frames += 3.0 / rate
+    return int(math.ceil(frames)) + 2
+
+
 class SynthesizerTrn(_HipModule):
     """reference models.py:261-349.  Only the inference entry point is implemented."""
     _destroy = "svoc_synth_destroy"
@@ -263,6 +283,8 @@ class SynthesizerTrn(_HipModule):
                              upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
         self.enc_q = PosteriorEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
         self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 8, gin_channels=gin_channels)
+        self.DECODER_RECEPTIVE_FRAMES = decoder_receptive_frames(resblock, resblock_kernel_sizes, resblock_dilation_sizes,
+                                                                 upsample_rates, upsample_kernel_sizes)
 
     # enc_q is not part of infer: keep it out of the native table and of the change signature
     def _state(self):
@@ -330,7 +352,8 @@ class SynthesizerTrn(_HipModule):
     # and <= 60/8 + 60/64 + 60/128 + 60/256 + upsampler taps) -- 128 covers it with margin
     RECEPTIVE_FRAMES = 128
     # decoder alone (frames past an utterance's end that still influence samples inside it; encoder and flows are masked
-    # layer by layer, so nothing else reaches across the end): 3 + 1 + 60/8 + 60/64 + 60/128 + 60/256 + taps < 14
+    # layer by layer, so nothing else reaches across the end): computed from the configuration in __init__
+    # (decoder_receptive_frames; iitp_base: 3 + 1 + 60/8 + 60/64 + 60/128 + 60/256 + taps -> 16)
     DECODER_RECEPTIVE_FRAMES = 16
 
     def infer_chunked(self, x, x_lengths, chunk_frames=1024, noise_scale=1, eps=None, halo_frames=None):

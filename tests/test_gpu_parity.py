@@ -95,22 +95,45 @@ def test_conv1d(M, C, k, d, L, B, res):
     check(f"conv1d C{C} k{k} d{d}", y, ref)
 
 
+def _wino_f4_expected(C, co, k, d, L):
+    """Which Winograd form the library documents for a shape: F(4,3) needs Cout as 64- / 128-row blocks with an even
+    number of 32-channel chunks (or the single 32 x 32 block of the last MRF stage); everything else the Winograd entry point takes
+    (odd row-block counts such as Cout = 96 / 160, odd chunk counts such as Cin = 192) runs the F(2,3) kernels.  (Both forms need
+    rows of a multiple of four floats: other lengths are refused by the entry point and run in direct form inside the library.)"""
+    import os
+    if os.environ.get("SVOC_WINO_F4") == "0":
+        return False
+    mt, nch = (co + 31) // 32, (C + 31) // 32
+    blocks = (mt % 2 == 0 and nch % 2 == 0) or (mt == 1 and nch == 1 and os.environ.get("SVOC_W4_C32") != "0")
+    return blocks and (d != 1 or L % 4 == 0)
+
+
 @pytest.mark.parametrize("C,co,k,d,L,B,res", [(128, 128, 3, 1, 4096, 2, True), (128, 128, 7, 1, 1000, 3, True), (128, 128, 11, 1, 4100, 1, False),
                                                (256, 256, 11, 1, 516, 2, True), (64, 96, 7, 1, 260, 2, False), (256, 256, 3, 1, 128, 1, True),
                                                (128, 128, 11, 1, 12, 1, True), (128, 128, 3, 3, 1000, 2, True), (128, 128, 7, 3, 4096, 1, True),
                                                (128, 128, 11, 3, 756, 2, True), (256, 256, 3, 5, 1204, 1, False), (128, 128, 7, 5, 4100, 2, True),
                                                (128, 128, 11, 5, 2400, 2, True), (64, 96, 11, 5, 40, 1, False), (128, 128, 11, 3, 8, 1, True),
                                                (64, 64, 11, 5, 1000, 2, True), (64, 64, 7, 3, 700, 1, True), (64, 64, 3, 1, 332, 2, True),
-                                               (128, 128, 7, 1, 1004, 1, True), (64, 64, 11, 1, 2048, 1, False)])
+                                               (128, 128, 7, 1, 1004, 1, True), (64, 64, 11, 1, 2048, 1, False),
+                                               (192, 64, 7, 1, 1000, 2, False), (64, 160, 3, 3, 600, 1, False),
+                                               (32, 32, 3, 1, 4096, 2, True), (32, 32, 7, 1, 1000, 3, True), (32, 32, 11, 1, 4100, 1, False),
+                                               (32, 32, 3, 3, 1500, 2, True), (32, 32, 7, 3, 4096, 1, True), (32, 32, 11, 3, 756, 2, True),
+                                               (32, 32, 3, 5, 1204, 1, False), (32, 32, 7, 5, 4100, 2, True), (32, 32, 11, 5, 2400, 2, True),
+                                               (32, 32, 11, 5, 40, 1, True), (32, 32, 11, 1, 12, 1, True), (32, 32, 7, 1, 516, 2, True)])
 def test_conv1d_winograd(M, C, co, k, d, L, B, res):
-    """lrelu -> Conv1d(k, dilation d) [+ residual] in Winograd F(2,3) form (conv_wino.hip: three-tap groups at tap offsets
-    0/4/8 on shared transformed planes + direct taps 3/7 on de-interleaved planes; dilation through the polyphase pairing
-    (n, n + d)) against torch's direct convolution: every (k, d) of the model, ragged last tiles (L not a multiple of the
-    128/126/120-column tiles), inputs shorter than the halo, odd row-block counts (Cout = 96), lanes whose second
-    output falls beyond the end (dilated tiles), the 64-pair tiles of C = 64 incl. the k = 11 / d = 5 variant that stores E / O with its own geometry."""
+    """lrelu -> Conv1d(k, dilation d) [+ residual] through the Winograd entry point against torch's direct convolution, AND which
+    form ran, read from the executed-multiply-add counter: F(4,3) (conv_wino4.hip, the default: three-tap groups at tap offsets
+    0/4/8 on shared transformed planes + left-over taps 3/7 on the de-interleaved planes; dilation through the polyphase view)
+    issues (1.5, 4, 6.5)/k of the direct form's multiply-adds for k = 3/7/11, the documented fall-back F(2,3) (conv_wino.hip:
+    odd row-block or chunk counts, SVOC_WINO_F4=0) issues (2, 5, 8)/k.
+    Shapes: every (k, d) of the model for the 128- / 64-row blocks and for the single 32-row block of the last MRF stage (C = 32,
+    round 4: 1 x 4 consumers), ragged last tiles, inputs shorter than the halo, odd row-block counts (Cout = 96), lanes whose
+    later outputs fall beyond the end (dilated tiles)."""
     import ctypes, os
     if os.environ.get("SVOC_WINO") == "0":
         pytest.skip("SVOC_WINO=0: the Winograd entry point refuses by design (variant run of the direct-form fallback)")
+    if C == 32 and (os.environ.get("SVOC_WINO_F4") == "0" or os.environ.get("SVOC_W4_C32") == "0"):
+        pytest.skip("C = 32 exists in F(4,3) form only")
     seed = 300 + C + 7 * k + L + 1000 * d
     v = T(cases.rnd(seed, "v", (co, C, k), 1.0 / np.sqrt(C * k)))
     g = T((0.5 + sw.uniform01(seed, "g", co)).astype(np.float32)).reshape(co, 1, 1)
@@ -123,8 +146,14 @@ def test_conv1d_winograd(M, C, co, k, d, L, B, res):
     N = M.native
     xc, vc, gc, bc = x.cuda(), v.cuda(), g.cuda(), bias.cuda()
     y = torch.full((B, co, L), float("nan"), device="cuda")
+    N.stats_reset()
     N.check(N.lib().svoc_conv1d_winograd(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), N.ptr(xc) if res else None,
                                          N.ptr(y), B, C, co, L, k, d, ctypes.c_float(0.1)))
+    st = N.stats_get()
+    G = (k + 1) // 4
+    want = ((1.5 if _wino_f4_expected(C, co, k, d, L) else 2.0) * G + (G - 1)) / k
+    assert st["conv_flops"] == 2.0 * C * co * k * B * L, st
+    assert abs(st["executed_flops"] / st["conv_flops"] - want) < 1e-9, (st, want)
     check(f"winograd C{C} k{k} d{d} L{L}", y, ref)
     rc = N.lib().svoc_conv1d_winograd(N.stream_ptr(), N.ptr(xc), N.ptr(vc), N.ptr(gc), N.ptr(bc), None, N.ptr(y), B, C, co, L, 5, 1, ctypes.c_float(0.1))
     assert rc == -5

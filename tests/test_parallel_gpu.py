@@ -107,8 +107,9 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
 
 def test_bench_single_gpu_line_schema():
     """bench.py at N=1 on the timed configuration (16 x 512, 2 steps, no CPU leg): ONE JSON line with the contract's keys, the
-    roofline block with both fractions (direct-form `frac`, which the Winograd kernels may push above 1, and `frac_executed`,
-    which is bounded by the peak), the library's launch statistics and the HBM traffic of the step (live PMC passes)."""
+    roofline block (`frac` = executed multiply-adds over the peak, bounded by 1; `frac_direct_form`, which the Winograd kernels may
+    push above 1), the library's launch statistics, the HBM traffic of the step and the hardware's MFMA count of the default plan
+    (live PMC passes; the count must agree with the library's bookkeeping to 1.5 %), and the C1 / C3 / C5 timings."""
     cmd = [sys.executable, os.path.join(cases.ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -121,7 +122,15 @@ def test_bench_single_gpu_line_schema():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["vs_baseline"] is None and "workload" in j["config"]
     rf = j["roofline"]
     assert rf["bound"] == "mfma" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert 0.0 < rf["frac_executed"] <= 1.0 and rf["frac_executed"] <= rf["frac"] + 1e-9
+    assert 0.0 < rf["frac"] <= 1.0 and rf["frac"] <= rf["frac_direct_form"] + 1e-9
+    assert abs(rf["frac_direct_form"] - rf["achieved_direct_form"] / rf["peak"]) < 1e-9
+    dk = rf["dominant_kernel"]
+    assert 0.0 < dk["frac"] <= 1.0 and abs(dk["frac"] - dk["achieved"] / rf["peak"]) < 1e-9
+    if rf["traffic_source"].startswith("LIVE"):
+        assert rf["executed_flops_pmc"] is not None and abs(rf["executed_flops_pmc_over_library"] - 1.0) < 0.015, rf
+    oc = j["other_configs"]
+    for k in ("c1_1x200", "c3_32x512", "c5_8x4096"):
+        assert oc[k]["ms_per_step"] > 0 and oc[k]["finite"], oc
     assert abs(rf["flop_per_step"] - 2568280.0 * j["config"]["samples_per_step"]) / rf["flop_per_step"] < 0.01
     assert 0.5 < rf["executed_mfma_flop_fraction"] <= 1.0
     # HBM traffic: live rocprofv3 --pmc child runs (or, should the profiler fail on the box, this round's committed passes)

@@ -68,5 +68,18 @@ def traffic(read_dir, write_dir, per_step=0, steps=1):
             "method": "rocprofv3 --pmc, TCC_EA0_RDREQ_{32B,64B,128B}_sum and TCC_EA0_WRREQ{,_64B}_sum, separate passes, bench.py 16x512"}
 
 
+def counter_per_step(path, name, steps=1):
+    """Sum of counter `name` over the dispatches of the last `steps` inference steps (a step starts at its sequence_mask
+    dispatch), per step.  bench.py: SQ_INSTS_MFMA of the default launch plan -> `roofline.executed_flops_pmc`."""
+    by, names = load(path)
+    if not by:
+        raise RuntimeError("no counter_collection.csv under " + path)
+    ids = sorted(by)
+    marks = [k for k, i in enumerate(ids) if "sequence_mask" in names[i]]
+    if len(marks) < steps:
+        raise RuntimeError("fewer sequence_mask dispatches than steps in " + path)
+    return sum(by[i].get(name, 0.0) for i in ids[marks[-steps]:]) / steps
+
+
 if __name__ == "__main__":
     print(json.dumps(traffic(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0, int(sys.argv[4]) if len(sys.argv) > 4 else 1)))

@@ -15,7 +15,7 @@ python - <<PY
 import json
 for t in ("f2","f4"):
     try:
-        j=json.load(open("$O/bench_%s.json" % t)); print(t, j["ms_per_step"], j["roofline"]["frac_executed"], j["roofline"].get("dominant_kernel",{}).get("avg_launch_us"))
+        j=json.load(open("$O/bench_%s.json" % t)); print(t, j["ms_per_step"], j["roofline"]["frac"], j["roofline"].get("dominant_kernel",{}).get("avg_launch_us"))
     except Exception as e: print(t, "ERR", e, open("$O/bench_%s.err" % t).read()[-1500:])
 PY
 python tools/profile_infer.py 16 512 3 > $O/per_layer.txt 2>&1; head -60 $O/per_layer.txt
