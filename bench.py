@@ -131,7 +131,8 @@ def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     return best, rep
 
 
-MFMA_FLOP = 4096.0                   # 2*MAC of one v_mfma_f32_32x32x2_f32 (the only MFMA opcode in the library: 32 x 32 x 2 x 2)
+MFMA_MOPS_FLOP = 512.0               # SQ_INSTS_VALU_MFMA_MOPS_F32 counts fp32 MFMA work in units of 512 FLOP (rocprofv3's MfmaFlopsF32 =
+                                     # MOPS_F32 * 512): 8 per v_mfma_f32_32x32x2_f32, 4 per v_mfma_f32_16x16x4_f32 (the WN layers' F(2,5) stream)
 
 
 def other_configs(net, dev):
@@ -167,8 +168,8 @@ def other_configs(net, dev):
 
 def live_hbm_traffic(B, T, timeout_s=150):
     """Three child runs of this script under `rocprofv3 --pmc` on the DEFAULT launch plan (read-request counters, write-request
-    counters, SQ_INSTS_MFMA: separate passes, no tracing beside them), 2 steps each; returns (HBM bytes of the GEMM-family kernels
-    per step, description, MFMA instructions per step as the hardware counted them)."""
+    counters, SQ_INSTS_VALU_MFMA_MOPS_F32: separate passes, no tracing beside them), 2 steps each; returns (HBM bytes of the
+    GEMM-family kernels per step, description, fp32 MFMA operations per step as the hardware counted them, in units of 512 FLOP)."""
     import shutil, subprocess, tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
@@ -181,7 +182,7 @@ def live_hbm_traffic(B, T, timeout_s=150):
     base = tempfile.mkdtemp(prefix="svoc_pmc_", dir="/tmp")
     try:
         dirs = []
-        for tag, counters in (("rd", pmc_traffic.READ_COUNTERS), ("wr", pmc_traffic.WRITE_COUNTERS), ("mfma", ["SQ_INSTS_MFMA"])):
+        for tag, counters in (("rd", pmc_traffic.READ_COUNTERS), ("wr", pmc_traffic.WRITE_COUNTERS), ("mfma", ["SQ_INSTS_VALU_MFMA_MOPS_F32"])):
             d = os.path.join(base, tag)
             cmd = [prof, "--pmc", *counters, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "2", "--warmup", "1", "--batch", str(B), "--frames", str(T), "--no-cpu-baseline", "--no-pmc", "--no-other-configs"]
@@ -192,10 +193,10 @@ def live_hbm_traffic(B, T, timeout_s=150):
         tj = pmc_traffic.traffic(dirs[0], dirs[1], 0, 2)
         if tj["gemm_family_launches_per_step"] < 1:
             raise RuntimeError("no GEMM-family dispatches in the counter traces")
-        mfma = pmc_traffic.counter_per_step(dirs[2], "SQ_INSTS_MFMA", 2)
+        mfma = pmc_traffic.counter_per_step(dirs[2], "SQ_INSTS_VALU_MFMA_MOPS_F32", 2)
         return (tj["gemm_family_read_bytes_per_step"] + tj["gemm_family_write_bytes_per_step"],
                 f"LIVE: `rocprofv3 --pmc` child runs of bench.py after the timed region ({', '.join(pmc_traffic.READ_COUNTERS)} | "
-                f"{', '.join(pmc_traffic.WRITE_COUNTERS)} | SQ_INSTS_MFMA; 2 steps each, {tj['dispatches_counted_per_step']:.0f} dispatches per step; "
+                f"{', '.join(pmc_traffic.WRITE_COUNTERS)} | SQ_INSTS_VALU_MFMA_MOPS_F32; 2 steps each, {tj['dispatches_counted_per_step']:.0f} dispatches per step; "
                 f"whole step {((tj['hbm_read_bytes_per_step'] + tj['hbm_write_bytes_per_step']) / 1e9):.1f} GB)", mfma)
     finally:
         shutil.rmtree(base, ignore_errors=True)
@@ -379,7 +380,7 @@ def main():
         }
         # Roofline.  `achieved` / `frac` (round 4): 2*MAC the matrix pipe really ISSUED in the timed region - counted per launch by
         # the library (the Winograd kernels issue a fixed share of the direct form's multiply-adds) and checked against the hardware's
-        # SQ_INSTS_MFMA count below - over the device time of the region (HIP events on the launch stream; conservative: the region
+        # SQ_INSTS_VALU_MFMA_MOPS_F32 count below - over the device time of the region (HIP events on the launch stream; conservative: the region
         # includes the few % of non-GEMM kernels).  Bounded by the FP32 MFMA peak.  `achieved_direct_form` / `frac_direct_form` price
         # the ALGORITHMIC direct-form FLOPs of SURVEY.md 8(d) (2 568 280 per sample) over the same time: a statement about time to
         # solution that the peak does not bound (Winograd arithmetic does the same convolutions with fewer multiply-adds).
@@ -439,11 +440,11 @@ def main():
                 except Exception:   # noqa: BLE001
                     pass
         if mfma_insts is not None:
-            # hardware check of the library's bookkeeping: SQ_INSTS_MFMA of one step of the DEFAULT plan x 4096 FLOP per
-            # v_mfma_f32_32x32x2_f32 (includes the padding of ragged tiles, which the library's counter leaves out)
-            res["roofline"]["executed_flops_pmc"] = mfma_insts * MFMA_FLOP
-            res["roofline"]["executed_flops_pmc_over_library"] = mfma_insts * MFMA_FLOP / max(1.0, stats["executed_flops"] / args.steps)
-            res["roofline"]["frac_pmc"] = mfma_insts * MFMA_FLOP / (gpu_ms / args.steps * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            # hardware check of the library's bookkeeping: SQ_INSTS_VALU_MFMA_MOPS_F32 of one step of the DEFAULT plan x 512 FLOP
+            # (includes the padding of ragged tiles, which the library's counter leaves out)
+            res["roofline"]["executed_flops_pmc"] = mfma_insts * MFMA_MOPS_FLOP
+            res["roofline"]["executed_flops_pmc_over_library"] = mfma_insts * MFMA_MOPS_FLOP / max(1.0, stats["executed_flops"] / args.steps)
+            res["roofline"]["frac_pmc"] = mfma_insts * MFMA_MOPS_FLOP / (gpu_ms / args.steps * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
         if step_bytes is not None:
             res["roofline"]["traffic"] = step_bytes / max(1.0, res["roofline"]["gemm_launches_per_step"])
             res["roofline"]["traffic_unit"] = "HBM bytes per GEMM-family launch (mean over gemm_launches_per_step)"

@@ -34,6 +34,7 @@ static inline int stage_ld(int n) { return round_up(n, 4); }
 struct WNStack {
   int H = 0, K = 0, DR = 1, NL = 0, gin = 0;
   std::vector<std::unique_ptr<PackedConv>> in_l, rs_l;
+  std::vector<std::unique_ptr<DevBuf>> in_f25;            // in_layers in Winograd F(2,5) form where wn_fused.hip serves the shape
   std::unique_ptr<PackedConv> cond;
   DevBuf ws;
 
@@ -45,6 +46,8 @@ struct WNStack {
       PackSpec sp{}; sp.Cin = H; sp.Cout = 2 * H; sp.K = K; sp.dil = d; sp.paired = true;
       in_l.emplace_back(new PackedConv());
       SVOC_TRY(pack_conv_named(*in_l.back(), sp, tab, prefix + "in_layers." + std::to_string(i), st));
+      in_f25.emplace_back(new DevBuf());
+      SVOC_TRY(pack_wn_f25_named(*in_f25.back(), H, K, d, tab, prefix + "in_layers." + std::to_string(i), st));
       PackSpec rp{}; rp.Cin = H; rp.K = 1;
       if (i < NL - 1) { rp.Cout = 2 * H; rp.split_at = H; } else { rp.Cout = H; }
       rs_l.emplace_back(new PackedConv());
@@ -94,7 +97,7 @@ struct WNStack {
       const int gts = g_T == 1 ? 0 : 1;
       {   // whole layer in one kernel (wn_fused.hip) when eligible
         const int r = launch_wn_layer_fused(*in_l[i], *rs_l[i], H, src, src_bs, src_ld, dst, per, Tp, out, out_bs, out_ld, mask, mask_bs,
-                                            gl, gper, gTp, gts, i == 0 ? 1 : 0, last ? 1 : 0, B, T, st);
+                                            gl, gper, gTp, gts, i == 0 ? 1 : 0, last ? 1 : 0, B, T, st, in_f25[i]->f());
         if (r < 0) return r;
         if (r == 0) { src = dst; src_bs = per; src_ld = Tp; continue; }
       }

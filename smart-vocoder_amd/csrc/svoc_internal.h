@@ -211,7 +211,10 @@ bool resblock_fused_ct_supported(int C, int k, int dil);   // shapes served by t
 int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H, const float* x, long long x_bs, int x_ld,
                           float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs, int out_ld, const float* mask,
                           long long mask_bs, const float* gadd, long long gadd_bs, int gadd_ld, int gadd_ts, int first, int last,
-                          int B, int T, hipStream_t st);
+                          int B, int T, hipStream_t st, const float* wpf = nullptr);
+// F(2,5) image of an in_layer (H = 192, k = 5, dilation 1; wn_layer_f25_kernel), left empty when the form does not apply
+bool wn_f25_enabled();
+int pack_wn_f25_named(DevBuf& img, int H, int K, int dil, const TensorTable& tab, const std::string& prefix, hipStream_t st);
 
 // ------------------------------------------------------------------ small kernels (misc_kernels.hip)
 int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, int T);

@@ -28,6 +28,7 @@ struct WnArgs {
   const float* gadd; long long gadd_bs; int gadd_ld; int gadd_ts;   // conditioning slice of this layer: rows [0,2H)
   const float* wp1; const float* bias1; int ksg1; int dil; int pad;  // in_layer (paired packing)
   const float* wp2; const float* bias2; int ksg2;                     // res_skip (split packing, or plain on the last layer)
+  const float* wpf;                                                   // in_layer in Winograd F(2,5) form (wn_layer_f25_kernel), or null
   int H; int ktaps; int nchunks; int npairs; int T;
   int xoff0; int xrow; int arow;
   int first; int last;
@@ -519,6 +520,356 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
   dump();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the in_layer (k = 5: 960 of the 1152 k-steps of a layer) in Winograd F(2,5) form - two outputs from six products
+// instead of ten, 3/5 of the direct form's multiply-adds - with the matrix pipe's 16-column tile (v_mfma_f32_16x16x4_f32: same
+// FLOP rate as 32x32x2, half the columns), so that a 32-column workgroup still fills its MFMAs: 16 windows of two outputs.
+// Interpolation points 0, +-1, +-2, infinity: the input transform is conv_wino4.hip's (it depends on the points only),
+//     V0 = 4 d0 - 5 d2 + d4     V1 = -4 d1 - 4 d2 + d3 + d4     V2 = 4 d1 - 4 d2 - d3 + d4     d_j = x[2q - 2 + j]
+//     V3 = -2 d1 - d2 + 2 d3 + d4     V4 = 2 d1 - d2 - 2 d3 + d4     V5 = 4 d1 - 5 d3 + d5
+//     U0 = w0/4   U1 = -(w0+w1+w2+w3+w4)/6   U2 = -(w0-w1+w2-w3+w4)/6   U3 = (w0+2w1+4w2+8w3+16w4)/24
+//     U4 = (w0-2w1+4w2-8w3+16w4)/24   U5 = w4          M_p = sum_c U_p[c] V_p[c]  (the GEMMs)
+//     y[2q] = M0 + M1 + M2 + M3 + M4          y[2q+1] = M1 - M2 + 2 M3 - 2 M4 + M5
+// fp32 error 3.6 x the direct form's (tools/wino_numerics.py) - the F(4,3) decoder kernels' constant.  Same workgroup as the
+// K-split kernel: 12 waves, wave (pi, kh) = row pair pi (tanh rows 32 pi .., sigmoid rows H + 32 pi ..: four 16-row tiles) over
+// half kh of the input channels, 4 x 6 accumulator tiles of 4 registers; per (k-step, product) ONE ds_read_b32 (the B fragment is
+// shared by the four row tiles) and ONE 16-byte buffer load (the four tiles' A values): a VALU-free stream of 576 MFMAs of 32
+// cycles (the direct form: 480 of 64).  The six planes [p][H][16 windows] are written by all waves ahead of the stream (4 windows
+// per thread); the output transform runs on the partial sums before the K-half exchange.  Phases B (res_skip 1x1) and the
+// epilogue are the K-split kernel's.  H = 192, k = 5, dilation 1 only (every WN of the path).
+typedef float wn_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WNF_H = 192, WNF_XROW = 40, WNF_AROW = 33, WNF_NP = 6, WNF_NQ = 16, WNF_PLANE = WNF_H * WNF_NQ;
+constexpr int WNF_KS = 24;                                  // k-steps (of 4 channels) per wave: half of the 192 channels
+constexpr int WNF_LDS_FLOATS = WNF_H * WNF_XROW + 6 * WNF_PLANE + 2 * WNF_NP * 16 * 64;
+
+template <bool LAST>
+__global__ void __launch_bounds__(768) wn_layer_f25_kernel(const WnArgs p) {
+  constexpr int H = WNF_H, NPAIRS = WNF_NP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const XT = lds;                                    // x tile [H][40]; later aliased by the acts tile [H][33]
+  float* const AT = lds;
+  float* const PLN = lds + H * WNF_XROW;                    // V_p [6][H][16]
+  float* const RED = PLN + 6 * WNF_PLANE;                   // exchange area [12 waves][16][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave >= NPAIRS ? 1 : 0;                    // K half
+  const int pi = wave - kh * NPAIRS;                        // row pair
+  const int l31 = lane & 31, hi = lane >> 5;                // 32x32x2 fragment coordinates (phase B, epilogue)
+  const int col = lane & 15, k4 = lane >> 4;                // 16x16x4 fragment coordinates (phase A)
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * 32;
+  float* const red_mine = RED + (wave * 16) * 64 + lane;
+  float* const red_peer = RED + ((kh ? pi : pi + NPAIRS) * 16) * 64 + lane;
+
+  long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int i) { if (p.dbg) ts[i] = (long long)__builtin_readcyclecounter(); };
+  stamp(0);
+  // ---- stage the x tile: all H channels, columns [t0 - 4, t0 + 36), zero outside [0, T)
+  {
+    constexpr int R4 = WNF_XROW / 4, total = H * R4, SU = 3;       // 1920 groups of four floats: 2.5 per thread
+    const int xs_start = t0 - 4;
+    const float* xb = p.x + (long long)b * p.x_bs;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (p.x_ld & 3) == 0 && (p.x_bs & 3) == 0;
+    float4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int it = min(tid + 768 * u, total - 1);
+      const int c = it / R4, g4 = it - c * R4;
+      int t = xs_start + 4 * g4;
+      const float* row = xb + (long long)c * p.x_ld;
+      if (vec) {
+        t = (t >= 0 && t < p.T) ? t : 0;
+        v[u] = *reinterpret_cast<const float4*>(row + t);
+      } else {
+        v[u].x = (t >= 0 && t < p.T) ? row[t] : 0.f;
+        v[u].y = (t + 1 >= 0 && t + 1 < p.T) ? row[t + 1] : 0.f;
+        v[u].z = (t + 2 >= 0 && t + 2 < p.T) ? row[t + 2] : 0.f;
+        v[u].w = (t + 3 >= 0 && t + 3 < p.T) ? row[t + 3] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int it = tid + 768 * u;
+      if (it < total) {
+        const int c = it / R4, g4 = it - c * R4;
+        const int t = xs_start + 4 * g4;
+        float4 q = v[u];
+        q.x = (t >= 0 && t < p.T) ? q.x : 0.f;
+        q.y = (t + 1 >= 0 && t + 1 < p.T) ? q.y : 0.f;
+        q.z = (t + 2 >= 0 && t + 2 < p.T) ? q.z : 0.f;
+        q.w = (t + 3 >= 0 && t + 3 < p.T) ? q.w : 0.f;
+        *reinterpret_cast<float4*>(XT + c * WNF_XROW + 4 * g4) = q;
+      }
+    }
+  }
+  __syncthreads();
+  stamp(1);
+  // ---- input transform: window q of channel c reads x[t0 + 2q - 2 .. + 3] = tile columns 2q + 2 .. 2q + 7 (8-byte aligned)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = (tid >> 4) + 48 * u, q = tid & 15;
+    const float* r = XT + c * WNF_XROW + 2 * q + 2;
+    const float2 f0 = *reinterpret_cast<const float2*>(r), f1 = *reinterpret_cast<const float2*>(r + 2), f2 = *reinterpret_cast<const float2*>(r + 4);
+    const float d0 = f0.x, d1 = f0.y, d2 = f1.x, d3 = f1.y, d4 = f2.x, d5 = f2.y;
+    const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);      // d4 - 4 d2, d3 - 4 d1
+    const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+    float* o = PLN + c * WNF_NQ + q;
+    o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+    o[WNF_PLANE] = a_ + b_;
+    o[2 * WNF_PLANE] = a_ - b_;
+    o[3 * WNF_PLANE] = c_ + e_;
+    o[4 * WNF_PLANE] = c_ - e_;
+    o[5 * WNF_PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+  }
+  __syncthreads();
+  stamp(2);
+  // ---- phase A: 24 k-steps x 6 products x 4 row tiles of v_mfma_f32_16x16x4_f32
+  wn_f32x4 M[4][6];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) M[rt][q] = (wn_f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    constexpr int NST = WNF_KS * 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpf), 0, 0x7fffffff, 0x00020000);
+    const int w0 = __builtin_amdgcn_readfirstlane((pi * 2 + kh) * NST * 1024);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned baddr0 = (unsigned)(size_t)PLN + (unsigned)(((kh * 96 + k4) * WNF_NQ + col) * 4);
+    const unsigned baddr1 = baddr0 + 3u * WNF_PLANE * 4u;
+    float4 a[4];
+    float fb[2];
+    auto wload = [&](float4& d, int soff) {
+      const wn_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wlane, soff, 0);
+      d = *reinterpret_cast<const float4*>(&t);
+    };
+    auto rdb = [&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      if constexpr (I < NST) {
+        constexpr int KS_ = I / 6, P_ = I % 6;
+        constexpr int O = ((P_ % 3) * WNF_PLANE + KS_ * 4 * WNF_NQ) * 4;
+        fb[I & 1] = wino_lds_rd<O>(P_ < 3 ? baddr0 : baddr1);
+      }
+    };
+    auto rqw = [&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      if constexpr (I < NST) wload(a[I & 3], w0 + I * 1024);
+    };
+    auto step = [&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int P_ = I % 6;
+      rqw(std::integral_constant<int, I + 3>{});
+      {
+        float& bq = fb[I & 1];
+        if constexpr (I + 1 < NST) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq));
+      }
+      const float4 av = a[I & 3];
+      const float bv = fb[I & 1];
+      M[0][P_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv, M[0][P_], 0, 0, 0);
+      M[1][P_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv, M[1][P_], 0, 0, 0);
+      M[2][P_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv, M[2][P_], 0, 0, 0);
+      M[3][P_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv, M[3][P_], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdb(std::integral_constant<int, I + 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    rqw(std::integral_constant<int, 0>{}); rqw(std::integral_constant<int, 1>{}); rqw(std::integral_constant<int, 2>{});
+    rdb(std::integral_constant<int, 0>{}); rdb(std::integral_constant<int, 1>{});
+    wino_static_for<0, NST>(step);
+  }
+  stamp(3);
+  // ---- output transform of the partial sums; this wave finishes 16-row tile kh of both halves and hands the other to its peer
+  float own[2][4][2];                                       // [tanh | sigmoid][register i][output 0 | 1]
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int h = rt >> 1;
+    const bool mine = (rt & 1) == kh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s12 = M[rt][1][i] + M[rt][2][i], d12 = M[rt][1][i] - M[rt][2][i];
+      const float s34 = M[rt][3][i] + M[rt][4][i], d34 = M[rt][3][i] - M[rt][4][i];
+      const float y0 = M[rt][0][i] + (s12 + s34);
+      const float y1 = __builtin_fmaf(2.f, d34, d12) + M[rt][5][i];
+      if (mine) { own[h][i][0] = y0; own[h][i][1] = y1; }
+      else { red_mine[(h * 8 + 2 * i) * 64] = y0; red_mine[(h * 8 + 2 * i + 1) * 64] = y1; }
+    }
+  }
+  stamp(7);
+  __syncthreads();     // partials published
+  stamp(8);
+  {
+    const float* gb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = 16 * kh + 4 * k4 + i;                  // row inside the pair's 32-row tiles
+      const int chn = pi * 32 + rr;
+      const float bA = p.bias1[(2 * pi) * 32 + rr], bB = p.bias1[(2 * pi + 1) * 32 + rr];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const int m = 2 * col + o;
+        float vA = (own[0][i][o] + red_peer[(2 * i + o) * 64]) + bA;
+        float vB = (own[1][i][o] + red_peer[(8 + 2 * i + o) * 64]) + bB;
+        if (gb) {
+          const int t = min(t0 + m, p.T - 1);
+          vA += gb[(long long)chn * p.gadd_ld + (long long)t * p.gadd_ts];
+          vB += gb[(long long)(H + chn) * p.gadd_ld + (long long)t * p.gadd_ts];
+        }
+        AT[chn * WNF_AROW + m] = gate_tanh_sigmoid(vA, vB);
+      }
+    }
+  }
+  stamp(9);
+  // ---- phase B: res_skip 1x1 on the acts tile (the K-split kernel's): tile pi = x part, tile npairs + pi = skip part
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      acc[h][0][i] = (!kh && (h == 0 || !LAST)) ? p.bias2[(h * NPAIRS + pi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi] : 0.f;
+  __syncthreads();     // acts tile complete, exchange area free again
+  stamp(4);
+  {
+    const unsigned baddr = (unsigned)(size_t)AT + (unsigned)((kh * 96 + hi) * WNF_AROW + l31) * 4u;
+    const int w0 = __builtin_amdgcn_readfirstlane((pi * p.ksg2 + kh * 12) * 1024);
+    const int w1 = __builtin_amdgcn_readfirstlane(((NPAIRS + pi) * p.ksg2 + kh * 12) * 1024);
+    wn_gemm_ct<WNF_AROW, 1, 1, !LAST>(acc, p.wp2, w0, LAST ? w0 : w1, baddr, (unsigned)lane * 16u);
+  }
+  stamp(5);
+  // exchange: kh=0 finishes tile 0 (residual part; on the last layer the only tile), kh=1 finishes tile 1 (skip part)
+  if (!LAST) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red_mine[q * 64] = kh ? acc[0][0][q] : acc[1][0][q];
+  } else if (kh) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red_mine[q * 64] = acc[0][0][q];
+  }
+  __syncthreads();
+  float fin[16];
+  if (!LAST || !kh) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) fin[q] = (kh ? acc[1][0][q] : acc[0][0][q]) + red_peer[q * 64];
+  }
+  auto dump = [&]() {
+    if (p.dbg && tid == 0) {
+      long long* d = p.dbg + 8 * (long long)(blockIdx.x + gridDim.x * blockIdx.z);
+      d[0] = ts[0]; d[1] = ts[2]; d[2] = ts[3]; d[3] = ts[4]; d[4] = ts[5]; d[5] = (long long)__builtin_readcyclecounter();
+      d[6] = (long long)__builtin_readcyclecounter(); d[7] = ((ts[7] - ts[3]) << 42) | ((ts[8] - ts[7]) << 21) | (ts[9] - ts[8]);
+    }
+  };
+  // ---- epilogue (modules.py:168-175)
+  const int t = t0 + l31;
+  if (t >= p.T) { dump(); return; }
+  const float* mb = p.mask + (long long)b * p.mask_bs;
+  const float mk = mb[t];
+  const int row0 = pi * 32 + 4 * hi;
+  float* ob = p.out + (long long)b * p.out_bs + (long long)row0 * p.out_ld + t;
+  if (!LAST) {
+    if (!kh) {         // x = (x + rs[:H]) * mask
+      const float* xr = p.x + (long long)b * p.x_bs + (long long)row0 * p.x_ld + t;
+      float* xw = p.xo + (long long)b * p.xo_bs + (long long)row0 * p.xo_ld + t;
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = xr[(long long)((r & 3) + 8 * (r >> 2)) * p.x_ld];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xw[(long long)((r & 3) + 8 * (r >> 2)) * p.xo_ld] = (rv[r] + fin[r]) * mk;
+    } else {           // out += rs[H:]
+      float ov[16];
+      if (!p.first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = p.first ? fin[r] : ov[r] + fin[r];
+    }
+  } else if (!kh) {    // last layer: out = (out + rs) * mask
+    float ov[16];
+    if (!p.first) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = p.first ? fin[r] : ov[r] + fin[r];
+      ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = v * mk;
+    }
+  }
+  dump();
+}
+
+// F(2,5) image of one in_layer: [pair 6][K half 2][k-step 24][product 6][lane 64][row tile 4]; lane = (k4 = lane / 16, r = lane % 16)
+// holds U_p[row(rt, r)][channel 96 kh + 4 ks + k4] for the four 16-row tiles rt of the pair (tanh rows 32 pi + 16 (rt & 1) + r,
+// sigmoid rows H + the same): one 16-byte load = the A operands of the four MFMAs of a (k-step, product).
+__global__ void pack_wn_f25_kernel(const float* __restrict__ src, const float* __restrict__ scale, float* __restrict__ img, long long total) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int rt = (int)(e & 3);
+  const int lane = (int)((e >> 2) & 63);
+  long long rest = e >> 8;
+  const int pp = (int)(rest % 6); rest /= 6;
+  const int ks = (int)(rest % WNF_KS); rest /= WNF_KS;
+  const int kh = (int)(rest & 1);
+  const int pi = (int)(rest >> 1);
+  const int row = (rt >> 1) * WNF_H + pi * 32 + 16 * (rt & 1) + (lane & 15);
+  const int chan = 96 * kh + 4 * ks + (lane >> 4);
+  const float* w = src + ((long long)row * WNF_H + chan) * 5;
+  const float sc = scale ? scale[row] : 1.0f;
+  const float w0 = w[0] * sc, w1 = w[1] * sc, w2 = w[2] * sc, w3 = w[3] * sc, w4 = w[4] * sc;
+  float val;
+  switch (pp) {
+    case 0: val = 0.25f * w0; break;
+    case 1: val = -(((w0 + w2) + w4) + (w1 + w3)) * (1.0f / 6.0f); break;
+    case 2: val = -(((w0 + w2) + w4) - (w1 + w3)) * (1.0f / 6.0f); break;
+    case 3: val = (((w0 + 4.f * w2) + 16.f * w4) + (2.f * w1 + 8.f * w3)) * (1.0f / 24.0f); break;
+    case 4: val = (((w0 + 4.f * w2) + 16.f * w4) - (2.f * w1 + 8.f * w3)) * (1.0f / 24.0f); break;
+    default: val = w4; break;
+  }
+  img[e] = val;
+}
+__global__ void wnf_scale_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ scale, long long inner) {
+  __shared__ float red[256];
+  const int i = blockIdx.x;
+  const float* q = v + (long long)i * inner;
+  float s = 0.f;
+  for (long long k = threadIdx.x; k < inner; k += blockDim.x) s += q[k] * q[k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scale[i] = g[i] / sqrtf(red[0]);
+}
+
+bool wn_f25_enabled() {
+  static const bool on = !(getenv("SVOC_WN_F25") && atoi(getenv("SVOC_WN_F25")) == 0);      // SVOC_WN_F25=0: the direct-form layer kernels
+  return on;
+}
+// Builds the F(2,5) image of `prefix` (an in_layer of a WN with H = 192, k = 5) when the form applies; leaves `img` empty otherwise.
+int pack_wn_f25_named(DevBuf& img, int H, int K, int dil, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
+  if (!wn_f25_enabled() || H != WNF_H || K != 5 || dil != 1) return SVOC_OK;
+  const svoc_tensor* w = tab.find(prefix + ".weight");
+  const svoc_tensor* v = tab.find(prefix + ".weight_v");
+  const svoc_tensor* g = tab.find(prefix + ".weight_g");
+  const svoc_tensor* src = w ? w : v;
+  if (!src || (!w && !g)) SVOC_FAIL(SVOC_ERR_MISSING_TENSOR, "missing tensor %s.weight / .weight_v / .weight_g", prefix.c_str());
+  if (src->ndim != 3 || src->shape[0] != 2 * H || src->shape[1] != H || src->shape[2] != 5) SVOC_FAIL(SVOC_ERR_SHAPE, "tensor %s has the wrong shape", src->name);
+  const long long total = (long long)WNF_NP * 2 * WNF_KS * 6 * 256;
+  SVOC_TRY(img.ensure((size_t)(total + 1024) * sizeof(float)));
+  SVOC_HIP(hipMemsetAsync(img.f() + total, 0, 1024 * sizeof(float), st));
+  DevBuf scale;
+  if (!w) {
+    SVOC_TRY(scale.ensure((size_t)2 * H * sizeof(float)));
+    hipLaunchKernelGGL(wnf_scale_kernel, dim3((unsigned)(2 * H)), dim3(256), 0, st, (const float*)src->data, (const float*)g->data, scale.f(), (long long)H * 5);
+  }
+  hipLaunchKernelGGL(pack_wn_f25_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)src->data, w ? nullptr : scale.f(), img.f(), total);
+  SVOC_HIP(hipGetLastError());
+  SVOC_HIP(hipStreamSynchronize(st));                      // `scale` is freed on return
+  return SVOC_OK;
+}
+
 // (A compile-time specialised copy of the K-split kernel - immediate-offset fragment reads, uniform-base weight stream, static
 // group list as in conv_wino.hip - measured 73.8 us per layer against 72.1 us for this one: the layer is not bound by the
 // instructions around its MFMAs but by the serial phases of the ONE workgroup a CU holds: staging, two exchanges, gate,
@@ -529,7 +880,7 @@ __global__ void __launch_bounds__(768) wn_layer_fused_ks_kernel(const WnArgs p) 
 int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H, const float* x, long long x_bs, int x_ld,
                           float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs, int out_ld, const float* mask,
                           long long mask_bs, const float* gadd, long long gadd_bs, int gadd_ld, int gadd_ts, int first, int last,
-                          int B, int T, hipStream_t st) {
+                          int B, int T, hipStream_t st, const float* wpf) {
   static const bool enabled = !(getenv("SVOC_FUSE_WN") && atoi(getenv("SVOC_FUSE_WN")) == 0);
   if (!enabled) return 1;
   if (H % 32 != 0 || H / 32 > 8 || !in_l.paired || in_l.Cin != H || in_l.Cout != 2 * H || rs_l.Cin != H) return 1;
@@ -545,6 +896,7 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   a.wp2 = rs_l.wp.f(); a.bias2 = rs_l.bias.f(); a.ksg2 = rs_l.ksg_total;
   a.H = H; a.ktaps = in_l.ktaps; a.nchunks = H / KC; a.npairs = npairs; a.T = T;
   a.first = first; a.last = last;
+  a.wpf = wpf;
   a.dbg = debug_stamp_buffer();
   // narrow tiles when there are few columns: every CU should get a workgroup
   const int ncu = device_cu_count();
@@ -569,17 +921,30 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   if (lds > 160 * 1024) return 1;
   dim3 grid((T + NA - 1) / NA, 1, B);
   const double flops = (in_l.flops_per_col + rs_l.flops_per_col) * (double)B * (double)T;
-  stats_add_conv(flops, 2);
-  int prof_idx = -1;
-  if (prof_enabled()) {
-    char d[160];
-    snprintf(d, sizeof(d), "fusedWN H%-4d k%-2d d%-2d N%-7d B%-3d NA%d%s%s", H, in_l.ktaps, in_l.dil, T, B, NA, ksplit ? " ksplit" : "", last ? " last" : "");
-    prof_idx = prof_begin(st, d, flops);
-  }
   static const bool ct_on = !(getenv("SVOC_WN_CT") && atoi(getenv("SVOC_WN_CT")) == 0);
   const bool ct = ct_on && ksplit && H == 192 && in_l.ktaps == 5 && in_l.dil == 1 && a.xrow == 40 && a.arow == 33 && a.nchunks == 6 &&
                   (long long)in_l.mtiles * in_l.ksg_total * 1024 < (1LL << 31);
-  if (ksplit && ct) {
+  const bool f25 = ksplit && ct && wpf != nullptr && wn_f25_enabled() && rs_l.ksg_total == 24;
+  // F(2,5): 6 products per two outputs instead of 10 for the in_layer
+  stats_add_conv(flops, 2, f25 ? (0.6 * in_l.flops_per_col + rs_l.flops_per_col) * (double)B * (double)T : -1.0);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "fusedWN H%-4d k%-2d d%-2d N%-7d B%-3d NA%d%s%s%s", H, in_l.ktaps, in_l.dil, T, B, NA, ksplit ? " ksplit" : "", f25 ? " F(2,5)" : "", last ? " last" : "");
+    prof_idx = prof_begin(st, d, flops);
+  }
+  if (f25) {
+    const size_t ldsf = (size_t)WNF_LDS_FLOATS * sizeof(float);
+    if (last) {
+      auto kern = wn_layer_f25_kernel<true>;
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+      hipLaunchKernelGGL(kern, grid, dim3(768), ldsf, st, a);
+    } else {
+      auto kern = wn_layer_f25_kernel<false>;
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+      hipLaunchKernelGGL(kern, grid, dim3(768), ldsf, st, a);
+    }
+  } else if (ksplit && ct) {
     if (last) {
       auto kern = wn_layer_fused_ks_kernel<true, true>;
       SVOC_TRY(ensure_max_dyn_lds((const void*)kern));

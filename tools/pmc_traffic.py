@@ -70,7 +70,7 @@ def traffic(read_dir, write_dir, per_step=0, steps=1):
 
 def counter_per_step(path, name, steps=1):
     """Sum of counter `name` over the dispatches of the last `steps` inference steps (a step starts at its sequence_mask
-    dispatch), per step.  bench.py: SQ_INSTS_MFMA of the default launch plan -> `roofline.executed_flops_pmc`."""
+    dispatch), per step.  bench.py: SQ_INSTS_VALU_MFMA_MOPS_F32 of the default launch plan -> `roofline.executed_flops_pmc`."""
     by, names = load(path)
     if not by:
         raise RuntimeError("no counter_collection.csv under " + path)
