@@ -233,7 +233,10 @@ def main():
     dev = torch.device("cuda", dev_index)
     dist = None
     cdev = dev                                     # device of the small control tensors of the collectives
-    if world > 1:
+    # one process launched by torch.distributed.run (RANK set, WORLD_SIZE 1) still builds its process group and runs the
+    # scatter / gather: the RCCL data path executes on a 1-GPU box (tests/test_parallel_gpu.py)
+    use_dist = world > 1 or (os.environ.get("BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
@@ -255,7 +258,7 @@ def main():
     Bj = B * world
     mel = eps = ln = None
     scatter_ok = False
-    if world > 1:
+    if use_dist:
         try:
             if rank == 0:
                 full = [torch.from_numpy(sw.synthetic_mel(1001, Bj, T)).to(dev), torch.full((Bj,), T, dtype=torch.int64, device=dev),
@@ -275,12 +278,16 @@ def main():
         eps = torch.from_numpy(sw.synthetic_eps(1001, Bj, T)[a:b_]).to(dev)
         ln = torch.full((B,), T, dtype=torch.int64, device=dev)
 
-    gather_mode = {"v": "gather" if world > 1 else "none"}
+    gather_mode = {"v": "gather" if use_dist else "none"}
+    gather_out = {"v": None}                       # rank 0's receive buffer [Bj, 1, L]: allocated once, outside the timed region
 
     def collect(o):
         """waveforms back to rank 0 (inside the timed region): RCCL gather, falling back to all_gather"""
         if gather_mode["v"] == "gather":
-            return parallel.gather_waveforms(o, Bj, dst=0)
+            if rank == 0 and gather_out["v"] is None:
+                gdev = o.device if cdev.type != "cpu" else torch.device("cpu")
+                gather_out["v"] = torch.empty((Bj,) + tuple(o.shape[1:]), dtype=o.dtype, device=gdev)
+            return parallel.gather_waveforms(o, Bj, dst=0, out=gather_out["v"])
         if gather_mode["v"] == "all_gather":
             out = torch.empty((Bj,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
             dist.all_gather_into_tensor(out, o.contiguous())
@@ -291,7 +298,7 @@ def main():
         o = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
         return collect(o)
 
-    if world > 1:   # choose a collective that works on this node before any timing
+    if use_dist:   # choose a collective that works on this node before any timing
         with torch.no_grad():
             o_probe = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
             for mode in ("gather", "all_gather", "none"):
@@ -318,7 +325,7 @@ def main():
             out = step()
         torch.cuda.synchronize()
         _native.stats_reset()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -328,14 +335,14 @@ def main():
             out = step()
         ev1.record()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
     stats = _native.stats_get()
     scatter_ms = None
-    if world > 1 and scatter_ok:
+    if use_dist and scatter_ok:
         # the other collective of the data path, timed on its own (setup in the weak-scaling protocol, so not inside `value`):
         # rank 0's job batch -> one 16 x T shard per rank, K times, barrier + synchronize on both sides, max over ranks
         full = None
@@ -351,7 +358,7 @@ def main():
         tsc = torch.tensor([(time.perf_counter() - ts) / nsc * 1e3], dtype=torch.float64, device=cdev)
         dist.all_reduce(tsc, op=dist.ReduceOp.MAX)
         scatter_ms = float(tsc.item())
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -474,7 +481,7 @@ def main():
         if fail:
             print("[bench] " + fail, file=sys.stderr)
             raise SystemExit(4)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -952,8 +952,8 @@ int wino4_slots(int K);
 int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
 int wino4_launch(const WinoArgs& w, int K, int D, int NC, long long total, hipStream_t st);
-int wino4_launch_group(const WinoGroup& g, int D, int NC, long long total, hipStream_t st);
-int wino4_launch_accum(const WinoGroup& g, int NRT, long long total, hipStream_t st);
+int wino4_launch_group(const WinoGroup& g, int D, int NC, int in_perm, int out_perm, long long total, hipStream_t st);
+int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, long long total, hipStream_t st);
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
@@ -1029,6 +1029,7 @@ static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, int D, int
   const int W = wino_tile_w(D, WM);
   w.ntn = (a.Ncols + W - 1) / W; w.gy = (pw.mtiles + WM - 1) / WM; w.xcd = xcd_mapping_enabled();
   w.dbg = debug_stamp_buffer(); w.dbg_base = 0;
+  w.out_perm = 0;
   (void)B;
   return true;
 }
@@ -1106,7 +1107,11 @@ static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const W
     if ((reinterpret_cast<uintptr_t>(o.y) & 15) || (o.y_ld & 3) || (o.y_bs & 3)) return false;
     if ((o.flags & F_RES) && ((reinterpret_cast<uintptr_t>(o.res) & 15) || (o.res_ld & 3) || (o.res_bs & 3))) return false;
   }
+  // window-major rows: written by a dilated convolution with a plain epilogue, read by an undilated one; the row must hold whole q blocks
+  if (a.wperm_out && (dil == 1 || a.wperm_out != dil || (o.flags & (F_RES | F_ACC | F_DIV)) || o.y_ld < 4 * dil * ((a.Ncols + 4 * dil - 1) / (4 * dil)))) return false;
+  if (a.wperm_in && (dil != 1 || !(a.wperm_in == 3 || a.wperm_in == 5) || a.x_ld < 4 * a.wperm_in * ((a.Ncols + 4 * a.wperm_in - 1) / (4 * a.wperm_in)))) return false;
   w4 = w;
+  w4.out_perm = a.wperm_out;
   w4.wp = pw.wp4.f();
   static const bool prio = !(getenv("SVOC_W4_PRIO") && atoi(getenv("SVOC_W4_PRIO")) == 0);      // producers at s_setprio 3 (conv_wino4.hip)
   if (prio) w4.flags |= 0x100u;
@@ -1119,6 +1124,7 @@ static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const W
 int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles) {
   WinoArgs w;
   const int WM = wino_wm(pw);
+  if (a.wperm_in || a.wperm_out) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "window-major rows exist in the grouped F(4,3) launches only");
   if (B <= 0 || !wino_args(pw, a, B, dil, WM, w)) return 1;
   const long long total = (long long)w.ntn * w.gy * B;
   if (min_tiles < 0) min_tiles = 2LL * device_cu_count();
@@ -1163,7 +1169,7 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
 // The three chains' last convolutions (k = 3, 7, 11 in chain order, dilation 1), each with its own epilogue flags (residual;
 // + accumulate; + accumulate and divide) into one output: ONE launch of conv_wino4_accum_kernel.  1 = not eligible (the caller
 // runs them one by one).
-int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st) {
+int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st, bool query) {
   static const bool on = !(getenv("SVOC_W4_ACCUM") && atoi(getenv("SVOC_W4_ACCUM")) == 0);
   if (!on || B <= 0 || !pws[0] || !pws[1] || !pws[2] || pws[0]->K != 3 || pws[1]->K != 7 || pws[2]->K != 11) return 1;
   WinoGroup g4{};
@@ -1182,6 +1188,9 @@ int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, in
     exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K);
   }
   if (total * 3 / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
+  const int in_perm = as[0].wperm_in;
+  if (as[1].wperm_in != in_perm || as[2].wperm_in != in_perm) return 1;
+  if (query) return 0;
   stats_add_conv(flops, 3, exec4);
   int prof_idx = -1;
   if (prof_enabled()) {
@@ -1189,14 +1198,14 @@ int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, in
     snprintf(d, sizeof(d), "wino4A Ci%-4d Co%-4d k3+7+11 accumulate N%-7d B%-3d", pws[0]->Cin, pws[0]->Cout, as[0].Ncols, B);
     prof_idx = prof_begin(st, d, flops);
   }
-  const int rc = wino4_launch_accum(g4, wino4_nc(*pws[0]), total, st);
+  const int rc = wino4_launch_accum(g4, wino4_nc(*pws[0]), in_perm, total, st);
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;
 }
 
-int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st) {
+int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st, bool query) {
   if (n < 2 || n > 3 || B <= 0) return 1;
   WinoGroup g{}, g4{};
   long long total = 0, total4 = 0;
@@ -1223,6 +1232,10 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   }
   if (!f4 && pws[0]->mtiles < 2) return 1;                  // C = 32 exists in F(4,3) form only
   if ((f4 ? total4 : total) / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
+  const int in_perm = as[0].wperm_in, out_perm = as[0].wperm_out;
+  for (int i = 1; i < n; ++i) if (as[i].wperm_in != in_perm || as[i].wperm_out != out_perm) return 1;
+  if (query) return f4 ? 0 : 1;
+  if ((in_perm || out_perm) && !f4) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "window-major rows exist in the grouped F(4,3) launches only");
   for (int i = n; i < 3; ++i) { g.end[i] = 0x7fffffff; g.k[i] = 3; }
   stats_add_conv(flops, n, f4 ? exec4 : exec_flops);
   int prof_idx = -1;
@@ -1233,7 +1246,7 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
-  if (f4) rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), total4, st);
+  if (f4) rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), in_perm, out_perm, total4, st);
   else if (wino_ws_on() && WM == 4 && dil <= 3 && n == 3 && pws[0]->K == 11 && pws[1]->K == 7 && pws[2]->K == 3 && (pws[1]->nchunks & 1) == 0)
     rc = dil == 1 ? wino_ws_launch_group<1>(g, total, st) : wino_ws_launch_group<3>(g, total, st);
   else if (WM == 4) rc = dil == 1 ? wino_launch_group<1, 4>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 4>(g, total, lds, st) : wino_launch_group<5, 4>(g, total, lds, st));

@@ -45,8 +45,9 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // NRT = 1 (round 4: C = 32, the last MRF stage): 1 x 4 consumers, 32 rows x 128 windows = 512 outputs per workgroup tile; one row
 // tile feeds on planes four column tiles wide, so a stage is 16 channels (k = 3: k-groups {0,1} / {2,3}) or 8 channels (k = 7 / 11:
 // one k-group of every slot, four stages per weight chunk) - 48 / 64 / 104 MFMAs per stage and consumer.
-template <int K, int D, int NRT = 4>
+template <int K, int D, int NRT = 4, int PERM = 0>
 struct W4Geo {
+  static_assert(PERM == 0 || D == 1, "a window-major input belongs to an undilated convolution (the c2 behind a dilated c1)");
   static constexpr int NCT = 4 / NRT;                     // column tiles (of 32 windows) per workgroup
   static constexpr int KS = NRT == 1 ? (K == 3 ? 16 : 8) : (NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32));   // channels per stage
   static constexpr int CPS = KS >= KC ? KS / KC : 1;      // weight chunks per stage
@@ -80,7 +81,14 @@ struct W4Geo {
   static constexpr int NACC = ND > 0 ? 8 : 6;
   static constexpr int PLANE = KS * PQ;
   static constexpr int PLF = NPL * PLANE;                 // floats per plane set
-  static constexpr int RAW_FLOATS = KS * RAW;
+  // PERM = P > 0 (round 4): the INPUT rows are in the window-major order a dilation-P convolution's epilogue writes with 16-byte
+  // stores (P[4 w + r] = y[4 P b + ph + r P], w = P b + ph): the producers load whole q blocks and scatter each group's four samples
+  // P columns apart into the raw tile, whose rows get slack on both sides for the columns of those blocks outside [xs, xs + RAW)
+  static constexpr int PORG = PERM > 0 ? 4 * PERM : 0;                           // slack ahead of column xs
+  static constexpr int RAWS = PERM > 0 ? ((RAW + 12 * PERM + 3) & ~3) : RAW;     // raw row stride
+  static constexpr int PNBLK = PERM > 0 ? (RAW + 4 * PERM - 2) / (4 * PERM) + 1 : 0;   // q blocks that a RAW-wide range can touch
+  static constexpr int PNG = PERM * PNBLK;                                       // 16-byte groups loaded per row and stage
+  static constexpr int RAW_FLOATS = KS * RAWS;
   // plane sets: two (producers one stage ahead); three where they fit (NRT = 1, k = 7 / 11: the producers run two stages ahead, so
   // that they work through the consumers' epilogue and a late stage does not stall the streams)
   static constexpr int NPS = (NRT == 1 && (RAW_FLOATS + 3 * PLF) * 4 <= 160 * 1024) ? 3 : 2;
@@ -96,9 +104,14 @@ struct W4Geo {
   static constexpr int acc(int t) { return t < NGS ? (t / KGS) % 6 : (tr(t) == 0 ? 0 : (tr(t) == 3 ? 5 : 5 + tr(t))); }
 };
 
-template <int K, int D, int NRT = 4, bool DBG = false>
+// PERM_: D = 1: the input rows are window-major for dilation PERM_ (W4Geo::PERM); D > 1: nonzero = the OUTPUT rows are written
+// window-major (compile-time: as a run-time branch the two epilogues together cost the dilated kernels ~100 spilled registers)
+template <int K, int D, int NRT = 4, bool DBG = false, int PERM_ = 0>
 __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
-  using Geo = W4Geo<K, D, NRT>;
+  constexpr int PERM = D == 1 ? PERM_ : 0;
+  constexpr bool OPERM = D > 1 && PERM_ != 0;
+  using Geo = W4Geo<K, D, NRT, PERM>;
+  constexpr int RAWS = Geo::RAWS, PORG = Geo::PORG;
   constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQ = Geo::PQ, RAW = Geo::RAW, WSLOTS = Geo::WSLOTS;
   constexpr int NWT = Geo::NWT, NCT = Geo::NCT, XOFF = Geo::XOFF, NE = Geo::NE, LEAD = Geo::LEAD, PLANE = Geo::PLANE, PLF = Geo::PLF;
   constexpr int NSTEP = Geo::NSTEP, NACC = Geo::NACC, CPS = Geo::CPS, KS = Geo::KS, RPW = KS / 4, HALVES = Geo::HALVES, KGS = Geo::KGS;
@@ -157,8 +170,26 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       const int it = min(lane + 64 * u, NGW - 1);
       const int row = RPW * pw_ + it / R4, g4 = it % R4;
       goff[u] = (unsigned)(row * p.x_ld + 4 * g4) * 4u;
-      rdst[u] = raw + row * RAW + 4 * g4;
+      rdst[u] = raw + row * RAWS + PORG + 4 * g4;
     }
+    // window-major input: group g of a row = window P b_first + g of the source row, scattered to columns 4 P (g / P) + g % P + r P
+    constexpr int NGWP = PERM > 0 ? RPW * Geo::PNG : 1, SPWP = PERM > 0 ? (NGWP + 63) / 64 : 1;
+    unsigned pgoff[SPWP];
+    float* pdst[SPWP];
+    int pgb[SPWP];                                         // edge tiles: block of the group relative to the first loaded one | its phase << 16
+    if constexpr (PERM > 0) {
+#pragma unroll
+      for (int u = 0; u < SPWP; ++u) {
+        const int it = min(lane + 64 * u, NGWP - 1);
+        const int row = RPW * pw_ + it / Geo::PNG, g = it % Geo::PNG;
+        pgoff[u] = (unsigned)(row * p.x_ld + 4 * g) * 4u;
+        pdst[u] = raw + row * RAWS + PORG + 4 * PERM * (g / PERM) + g % PERM;
+        pgb[u] = (g / PERM) | ((g % PERM) << 16) | (row << 20);
+      }
+    }
+    const int pnblk_row = PERM > 0 ? (L + 4 * PERM - 1) / (4 * PERM) : 0;      // q blocks of a row
+    // first q block a tile loads: the one that holds column xs (xs >= -4 PERM: the left halo is at most 8 columns)
+    auto pfirst = [&](int xs_) -> int { return (xs_ + 4 * PERM) / (4 * PERM) - 1; };
     const float* tsrc[TPW];                                // D = 1: the item's samples; D > 1: the item's raw row (the column follows the tile)
     int tdst[TPW];                                         // float offset of the item's entry inside plane 0 of a set
     int tent[TPW];                                         // D > 1: the item's entry index e
@@ -168,7 +199,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       const int it = min(lane + 64 * u, NIW - 1);
       const int row = RPW * pw_ + it / IPR, e = it % IPR;
       // D = 1: the sixteen-byte group that holds d1..d4 (LEAD = 3) or d0..d2 | d3..d5 (LEAD = 1) of the window starts at 4 e (+ 4)
-      tsrc[u] = D == 1 ? raw + row * RAW + 4 * e : raw + row * RAW;
+      tsrc[u] = D == 1 ? raw + row * RAWS + PORG + 4 * e : raw + row * RAWS;
       tdst[u] = row * PQ + e;
       tent[u] = e; toff[u] = 0;
     }
@@ -184,11 +215,24 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
         }
       }
     };
-    float4 v[SPW];
+    float4 v[PERM > 0 ? (SPWP > SPW ? SPWP : SPW) : SPW];
     int w0 = 0, bz = 0, by = 0, xs0 = 0, ph0 = 0, lead0 = 0;
     auto issue = [&](const char* xb_, int xs_, bool interior_, int ch) {
       const char* cb = xb_ + (long long)ch * KS * ldb;
-      if (interior_) {
+      if constexpr (PERM > 0) {
+        if (interior_) {                                   // whole q blocks from the one that holds column xs
+          const char* ct = cb + (long long)(xs_ / (4 * PERM)) * (16 * PERM);
+#pragma unroll
+          for (int u = 0; u < SPWP; ++u) v[u] = *reinterpret_cast<const float4*>(ct + pgoff[u]);
+        } else {                                           // edge tile: the same groups from blocks clamped into the row (zeroed by publish)
+          const int bf = pfirst(xs_);
+#pragma unroll
+          for (int u = 0; u < SPWP; ++u) {
+            const int bb = min(max(bf + (pgb[u] & 0xffff), 0), pnblk_row - 1), ph_ = (pgb[u] >> 16) & 15, row = pgb[u] >> 20;
+            v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)(PERM * bb + ph_) * 16);
+          }
+        }
+      } else if (interior_) {
         const char* ct = cb + (long long)xs_ * 4;
 #pragma unroll
         for (int u = 0; u < SPW; ++u) v[u] = *reinterpret_cast<const float4*>(ct + goff[u]);
@@ -216,7 +260,39 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       const bool interior = xs_start >= 0 && xs_start + RAW <= L;
       const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
       // ---- publish own rows (lrelu, zero padding on edge tiles)
-      if (interior) {
+      if constexpr (PERM > 0) {
+        if (interior) {
+          const int delta = (xs_start / (4 * PERM)) * (4 * PERM) - xs_start;      // column of the first loaded block relative to xs
+#pragma unroll
+          for (int u = 0; u < SPWP; ++u) {
+            if (64 * (u + 1) <= NGWP || lane < NGWP - 64 * u) {
+              float4 q = v[u];
+              wino_lrelu4(q, slope);
+              float* d = pdst[u] + delta;
+              d[0] = q.x; d[PERM] = q.y; d[2 * PERM] = q.z; d[3 * PERM] = q.w;
+            }
+          }
+        } else {                                           // edge tile: groups of blocks outside the row, and samples beyond L, are zero
+          const int bf = pfirst(xs_start);
+          const int delta = bf * (4 * PERM) - xs_start;
+#pragma unroll
+          for (int u = 0; u < SPWP; ++u) {
+            if (64 * (u + 1) <= NGWP || lane < NGWP - 64 * u) {
+              const int bb = bf + (pgb[u] & 0xffff), ph_ = (pgb[u] >> 16) & 15;
+              const int n0 = 4 * PERM * bb + ph_;          // natural column of the group's first sample
+              const bool inrow = bb >= 0 && bb < pnblk_row;
+              float4 q = v[u];
+              q.x = (inrow && n0 < L) ? q.x : 0.f;
+              q.y = (inrow && n0 + PERM < L) ? q.y : 0.f;
+              q.z = (inrow && n0 + 2 * PERM < L) ? q.z : 0.f;
+              q.w = (inrow && n0 + 3 * PERM < L) ? q.w : 0.f;
+              wino_lrelu4(q, slope);
+              float* d = pdst[u] + delta;
+              d[0] = q.x; d[PERM] = q.y; d[2 * PERM] = q.z; d[3 * PERM] = q.w;
+            }
+          }
+        }
+      } else if (interior) {
 #pragma unroll
         for (int u = 0; u < SPW; ++u) {
           if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
@@ -505,7 +581,23 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
       };
-      if (res_only) {
+      if constexpr (OPERM) {
+        // window-major store (round 4): the lane's four outputs n, n + D, n + 2D, n + 3D go to P[4 w .. 4 w + 3] of the row, w = w0 + uu:
+        // one 16-byte store per row instead of four scattered dwords; the undilated convolution that follows reads through the
+        // same map (W4Geo::PERM).  Plain epilogue only (a c1 has no residual): host.
+        char* const yp = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld) + (size_t)(w0 + uu) * 16;
+        auto quarter = [&](auto q_c) {
+          constexpr int Q = decltype(q_c)::value;
+          float4 vo[4];
+          ytrans(q_c, vo);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(yp + (size_t)(8 * Q + 4 * hi + r) * ylb) = vo[r];
+        };
+        quarter(std::integral_constant<int, 0>{});
+        quarter(std::integral_constant<int, 1>{});
+        quarter(std::integral_constant<int, 2>{});
+        quarter(std::integral_constant<int, 3>{});
+      } else if (res_only) {
         {
           auto quarter = [&](auto q_c, const float4* rv) {
             constexpr int Q = decltype(q_c)::value;
@@ -589,22 +681,23 @@ template <int K, int D, int NRT, bool DBG>
 __global__ void __launch_bounds__(512, 2) conv_wino4_kernel(const WinoArgs p, const int total) {
   wino4_problem<K, D, NRT, DBG>(p, blockIdx.x, total, 0, gridDim.x);
 }
-template <int K, int D, int NRT>
+template <int K, int D, int NRT, int PERM = 0>
 __device__ __forceinline__ void wino4_member(const WinoArgs& p, const int first, const int vend, const int b, const int G_) {
   if (vend <= first) return;
   int v0 = b - first % G_;
   if (v0 < 0) v0 += G_;
-  wino4_problem<K, D, NRT>(p, v0 + first, vend, first, G_);
+  wino4_problem<K, D, NRT, false, PERM>(p, v0 + first, vend, first, G_);
 }
-// the MRF chains' three convolutions of one step (k = 11 / 7 / 3) back to back in one persistent launch
-template <int D, int NRT>
+// the MRF chains' three convolutions of one step (k = 11 / 7 / 3) back to back in one persistent launch; PERM: their inputs are
+// in the window-major order of a dilation-PERM predecessor (D = 1 only)
+template <int D, int NRT, int PERM = 0>
 __global__ void __launch_bounds__(512, 2) conv_wino4_group_kernel(const WinoGroup g) {
   const int b = blockIdx.x, G_ = gridDim.x;
-  wino4_member<11, D, NRT>(g.a[0], 0, g.end[0], b, G_);
+  wino4_member<11, D, NRT, PERM>(g.a[0], 0, g.end[0], b, G_);
   __syncthreads();
-  wino4_member<7, D, NRT>(g.a[1], g.end[0], g.end[1], b, G_);
+  wino4_member<7, D, NRT, PERM>(g.a[1], g.end[0], g.end[1], b, G_);
   __syncthreads();
-  wino4_member<3, D, NRT>(g.a[2], g.end[1], g.end[2], b, G_);
+  wino4_member<3, D, NRT, PERM>(g.a[2], g.end[1], g.end[2], b, G_);
 }
 
 // The last convolutions of the three MRF chains accumulate into ONE tensor in chain order, xs = rb_0 + rb_1 + rb_2, x = xs / 3
@@ -613,14 +706,14 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_group_kernel(const WinoGrou
 // accumulates into was written by that very wave (same lane, same registers' worth of addresses) one member earlier: program
 // order makes the read-modify-write safe without any inter-workgroup synchronisation, and the summation order of the reference
 // is kept bit for bit.
-template <int NRT>
+template <int NRT, int PERM = 0>
 __global__ void __launch_bounds__(512, 2) conv_wino4_accum_kernel(const WinoGroup g) {
   const int b = blockIdx.x, G_ = gridDim.x, total = g.end[0];
-  wino4_problem<3, 1, NRT>(g.a[0], b, total, 0, G_);
+  wino4_problem<3, 1, NRT, false, PERM>(g.a[0], b, total, 0, G_);
   __syncthreads();
-  wino4_problem<7, 1, NRT>(g.a[1], b, total, 0, G_);
+  wino4_problem<7, 1, NRT, false, PERM>(g.a[1], b, total, 0, G_);
   __syncthreads();
-  wino4_problem<11, 1, NRT>(g.a[2], b, total, 0, G_);
+  wino4_problem<11, 1, NRT, false, PERM>(g.a[2], b, total, 0, G_);
 }
 
 // ------------------------------------------------------------------ weight transform + packing
@@ -683,8 +776,8 @@ bool wino4_c32_enabled() {
   static const bool on = wino4_enabled() && !(getenv("SVOC_W4_C32") && atoi(getenv("SVOC_W4_C32")) == 0);
   return on;
 }
-template <int K, int D, int NRT>
-static size_t wino4_lds() { return (size_t)W4Geo<K, D, NRT>::LDS_BYTES; }
+template <int K, int D, int NRT, int PERM = 0>
+static size_t wino4_lds() { return (size_t)W4Geo<K, D, NRT, D == 1 ? PERM : 0>::LDS_BYTES; }
 // column tiles per row: a tile is 32 * (4 / NRT) consecutive windows; a row of L outputs has D * ceil(L / 4D) windows
 int wino4_ntn(int L, int D, int NRT) {
   const long long nw = (long long)D * ((L + 4 * D - 1) / (4 * D));
@@ -717,32 +810,41 @@ int wino4_launch(const WinoArgs& w, int K, int D, int NRT, long long total, hipS
 #undef SVOC_W4
   return rc;
 }
-template <int D, int NRT>
+template <int D, int NRT, int PERM = 0>
 static int wino4_launch_group_d(const WinoGroup& g, long long total, hipStream_t st) {
-  auto kern = conv_wino4_group_kernel<D, NRT>;
+  auto kern = conv_wino4_group_kernel<D, NRT, PERM>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  const size_t l11 = wino4_lds<11, D, NRT>(), l7 = wino4_lds<7, D, NRT>(), l3 = wino4_lds<3, D, NRT>();
+  const size_t l11 = wino4_lds<11, D, NRT, PERM>(), l7 = wino4_lds<7, D, NRT, PERM>(), l3 = wino4_lds<3, D, NRT, PERM>();
   const size_t lds = std::max(l11, std::max(l7, l3));
   hipLaunchKernelGGL(kern, dim3(wino4_grid(total)), dim3(512), lds, st, g);
   return SVOC_OK;
 }
-template <int NRT>
+template <int NRT, int PERM = 0>
 static int wino4_launch_accum_n(const WinoGroup& g, long long total, hipStream_t st) {
-  auto kern = conv_wino4_accum_kernel<NRT>;
+  auto kern = conv_wino4_accum_kernel<NRT, PERM>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  const size_t l11 = wino4_lds<11, 1, NRT>(), l7 = wino4_lds<7, 1, NRT>(), l3 = wino4_lds<3, 1, NRT>();
+  const size_t l11 = wino4_lds<11, 1, NRT, PERM>(), l7 = wino4_lds<7, 1, NRT, PERM>(), l3 = wino4_lds<3, 1, NRT, PERM>();
   const size_t lds = std::max(l11, std::max(l7, l3));
   hipLaunchKernelGGL(kern, dim3(wino4_grid(total)), dim3(512), lds, st, g);
   return SVOC_OK;
 }
-// members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each)
-int wino4_launch_accum(const WinoGroup& g, int NRT, long long total, hipStream_t st) {
-  return NRT == 4 ? wino4_launch_accum_n<4>(g, total, st) : (NRT == 2 ? wino4_launch_accum_n<2>(g, total, st) : wino4_launch_accum_n<1>(g, total, st));
+// members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each); in_perm: 0, or the dilation (3 / 5) of the
+// convolutions that wrote the members' inputs window-major
+int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, long long total, hipStream_t st) {
+#define SVOC_W4A(P) (NRT == 4 ? wino4_launch_accum_n<4, P>(g, total, st) : (NRT == 2 ? wino4_launch_accum_n<2, P>(g, total, st) : wino4_launch_accum_n<1, P>(g, total, st)))
+  if (in_perm == 5) return SVOC_W4A(5);
+  if (in_perm == 3) return SVOC_W4A(3);
+  return SVOC_W4A(0);
+#undef SVOC_W4A
 }
-int wino4_launch_group(const WinoGroup& g, int D, int NRT, long long total, hipStream_t st) {
-  if (NRT == 4) return D == 1 ? wino4_launch_group_d<1, 4>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 4>(g, total, st) : wino4_launch_group_d<5, 4>(g, total, st));
-  if (NRT == 2) return D == 1 ? wino4_launch_group_d<1, 2>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 2>(g, total, st) : wino4_launch_group_d<5, 2>(g, total, st));
-  return D == 1 ? wino4_launch_group_d<1, 1>(g, total, st) : (D == 3 ? wino4_launch_group_d<3, 1>(g, total, st) : wino4_launch_group_d<5, 1>(g, total, st));
+// in_perm (D = 1): 0, or the dilation of the convolutions that wrote the members' inputs window-major; out_perm (D > 1): nonzero =
+// the members write window-major
+int wino4_launch_group(const WinoGroup& g, int D, int NRT, int in_perm, int out_perm, long long total, hipStream_t st) {
+#define SVOC_W4G(DD, P) (NRT == 4 ? wino4_launch_group_d<DD, 4, P>(g, total, st) : (NRT == 2 ? wino4_launch_group_d<DD, 2, P>(g, total, st) : wino4_launch_group_d<DD, 1, P>(g, total, st)))
+  if (D == 1) return in_perm == 5 ? SVOC_W4G(1, 5) : (in_perm == 3 ? SVOC_W4G(1, 3) : SVOC_W4G(1, 0));
+  if (D == 3) return out_perm ? SVOC_W4G(3, 3) : SVOC_W4G(3, 0);
+  return out_perm ? SVOC_W4G(5, 5) : SVOC_W4G(5, 0);
+#undef SVOC_W4G
 }
 
 }  // namespace svoc

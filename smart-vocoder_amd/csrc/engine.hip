@@ -28,7 +28,8 @@ static void set_res(EpiOut& o, const float* r, long long bs, int ld) { o.res = r
 static inline int pad4(int n) { return round_up(n, 4); }
 // Row stride of the decoder's stage tensors (padding it by a few cache lines so that the 32 channel rows of a tile
 // do not map to the same HBM channels was measured neutral in round 1 and removed).
-static inline int stage_ld(int n) { return round_up(n, 4); }
+// (+ 20 floats since round 4: a row in window-major order holds whole q blocks of 4 x dilation samples, up to 4 * 5 - 1 more than L.)
+static inline int stage_ld(int n) { return round_up(n, 4) + 20; }
 
 // =================================================================== WN (modules.py:111-185)
 struct WNStack {
@@ -499,7 +500,10 @@ struct Generator {
         if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
         return SVOC_OK;
       };
-      bool all_w = true;
+      bool all_w = true, all_w2 = true;
+      const PackedConv* pcs2[3];
+      const PackedWino* pws2[3];
+      ConvArgs as2[3];
       for (int q = 0; q < nk; ++q) {
         const int j = order[q];
         float* A = bufs[3 + 2 * j];
@@ -515,22 +519,50 @@ struct Generator {
         pcs[q] = rbs[stage * nk + j]->c1[it].get();
         pws[q] = rbs[stage * nk + j]->w1[it].get();
         all_w = all_w && pws[q] != nullptr;
+        ConvArgs a2 = mk_args();
+        set_in(a2, scratch[q], bs, ld, L);
+        a2.pre_slope = 0.1f;
+        a2.Ncols = L;
+        set_out(a2.out[0], nxt[q], bs, ld, C, F_RES);
+        set_res(a2.out[0], cur[j], bs, ld);
+        as2[q] = a2;
+        pcs2[q] = rbs[stage * nk + j]->c2[it].get();
+        pws2[q] = rbs[stage * nk + j]->w2[it].get();
+        all_w2 = all_w2 && pws2[q] != nullptr;
+      }
+      // xs = sum_j ResBlock_j(x) / n, accumulated in chain order (models.py:149-155): the last step's c2 members in chain order
+      const PackedWino* apw[3];
+      ConvArgs aas[3];
+      if (last && nk == 3) {
+        for (int j = 0; j < 3; ++j) {
+          int q = 0;
+          while (order[q] != j) ++q;
+          ConvArgs a = as2[q];
+          unsigned fl = F_RES;
+          if (j > 0) fl |= F_ACC;
+          if (j == nk - 1) fl |= F_DIV;
+          set_out(a.out[0], XS, bs, ld, C, fl);
+          a.out[0].div = (float)nk;
+          set_res(a.out[0], cur[j], bs, ld);
+          aas[j] = a; apw[j] = pws2[q];
+        }
+      }
+      // A dilated c1 writes its rows window-major (one 16-byte store per lane and row instead of four scattered dwords) and the c2
+      // behind it reads through the same map - when both launches are the grouped F(4,3) kernels (SVOC_W4_PERM=0: natural order)
+      {
+        static const bool perm_on = !(getenv("SVOC_W4_PERM") && atoi(getenv("SVOC_W4_PERM")) == 0);
+        const int dil = pcs[0]->dil;
+        if (perm_on && dil > 1 && all_w && all_w2 && (!last || nk == 3)) {
+          ConvArgs t1[3], t2[3];
+          for (int q = 0; q < nk; ++q) { t1[q] = as[q]; t1[q].wperm_out = dil; t2[q] = (last && nk == 3) ? aas[q] : as2[q]; t2[q].wperm_in = dil; }
+          const bool ok = launch_conv_wino_group(pws, t1, nk, B, dil, st, true) == 0 &&
+                          ((last && nk == 3) ? launch_conv_wino4_accum(apw, t2, B, st, true) == 0 : launch_conv_wino_group(pws2, t2, nk, B, 1, st, true) == 0);
+          if (ok) for (int q = 0; q < nk; ++q) { as[q].wperm_out = dil; as2[q].wperm_in = dil; if (last && nk == 3) aas[q].wperm_in = dil; }
+        }
       }
       SVOC_TRY(launch3(all_w, pcs[0]->dil));
-      all_w = true;
-      for (int q = 0; q < nk; ++q) {
-        const int j = order[q];
-        ConvArgs a = mk_args();
-        set_in(a, scratch[q], bs, ld, L);
-        a.pre_slope = 0.1f;
-        a.Ncols = L;
-        set_out(a.out[0], nxt[q], bs, ld, C, F_RES);
-        set_res(a.out[0], cur[j], bs, ld);
-        as[q] = a;
-        pcs[q] = rbs[stage * nk + j]->c2[it].get();
-        pws[q] = rbs[stage * nk + j]->w2[it].get();
-        all_w = all_w && pws[q] != nullptr;
-      }
+      for (int q = 0; q < nk; ++q) { as[q] = as2[q]; pcs[q] = pcs2[q]; pws[q] = pws2[q]; }
+      all_w = all_w2;
       if (!last) {
         SVOC_TRY(launch3(all_w, 1));
         for (int q = 0; q < nk; ++q) cur[order[q]] = nxt[q];
@@ -539,23 +571,10 @@ struct Generator {
         // F(4,3) kernel's (conv_wino4_accum_kernel), else one by one
         bool done = false;
         if (nk == 3) {
-          const PackedWino* apw[3];
-          ConvArgs aas[3];
-          for (int j = 0; j < 3; ++j) {
-            int q = 0;
-            while (order[q] != j) ++q;
-            ConvArgs a = as[q];
-            unsigned fl = F_RES;
-            if (j > 0) fl |= F_ACC;
-            if (j == nk - 1) fl |= F_DIV;
-            set_out(a.out[0], XS, bs, ld, C, fl);
-            a.out[0].div = (float)nk;
-            set_res(a.out[0], cur[j], bs, ld);
-            aas[j] = a; apw[j] = pws[q];
-          }
           const int ra = launch_conv_wino4_accum(apw, aas, B, st);
           if (ra < 0) return ra;
           done = ra == 0;
+          if (!done && aas[0].wperm_in) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "MRF: the accumulate launch refused window-major inputs it had accepted");
         }
         for (int j = 0; j < nk && !done; ++j) {
           int q = 0;

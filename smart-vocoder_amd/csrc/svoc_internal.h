@@ -98,6 +98,9 @@ struct ConvArgs {
   float* y2; float* y3;                              // EPI_PROJ: logs_p, z_p (same strides as out[0])
   float* logdet;                                     // EPI_CPL_FULL_FWD
   float mag_eps; float log_clamp;                    // EPI_MAG / F_LOGCLAMP
+  // F(4,3) grouped launches only (conv_wino4.hip, round 4): a dilated convolution writes its rows window-major (wperm_out = its
+  // dilation) with 16-byte stores and the undilated convolution behind it reads them through the same map (wperm_in)
+  int wperm_out; int wperm_in;
 };
 
 // One convolution layer repacked for the MFMA kernel.
@@ -182,8 +185,9 @@ int pack_wino_named(PackedWino& pw, int Cin, int Cout, int K, const TensorTable&
 // `a`: x / pre_slope / Ncols / out[0] as for launch_conv (plain epilogue, flags within F_RES | F_ACC | F_DIV); 1 = not
 // eligible (alignment, odd length, masks, or fewer than min_tiles workgroups; min_tiles < 0: twice the CU count)
 int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hipStream_t st, long long min_tiles = -1);
-int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st);
-int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st);   // chain order k = 3, 7, 11
+// query = true: launches nothing and returns 0 iff the F(4,3) kernel would run (the only form that honours wperm_in / wperm_out)
+int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st, bool query = false);
+int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st, bool query = false);   // chain order k = 3, 7, 11
 
 // convt_wino.hip: Winograd F(4,2) form of the polyphase transposed convolution (upsamplers k = 2 s: s = 8 or 2)
 struct PackedCtWino {

@@ -18,6 +18,7 @@ struct WinoArgs {
   unsigned flags; float div;                                        // F_RES | F_ACC | F_DIV
   int ntn; int gy; int xcd;                                         // column tiles per row, row blocks, XCD-aware order
   long long* dbg; int dbg_base;                                     // optional [workgroups][16] stamps (svoc_debug_set_stamp_buffer)
+  int out_perm;                                                     // F(4,3), dilation > 1: write rows window-major (conv_wino4.hip)
 };
 struct WinoGroup { WinoArgs a[3]; int end[3]; int k[3]; };
 

@@ -755,8 +755,10 @@ __global__ void __launch_bounds__(768) wn_layer_f25_kernel(const WnArgs p) {
   auto dump = [&]() {
     if (p.dbg && tid == 0) {
       long long* d = p.dbg + 8 * (long long)(blockIdx.x + gridDim.x * blockIdx.z);
-      d[0] = ts[0]; d[1] = ts[2]; d[2] = ts[3]; d[3] = ts[4]; d[4] = ts[5]; d[5] = (long long)__builtin_readcyclecounter();
-      d[6] = (long long)__builtin_readcyclecounter(); d[7] = ((ts[7] - ts[3]) << 42) | ((ts[8] - ts[7]) << 21) | (ts[9] - ts[8]);
+      // [0..6]: start | x tile staged | planes written | phase A stream done | acts complete (phase B starts) | phase B done | end;
+      // [7]: output transform + partial-sum writes, barrier, gate (21 bits each); a negative marker tells the tool which kernel stamped
+      d[0] = ts[0]; d[1] = ts[1]; d[2] = ts[2]; d[3] = ts[3]; d[4] = ts[4]; d[5] = ts[5];
+      d[6] = -(long long)__builtin_readcyclecounter(); d[7] = ((ts[7] - ts[3]) << 42) | ((ts[8] - ts[7]) << 21) | (ts[9] - ts[8]);
     }
   };
   // ---- epilogue (modules.py:168-175)

@@ -32,32 +32,65 @@ def _wire_device(device, group=None):
     return torch.device("cpu") if dist.get_backend(group) == "gloo" else device
 
 
+def _pack_layout(shapes_tail, dtypes, nmax):
+    """Byte layout of one rank's packed chunk: one region per tensor, [nmax, *tail] each, widest element type first (so every
+    region starts aligned for its type); the chunk is padded to a multiple of 16 bytes.  Returns ([(offset, nbytes)] in the
+    callers' tensor order, chunk_bytes)."""
+    per = [int(torch.tensor([], dtype=dt).element_size()) for dt in dtypes]
+    nb = [nmax * p * int(torch.Size(tail).numel()) for p, tail in zip(per, shapes_tail)]
+    order = sorted(range(len(dtypes)), key=lambda i: -per[i])
+    offs, off = [0] * len(dtypes), 0
+    for i in order:
+        offs[i] = off
+        off += (nb[i] + 15) // 16 * 16
+    return list(zip(offs, nb)), max(off, 16)
+
+
+def _region(buf2d, off, nbytes, dtype, nmax, tail):
+    """View of bytes [off, off + nbytes) of every row of a [rows, chunk_bytes] uint8 buffer as [rows, nmax, *tail] of `dtype`."""
+    return buf2d[:, off:off + nbytes].view(dtype).view((buf2d.shape[0], nmax) + tuple(tail))
+
+
 def scatter_batch(tensors, shapes_tail, dtypes, B, src=0, device=None, group=None):
-    """Scatter dim-0 chunks of each tensor from `src`.  `tensors` is the list of full tensors on `src`
-    (ignored elsewhere); shapes_tail/dtypes describe them on every rank.  Returns the local chunks on `device`."""
+    """Scatter dim-0 chunks of each tensor from `src` in ONE collective: the source packs (lengths | mel | eps ...) of every rank
+    into one byte buffer [world, chunk_bytes] - one strided device copy per tensor, no zero filling, no per-rank loop when B
+    divides evenly - and scatters its rows (views, no further copies).  `tensors` is the list of full tensors on `src` (ignored
+    elsewhere); shapes_tail/dtypes describe them on every rank.  Returns the local chunks on `device` (views of the receive
+    buffer)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bounds = shard_bounds(B, world)
     nloc = bounds[rank][1] - bounds[rank][0]
     nmax = max(b - a for a, b in bounds)
     wire = _wire_device(device, group)
+    layout, chunk = _pack_layout(shapes_tail, dtypes, nmax)
+    recv = torch.empty(chunk, dtype=torch.uint8, device=wire)
+    rows = None
+    if rank == src:
+        send = torch.empty((world, chunk), dtype=torch.uint8, device=wire)
+        big = B - world * (nmax - 1) if B % world else world            # ranks that hold nmax utterances (the first B % world)
+        for (off, nb), tail, dt, full in zip(layout, shapes_tail, dtypes, tensors):
+            full = full.to(device=wire, dtype=dt)
+            dst = _region(send, off, nb, dt, nmax, tail)
+            if big == world:
+                dst.copy_(full.reshape((world, nmax) + tuple(tail)))
+            else:                                                        # uneven split: two block copies; the spare slots stay unset
+                dst[:big].copy_(full[: big * nmax].reshape((big, nmax) + tuple(tail)))
+                if nmax > 1:
+                    dst[big:, : nmax - 1].copy_(full[big * nmax:].reshape((world - big, nmax - 1) + tuple(tail)))
+        rows = list(send.unbind(0))
+    dist.scatter(recv, rows, src=src, group=group)
     outs = []
-    for i, (tail, dt) in enumerate(zip(shapes_tail, dtypes)):
-        recv = torch.empty((nmax,) + tuple(tail), dtype=dt, device=wire)
-        chunks = None
-        if rank == src:
-            full = tensors[i].to(wire)
-            chunks = []
-            for a, b in bounds:
-                c = torch.zeros((nmax,) + tuple(tail), dtype=dt, device=wire)   # equal-size chunks (scatter needs them)
-                c[: b - a] = full[a:b]
-                chunks.append(c)
-        dist.scatter(recv, chunks, src=src, group=group)
-        outs.append(recv[:nloc].to(device).contiguous())
+    r2 = recv.view(1, chunk)
+    for (off, nb), tail, dt in zip(layout, shapes_tail, dtypes):
+        t = _region(r2, off, nb, dt, nmax, tail)[0, :nloc]
+        outs.append(t if wire == device or device is None else t.to(device))
     return outs
 
 
-def gather_waveforms(o_local, B, dst=0, group=None):
-    """Gather [n_local, 1, L] waveforms to `dst`; returns [B, 1, L] there and None elsewhere."""
+def gather_waveforms(o_local, B, dst=0, group=None, out=None):
+    """Gather [n_local, 1, L] waveforms to `dst`; returns [B, 1, L] there and None elsewhere.  The ranks' chunks land directly in
+    views of ONE receive buffer [world, nmax, 1, L] - `out` when the caller supplies it ([B, 1, L] on the gather device, even
+    split: bench.py preallocates it outside the timed region), else a fresh one - so an even split needs no concatenation."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bounds = shard_bounds(B, world)
     nmax = max(b - a for a, b in bounds)
@@ -66,13 +99,31 @@ def gather_waveforms(o_local, B, dst=0, group=None):
     wire = _wire_device(dev, group)
     send = o_local.to(wire)
     if o_local.shape[0] != nmax:
-        send = torch.zeros((nmax,) + tail, dtype=o_local.dtype, device=wire)
+        send = torch.empty((nmax,) + tail, dtype=o_local.dtype, device=wire)
         send[: o_local.shape[0]] = o_local
-    bufs = [torch.empty((nmax,) + tail, dtype=o_local.dtype, device=wire) for _ in range(world)] if rank == dst else None
-    dist.gather(send.contiguous(), bufs, dst=dst, group=group)
+    even = B == world * nmax
+    buf = views = None
+    used_out = False
+    if rank == dst:
+        if even and out is not None and out.device == wire and out.dtype == o_local.dtype and tuple(out.shape) == (B,) + tail and out.is_contiguous():
+            buf = out.view((world, nmax) + tail)
+            used_out = True
+        else:
+            buf = torch.empty((world, nmax) + tail, dtype=o_local.dtype, device=wire)
+        views = list(buf.unbind(0))
+    dist.gather(send.contiguous(), views, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([bufs[i][: b - a] for i, (a, b) in enumerate(bounds)], 0).to(dev)
+    if even:
+        res = buf.view((B,) + tail)
+    else:
+        big = B - world * (nmax - 1)
+        res = torch.cat([buf[:big].reshape((big * nmax,) + tail), buf[big:, : nmax - 1].reshape(((world - big) * (nmax - 1),) + tail)], 0)
+    res = res if wire == dev else res.to(dev)
+    if out is not None and not used_out and out.device == res.device and out.shape == res.shape:
+        out.copy_(res)
+        return out
+    return res
 
 
 def _now(dev):

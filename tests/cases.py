@@ -294,7 +294,31 @@ def full_model_weights(seed=WEIGHT_SEED, skip_enc_q=True):
         shapes = full_model_shapes()
         if skip_enc_q:
             shapes = {k: v for k, v in shapes.items() if not k.startswith("enc_q.")}
-        _FULL_SD[key] = sw.fill_state_dict(shapes, seed=seed)
+        # The variant suite starts ~25 processes that all need these 142 MB: generated once per box, then read back from /tmp
+        # (file name = digest of the generator's source, the seed and the shape list, so a change of any of them regenerates)
+        import hashlib, tempfile
+        h = hashlib.sha1()
+        h.update(open(sw.__file__, "rb").read())
+        h.update(repr((seed, sorted(shapes.items()))).encode())
+        path = os.path.join(tempfile.gettempdir(), f"svoc_test_weights_{h.hexdigest()[:16]}.npz")
+        sd = None
+        if os.path.exists(path):
+            try:
+                with np.load(path) as z:
+                    sd = {k: z[k] for k in z.files}
+                if set(sd) != set(shapes) or any(tuple(sd[k].shape) != tuple(shapes[k]) for k in shapes):
+                    sd = None
+            except Exception:   # noqa: BLE001 - a torn or foreign file: regenerate
+                sd = None
+        if sd is None:
+            sd = sw.fill_state_dict(shapes, seed=seed)
+            try:
+                tmp = f"{path}.{os.getpid()}.tmp.npz"
+                np.savez(tmp, **sd)
+                os.replace(tmp, path)
+            except Exception:   # noqa: BLE001 - read-only /tmp: every process generates its own
+                pass
+        _FULL_SD[key] = sd
     return _FULL_SD[key]
 
 

@@ -654,6 +654,30 @@ def test_variant_batch_pins_kernel_choice(M, net):
     assert (loose - full[4:6]).abs().max().item() <= BATCH_TOL
 
 
+def test_captured_plans_are_keyed_on_the_variant_batch(M, net):
+    """Kernel variants are frozen into a captured plan, so the plan key carries the effective variant batch: a shard
+    shape whose plan was captured under the default setting must NOT be replayed under variant_batch(n), and the other way
+    round.  No profiler here: every call goes through the plan cache.  2 x 200 frames alone take the short-input variants;
+    pinned to 16 they must reproduce rows of the 16-utterance job bit for bit, also after a loose plan for the same shape
+    exists - and the loose calls must keep their own bits afterwards."""
+    Bn, Tn = 16, 200
+    mel = T(sw.synthetic_mel(78, Bn, Tn)).cuda(); eps = T(sw.synthetic_eps(78, Bn, Tn)).cuda()
+    ln = torch.full((Bn,), Tn, dtype=torch.int64).cuda(); ln[5] = 131
+    ns = 0.4321                                                   # no other test shares these plan keys
+    M.native.profile_enable(True)
+    full = net.infer(mel, ln, noise_scale=ns, eps=eps)[0].clone()
+    loose_direct = net.infer(mel[4:6], ln[4:6], noise_scale=ns, eps=eps[4:6])[0].clone()
+    M.native.profile_enable(False)
+    loose = [net.infer(mel[4:6], ln[4:6], noise_scale=ns, eps=eps[4:6])[0].clone() for _ in range(3)]      # 2nd call captures, 3rd replays
+    assert all(torch.equal(o, loose_direct) for o in loose)
+    with M.native.variant_batch(Bn):
+        pinned = [net.infer(mel[4:6], ln[4:6], noise_scale=ns, eps=eps[4:6])[0].clone() for _ in range(3)]  # its own plan
+    assert all(torch.equal(o, full[4:6]) for o in pinned), "a plan captured under the default variants served a pinned call"
+    again = net.infer(mel[4:6], ln[4:6], noise_scale=ns, eps=eps[4:6])[0]
+    assert torch.equal(again, loose_direct), "a plan captured under a pinned batch served a default call"
+    assert (loose_direct - full[4:6]).abs().max().item() <= BATCH_TOL
+
+
 def test_plan_cache_many_shapes_never_syncs_the_device(M, net):
     """A serving process sees many distinct short lengths.  First sights only bump a counter (no plan, no capture); a
     shape earns a captured plan on its second call; beyond 32 plans the least recently used is retired WITHOUT a device
@@ -784,7 +808,9 @@ def test_c5_full_size(M, net):
     """BASELINE.json configs[4]: 8 x 4096-frame mels (1 M-sample rows, 9.7 GB workspace, 33 k tiles per launch).
     (a) bit-identical between two runs; (b) every checked utterance equals its own B=1 run to fp32 rounding (the WN
     kernel variant depends on B*T); (c) finite, inside tanh's range, right shape; (d) ORACLE: the last 64 frames of two
-    utterances (one ragged) against the CPU oracle run on the last 64+192 frames (receptive field 128 frames)."""
+    utterances (one ragged) against the CPU oracle run on the last 64+192 frames (receptive field 128 frames); (e) ORACLE:
+    64 frames from the MIDDLE of a third utterance (frames 2000..2063: tiles far from both edges, every kernel's interior
+    path) against the oracle run on those frames with 192 frames of real context on either side."""
     Bn, Tn = 8, 4096
     mel = sw.synthetic_mel(1005, Bn, Tn); eps = sw.synthetic_eps(1005, Bn, Tn)
     ln = np.full((Bn,), Tn, dtype=np.int64); ln[2] = 3001
@@ -810,13 +836,23 @@ def test_c5_full_size(M, net):
         err = got - want
         rms, ref = float(np.sqrt((err ** 2).mean())), float(np.sqrt((want ** 2).mean()))
         assert rms <= 1e-3 and rms / ref <= 1e-4, (b, rms, rms / ref)
+    b, f0, nf, ctx = 5, 2000, 64, 192                                              # (e)
+    a, e2 = f0 - ctx, f0 + nf + ctx
+    with torch.no_grad():
+        o_ref, *_ = O.infer(sd, T(mel[b:b + 1, :, a:e2]), torch.tensor([e2 - a]), T(eps[b:b + 1, :, a:e2]), 0.667)
+    got = o1[b, 0, f0 * 256:(f0 + nf) * 256].cpu().numpy()
+    want = o_ref[0, 0, ctx * 256:(ctx + nf) * 256].numpy()
+    err = got - want
+    rms, ref = float(np.sqrt((err ** 2).mean())), float(np.sqrt((want ** 2).mean()))
+    assert rms <= 1e-3 and rms / ref <= 1e-4, ("middle slice", rms, rms / ref)
 
 
 def test_c3_full_size_with_speaker_conditioning(M):
     """BASELINE.json configs[2] (iitp_base_ms, batch 32 x 512): SynthesizerTrn.infer hard-codes g=None (models.py:332), so
     the speaker-conditioned path is exercised where the reference can run it, at module level, at FULL size:
     ResidualCouplingBlock(g) reverse and Generator(g) with g [32,256,1].  Properties: determinism, per-utterance
-    equality with B=1 runs, flow(g) round trip, finiteness; plus one utterance of each module against the oracle."""
+    equality with B=1 runs, flow(g) round trip, finiteness; plus two utterances of flow(g) + Generator(g) (one ragged) and one of
+    WN(g) against the oracle."""
     Bn, Tn = 32, 512
     sd = cases.full_model_weights()
     flow_sd = {k[len("flow."):]: v for k, v in sd.items() if k.startswith("flow.")}
@@ -842,14 +878,15 @@ def test_c3_full_size_with_speaker_conditioning(M):
         ob = dec(z[b:b + 1] * mc[b:b + 1], g=gc[b:b + 1])
         assert (ob[0] - o[b]).abs().max().item() <= BATCH_TOL, b
     sdt = sdT(sd)
+    for b in (4, 31):            # a ragged utterance (300 of 512 frames) and the last, full-length one
+        with torch.no_grad():
+            z_ref = O.flow(sdt, (zp * mask)[b:b + 1], mask[b:b + 1], g[b:b + 1], reverse=True)
+            o_ref = O.generator(sdt, z_ref * mask[b:b + 1], g[b:b + 1])
+        check(f"c3 flow(g) vs oracle, utterance {b}", z[b:b + 1], z_ref.numpy(), 5e-5, 1e-4)
+        err = (o[b:b + 1].cpu() - o_ref).numpy()
+        rms, ref = float(np.sqrt((err ** 2).mean())), float(o_ref.pow(2).mean().sqrt())
+        assert rms <= 1e-3 and rms / ref <= 1e-4, (b, rms, rms / ref)
     b = 4
-    with torch.no_grad():
-        z_ref = O.flow(sdt, (zp * mask)[b:b + 1], mask[b:b + 1], g[b:b + 1], reverse=True)
-        o_ref = O.generator(sdt, z_ref * mask[b:b + 1], g[b:b + 1])
-    check("c3 flow(g) vs oracle", z[b:b + 1], z_ref.numpy(), 5e-5, 1e-4)
-    err = (o[b:b + 1].cpu() - o_ref).numpy()
-    rms, ref = float(np.sqrt((err ** 2).mean())), float(o_ref.pow(2).mean().sqrt())
-    assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)
     # WN with g at the full C3 column count (the conditioned gate epilogue of the fused WN kernel, NR = 2 tiles)
     wn_sd = {k[len("flow.flows.0.enc."):]: v for k, v in sd.items() if k.startswith("flow.flows.0.enc.")}
     wn = load(M.modules.WN(192, 5, 1, 8, gin_channels=256), wn_sd)

@@ -136,3 +136,66 @@ def test_bench_single_gpu_line_schema():
     # HBM traffic: live rocprofv3 --pmc child runs (or, should the profiler fail on the box, this round's committed passes)
     assert rf["traffic"] is not None and rf["traffic_source"].startswith(("LIVE", "OFFLINE")), rf
     assert 2e10 < rf["traffic_bytes_per_step"] < 8e10, rf["traffic_bytes_per_step"]
+
+
+_RCCL_WORLD1 = r'''
+import os, sys, json
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[2]); sys.path.insert(0, os.path.join(sys.argv[2], "tests"))
+import cases
+from cases import sw
+from smart_vocoder_amd import models, parallel, _native as N
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+B, T = 3, 96
+mel = torch.from_numpy(sw.synthetic_mel(71, B, T)).to(dev); eps = torch.from_numpy(sw.synthetic_eps(71, B, T)).to(dev)
+ln = torch.tensor([T, T - 9, 40], dtype=torch.int64, device=dev)
+m, l, e = parallel.scatter_batch([mel, ln, eps], [(80, T), (), (192, T)], [torch.float32, torch.int64, torch.float32], B, src=0, device=dev)
+res = {"scatter_on_device": bool(m.is_cuda and l.is_cuda and e.is_cuda),
+       "scatter_identity": bool(torch.equal(m, mel) and torch.equal(l, ln) and torch.equal(e, eps))}
+net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}, strict=False)
+net = net.to(dev).eval()
+with torch.no_grad():
+    N.profile_enable(True)                      # direct launches on both sides of the comparison
+    ref = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+    o = parallel.infer_sharded(net, mel, ln, eps, noise_scale=0.667, src=0, bitwise=True)
+    N.profile_enable(False)
+    out = torch.empty_like(ref)
+    g = parallel.gather_waveforms(ref, B, dst=0, out=out)
+torch.cuda.synchronize()
+res.update(sharded_bitwise=bool(o.is_cuda and torch.equal(o, ref)), gather_identity=bool(torch.equal(g, ref)), gather_in_place=bool(g.data_ptr() == out.data_ptr()))
+dist.barrier(); dist.destroy_process_group()
+print("RCCL1 " + json.dumps(res))
+'''
+
+
+def test_rccl_world_size_one_on_device(tmp_path):
+    """The RCCL code path on the hardware a 1-GPU box has (VERDICT r3): a world-size-1 "nccl" process group on cuda:0, then the
+    packed scatter, the gather into a preallocated buffer and infer_sharded(bitwise=True) on DEVICE tensors - librccl is loaded and
+    dist.scatter / dist.gather run on device buffers; results must equal plain infer bit for bit.  No scaling claim."""
+    script = tmp_path / "rccl1.py"
+    script.write_text(_RCCL_WORLD1)
+    r = subprocess.run([sys.executable, str(script), str(_free_port()), cases.ROOT], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL1 ")][-1]
+    res = json.loads(line[6:])
+    assert all(res.values()), res
+
+
+def test_bench_one_rank_rccl():
+    """bench.py launched by torch.distributed.run with ONE rank and BENCH_BACKEND=nccl (BENCH_FORCE_DIST=1): process group, packed
+    scatter and the waveform gather inside the timed region run over RCCL; the line reports collective == gather."""
+    env = dict(os.environ, BENCH_BACKEND="nccl", BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(cases.ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--frames", "128", "--no-cpu-baseline", "--no-pmc", "--no-other-configs"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["config"]["collective"] == "gather" and j["config"]["scatter_ms"] is not None, j["config"]

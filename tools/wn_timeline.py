@@ -22,9 +22,22 @@ print(f"WN(192, k5, 16 layers) B={B} T={T}: {e0.elapsed_time(e1) / 160 * 1e3:.1f
 buf = torch.zeros(1 << 14, 8, dtype=torch.long, device="cuda"); torch.cuda.synchronize()
 N.check(lib.svoc_debug_set_stamp_buffer(N.ptr(buf))); m(x, mask); torch.cuda.synchronize(); N.check(lib.svoc_debug_set_stamp_buffer(None))
 D = buf.cpu().numpy(); D = D[D[:, 6] != 0]          # stamps of the LAST layer that wrote each slot
+if not len(D): print("(short input: the unfused K-split path ran, no stamps)"); sys.exit(0)
+if (D[:, 6] < 0).all():      # wn_layer_f25_kernel (round 4): Winograd F(2,5) in_layer
+    D[:, 6] = -D[:, 6]
+    names = ["staging (loads -> LDS, barrier)", "input transform -> planes, barrier", "phase A (in_layer, F(2,5): 576 MFMAs 16x16x4 per wave)",
+             "output transform + exchange + gate + barrier", "phase B (res_skip MFMAs)", "exchange + barrier + epilogue"]
+    tot = D[:, 6] - D[:, 0]
+    print(f"{len(D)} workgroups (wn_layer_f25_kernel); wave 0, shader cycles: total {tot.mean():.0f} (= {tot.mean() / 2400:.1f} us at 2.4 GHz)")
+    sub = D[:, 7]
+    a, b_, c = (sub >> 42) & 0x1fffff, (sub >> 21) & 0x1fffff, sub & 0x1fffff
+    print(f"   (after the stream: output transform + partial-sum writes {a.mean():.0f} | barrier {b_.mean():.0f} | gate {c.mean():.0f} | bias loads + barrier {(D[:, 4] - D[:, 3] - a - b_ - c).mean():.0f})")
+    for i, n in enumerate(names):
+        d = D[:, i + 1] - D[:, i]
+        print(f"   {n:60s} {d.mean():8.0f}  ({100 * d.mean() / tot.mean():4.1f} %)")
+    sys.exit(0)
 names = ["staging (loads -> LDS, barrier)", "phase A (in_layer MFMAs)", "exchange + gate + barrier", "phase B (res_skip MFMAs)", "exchange + barrier", "epilogue"]
 tot = D[:, 6] - D[:, 0]
-if not len(D): print("(short input: the unfused K-split path ran, no stamps)"); sys.exit(0)
 print(f"{len(D)} workgroups; wave 0, shader cycles: total {tot.mean():.0f} (= {tot.mean() / 2400:.1f} us at 2.4 GHz)")
 sub = D[:, 7]
 a, b_, c = (sub >> 42) & 0x1fffff, (sub >> 21) & 0x1fffff, sub & 0x1fffff
