@@ -72,8 +72,10 @@ const char* svoc_build_arch(void);       /* "gfx950" */
 int svoc_stats_reset(void);
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches);
 int64_t svoc_stats_convolutions(void);
-/* 2 x the multiply-adds the matrix pipe ISSUED for those launches: equal to conv_flops for direct-form kernels, 2/3 (k=3),
- * 5/7 (k=7), 8/11 (k=11) of it for the Winograd F(2,3) kernels.  bench.py's roofline.frac_executed is this / time / peak. */
+/* 2 x the multiply-adds the matrix pipe ISSUED for those launches: equal to conv_flops for direct-form kernels; per Winograd
+ * form, as a share of the direct form for k = 3 / 7 / 11: F(4,3) (the default for every ResBlock convolution) 1/2, 4/7, 6.5/11;
+ * F(2,3) (fall-back) 2/3, 5/7, 8/11; F(4,2) (upsamplers, k = 2 stride) 5/8; F(2,5) (WN in_layers, k = 5) 3/5.
+ * bench.py's roofline.achieved / frac is this / time (/ peak). */
 double svoc_stats_executed_flops(void);
 
 /* Kernel variants (tile shape, K split, Winograd or direct form, fused or unfused WN layer, MRF launch plan) are chosen

@@ -954,6 +954,8 @@ int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, 
 int wino4_launch(const WinoArgs& w, int K, int D, int NC, long long total, hipStream_t st);
 int wino4_launch_group(const WinoGroup& g, int D, int NC, int in_perm, int out_perm, long long total, hipStream_t st);
 int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, long long total, hipStream_t st);
+int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, long long total, hipStream_t st);      // conv_wino4_acc.hip
+bool wino4_acc3_enabled();
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
@@ -1198,7 +1200,10 @@ int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, in
     snprintf(d, sizeof(d), "wino4A Ci%-4d Co%-4d k3+7+11 accumulate N%-7d B%-3d", pws[0]->Cin, pws[0]->Cout, as[0].Ncols, B);
     prof_idx = prof_begin(st, d, flops);
   }
-  const int rc = wino4_launch_accum(g4, wino4_nc(*pws[0]), in_perm, total, st);
+  // one set of accumulators for the three members (conv_wino4_acc.hip) when every member is a plain residual convolution
+  const bool merged = wino4_acc3_enabled() && (g4.a[0].flags & (F_RES | F_ACC | F_DIV)) == F_RES &&
+                      (g4.a[1].flags & (F_RES | F_ACC)) == (F_RES | F_ACC) && (g4.a[2].flags & (F_RES | F_ACC)) == (F_RES | F_ACC);
+  const int rc = merged ? wino4_launch_acc3(g4.a, wino4_nc(*pws[0]), in_perm, total, st) : wino4_launch_accum(g4, wino4_nc(*pws[0]), in_perm, total, st);
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
   SVOC_HIP(hipGetLastError());

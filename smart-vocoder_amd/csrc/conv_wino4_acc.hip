@@ -1,0 +1,464 @@
+// The accumulate launch of an MRF stage in ONE set of accumulators (round 4).
+//
+// The last convolutions of the three chains of a stage sum into one tensor: x = (rb_0 + rb_1 + rb_2) / 3 with
+// rb_j = c2_j(lrelu(t_j)) + cur_j (reference models.py:149-155, modules.py:210-223; k = 3 / 7 / 11, dilation 1).  As three
+// members of conv_wino4_accum_kernel the second and third read-modify-write the output: 11 tensor passes (3 inputs, 3 residuals,
+// 2 old outputs read; 3 outputs written) where 7 are needed, and at the 268 MB per tensor of the C = 128 / 64 / 32 stages those
+// launches are paced by exactly that traffic (+170 / +180 / +200 us against a plain grouped launch; the C = 256 stage, whose 67 MB
+// tensors stay in the Infinity Cache, pays +26 us; profiles/r04_accumulate_*_null_*.txt: hiding the LATENCY of the old-output
+// loads changes nothing).  The output transform of F(4,3) is linear, so the three convolutions can add their products into the
+// SAME transform-domain accumulators: per tile the k = 3 stages, the k = 7 stages and the k = 11 stages run back to back (each
+// with its own plane geometry and weight image, conv_wino4.h), the bias of M1 is the sum of the three biases, and ONE epilogue
+// adds the three residuals, divides and stores.  The sum is formed in another order than the reference's (products of the three
+// chains in one accumulator, then the residuals): fp32 rounding only (tests: the MRF goldens, Generator / infer against the oracle).
+//
+// Kernel form = conv_wino4.hip's: persistent eight-wave workgroups, ONE per CU, four consumers (nothing but the MFMA stream
+// and the epilogue) and four producers one stage ahead in the other of two plane sets, one workgroup barrier per stage; the
+// stage counter runs on across the members, the producers request the first raw rows of the next member at a member's last
+// stage, the consumers the next member's first weight slots right behind a member's last MFMA.
+#include "svoc_internal.h"
+#include "wino_common.h"
+#include "conv_wino4.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace svoc {
+
+struct WinoAcc3 { WinoArgs a[3]; int total; };              // members k = 3, 7, 11 (chain order); one tile space; output / flags / div of a[0]
+
+template <int NRT, int PERM>
+struct Acc3Geo {
+  using G3 = W4Geo<3, 1, NRT, PERM>;
+  using G7 = W4Geo<7, 1, NRT, PERM>;
+  using G11 = W4Geo<11, 1, NRT, PERM>;
+  static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+  static constexpr int RAWMAX = cmax(G3::RAW_FLOATS, cmax(G7::RAW_FLOATS, G11::RAW_FLOATS));
+  static constexpr int PLFMAX = cmax(G3::PLF, cmax(G7::PLF, G11::PLF));
+  static constexpr int LDS_BYTES = (RAWMAX + 2 * PLFMAX) * 4;
+  static_assert(G3::NWT == G7::NWT && G7::NWT == G11::NWT, "one tile space");
+};
+
+// ------------------------------------------------------------------------------------------------ producer side
+// Per-lane staging constants of one member (recomputed at every member start: three sets would not fit the register file)
+template <class Geo>
+struct Acc3Prod {
+  static constexpr int KS = Geo::KS, RPW = KS / 4, RAW = Geo::RAW, RAWS = Geo::RAWS, PORG = Geo::PORG, PERM = Geo::PORG / 4;
+  static constexpr int R4 = RAW / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
+  static constexpr int NGWP = PERM > 0 ? RPW * Geo::PNG : 1, SPWP = PERM > 0 ? (NGWP + 63) / 64 : 1;
+  static constexpr int NV = PERM > 0 ? (SPWP > SPW ? SPWP : SPW) : SPW;             // float4 registers of one stage's raw rows
+  static constexpr int NIW = RPW * Geo::NE, TPW = (NIW + 63) / 64;
+};
+
+// requests the raw rows of stage `ch` of the tile whose raw tile starts at column xs (interior tiles: plain 16-byte groups, or
+// whole q blocks of a window-major row; edge tiles: clamped addresses, zeroed by acc3_publish)
+template <class Geo>
+__device__ __forceinline__ void acc3_issue(float4 (&v)[Acc3Prod<Geo>::NV], const WinoArgs& p, const int bz, const int xs, const int ch,
+                                           const int lane, const int pw_) {
+  using P = Acc3Prod<Geo>;
+  constexpr int PERM = P::PERM;
+  const long long ldb = (long long)p.x_ld * 4;
+  const int L = p.L;
+  const bool interior = xs >= 0 && xs + P::RAW <= L;
+  const char* cb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs) + (long long)ch * P::KS * ldb;
+  int l_ = lane;
+  asm volatile("" : "+v"(l_));                             // keeps the per-lane address arithmetic inside the call (not hoisted and kept live)
+  if constexpr (PERM > 0) {
+    const int pnblk_row = (L + 4 * PERM - 1) / (4 * PERM);
+    const int bf = (xs + 4 * PERM) / (4 * PERM) - 1;
+#pragma unroll
+    for (int u = 0; u < P::SPWP; ++u) {
+      const int it = min(l_ + 64 * u, P::NGWP - 1);
+      const int row = P::RPW * pw_ + it / Geo::PNG, g = it % Geo::PNG;
+      int bb = bf + g / PERM;
+      if (!interior) bb = min(max(bb, 0), pnblk_row - 1);
+      v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)(PERM * bb + g % PERM) * 16);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < P::SPW; ++u) {
+      const int it = min(l_ + 64 * u, P::NGW - 1);
+      const int row = P::RPW * pw_ + it / P::R4, tg = xs + 4 * (it % P::R4);
+      v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)((interior || (tg >= 0 && tg + 3 < L)) ? tg : 0) * 4);
+    }
+  }
+}
+
+// One member of one tile on the producer side: publish (lrelu, padding) -> request the next stage -> transform -> barrier, per stage.
+// `v` holds the raw rows of the member's stage 0 on entry (requested by the caller's previous member).  next(): requests the raw
+// rows of whatever follows this member's last stage.
+template <class Geo, class Next>
+__device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3Prod<Geo>::NV], float* const raw, float* const pl, const int PLFMAX_,
+                                            const int w0, const int bz, int& s_, const int lane, const int pw_, Next&& next) {
+  using P = Acc3Prod<Geo>;
+  constexpr int PERM = P::PERM, RAWS = P::RAWS, PORG = P::PORG, RPW = P::RPW, R4 = P::R4, NGW = P::NGW, SPW = P::SPW, NGWP = P::NGWP, SPWP = P::SPWP;
+  constexpr int NE = Geo::NE, PQ = Geo::PQ, PLANE = Geo::PLANE, LEAD = Geo::LEAD, ND = Geo::ND, NIW = P::NIW, TPW = P::TPW;
+  const int L = p.L;
+  const float slope = p.pre_slope;
+  const int nst = p.nchunks * Geo::HALVES / Geo::CPS;
+  const int xs = 4 * w0 + Geo::XOFF;
+  const bool interior = xs >= 0 && xs + Geo::RAW <= L;
+  int l_ = lane;
+  asm volatile("" : "+v"(l_));
+  // per-lane constants of this member
+  float* rdst[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {
+    const int it = min(l_ + 64 * u, NGW - 1);
+    rdst[u] = raw + (RPW * pw_ + it / R4) * RAWS + PORG + 4 * (it % R4);
+  }
+  float* pdst[SPWP];
+  int pgb[SPWP];
+  if constexpr (PERM > 0) {
+#pragma unroll
+    for (int u = 0; u < SPWP; ++u) {
+      const int it = min(l_ + 64 * u, NGWP - 1);
+      const int row = RPW * pw_ + it / Geo::PNG, g = it % Geo::PNG;
+      pdst[u] = raw + row * RAWS + PORG + 4 * PERM * (g / PERM) + g % PERM;
+      pgb[u] = (g / PERM) | ((g % PERM) << 16);
+    }
+  }
+  const float* tsrc[TPW];
+  int tdst[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int it = min(l_ + 64 * u, NIW - 1);
+    const int row = RPW * pw_ + it / NE, e = it % NE;
+    tsrc[u] = raw + row * RAWS + PORG + 4 * e;
+    tdst[u] = row * PQ + e;
+  }
+  for (int ch = 0; ch < nst; ++ch) {
+    // ---- publish own rows
+    if constexpr (PERM > 0) {
+      const int pnblk_row = (L + 4 * PERM - 1) / (4 * PERM);
+      const int bf = (xs + 4 * PERM) / (4 * PERM) - 1;
+      const int delta = bf * (4 * PERM) - xs;
+#pragma unroll
+      for (int u = 0; u < SPWP; ++u) {
+        if (64 * (u + 1) <= NGWP || lane < NGWP - 64 * u) {
+          float4 q = v[u];
+          if (!interior) {                                 // groups of blocks outside the row, and samples beyond L, are zero
+            const int bb = bf + (pgb[u] & 0xffff), n0 = 4 * PERM * bb + ((pgb[u] >> 16) & 15);
+            const bool inrow = bb >= 0 && bb < pnblk_row;
+            q.x = (inrow && n0 < L) ? q.x : 0.f;
+            q.y = (inrow && n0 + PERM < L) ? q.y : 0.f;
+            q.z = (inrow && n0 + 2 * PERM < L) ? q.z : 0.f;
+            q.w = (inrow && n0 + 3 * PERM < L) ? q.w : 0.f;
+          }
+          wino_lrelu4(q, slope);
+          float* d = pdst[u] + delta;
+          d[0] = q.x; d[PERM] = q.y; d[2 * PERM] = q.z; d[3 * PERM] = q.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < SPW; ++u) {
+        if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
+          float4 q = v[u];
+          if (!interior) {                                 // L is a multiple of four (host): a group is inside or padding
+            const int tg = xs + 4 * ((l_ + 64 * u) % R4);
+            if (tg < 0 || tg + 3 >= L) q = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          wino_lrelu4(q, slope);
+          *reinterpret_cast<float4*>(rdst[u]) = q;
+        }
+      }
+    }
+    // ---- request the next stage's raw rows
+    if (ch + 1 < nst) acc3_issue<Geo>(v, p, bz, xs, ch + 1, lane, pw_);
+    else next();
+    // ---- transform own rows into plane set s & 1
+    float* const pb = pl + (s_ & 1) * PLFMAX_;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
+        const float* r = tsrc[u];
+        float* o = pb + tdst[u];
+        float d0, d1, d2, d3, d4, d5;
+        if constexpr (LEAD == 3) {
+          const float4 fm = *reinterpret_cast<const float4*>(r + 4);
+          d0 = r[3]; d1 = fm.x; d2 = fm.y; d3 = fm.z; d4 = fm.w; d5 = r[8];
+        } else {
+          static_assert(LEAD == 3 || LEAD == 1, "window alignment");
+          const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
+          d0 = fa.y; d1 = fa.z; d2 = fa.w; d3 = fb.x; d4 = fb.y; d5 = fb.z;
+        }
+        const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);
+        const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+        o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+        o[PLANE] = a_ + b_;
+        o[2 * PLANE] = a_ - b_;
+        o[3 * PLANE] = c_ + e_;
+        o[4 * PLANE] = c_ - e_;
+        o[5 * PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+        if constexpr (ND > 0) { o[6 * PLANE] = d1; o[7 * PLANE] = d2; o[8 * PLANE] = d3; o[9 * PLANE] = d4; }
+      }
+    }
+    __syncthreads();                                       // B_s: plane set s & 1 complete
+    ++s_;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ consumer side
+// One member of one tile: its stages' MFMA streams into the shared accumulators (conv_wino4.hip's stream: fragment reads two steps
+// ahead at immediate LDS offsets, weights through buffer loads with SGPR slot offsets, one or three slots ahead).
+template <class Geo, int NACC>
+__device__ __forceinline__ void acc3_consume(const WinoArgs& p, f32x16 (&M)[NACC], const unsigned plbase, const int PLFMAX_, const int wt, int& s_,
+                                            const unsigned wlane, const unsigned lanefrag) {
+  constexpr int PQ = Geo::PQ, WSLOTS = Geo::WSLOTS, PLANE = Geo::PLANE, NSTEP = Geo::NSTEP, CPS = Geo::CPS, HALVES = Geo::HALVES, KGS = Geo::KGS;
+  constexpr int NSET = Geo::NSET, PD = Geo::PD;
+  const int nst = p.nchunks * HALVES / CPS;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
+  float4 a[NSET][KGS];
+  auto wload = [&](float4& dst, int soff, auto kg_c) {
+    constexpr int KGO = decltype(kg_c)::value * 1024;
+    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane + KGO, soff, 0);
+    dst = *reinterpret_cast<const float4*>(&t);
+  };
+  auto wload4 = [&](float4 (&dst)[KGS], int soff, auto hf) {
+    constexpr int K0 = decltype(hf)::value * KGS;
+    wload(dst[0], soff, std::integral_constant<int, K0>{});
+    if constexpr (KGS >= 2) wload(dst[1], soff, std::integral_constant<int, K0 + 1>{});
+    if constexpr (KGS == 4) { wload(dst[2], soff, std::integral_constant<int, K0 + 2>{}); wload(dst[3], soff, std::integral_constant<int, K0 + 3>{}); }
+  };
+  // the member's first slots (requested here, right behind the previous member's last MFMA)
+  wload4(a[0], wt, std::integral_constant<int, 0>{});
+  if constexpr (PD > 1) { wload4(a[1], wt + 4096, std::integral_constant<int, 0>{}); wload4(a[2], wt + 2 * 4096, std::integral_constant<int, 0>{}); }
+  auto mfma_chunk = [&](const unsigned baddr, const int wa, const int wnext, auto par, auto cc, auto hf) {
+    constexpr int PAR = decltype(par)::value, CC = decltype(cc)::value, HF = decltype(hf)::value;
+    constexpr int NHF = HF + 1 < HALVES ? HF + 1 : 0;
+    float fb[2][4];
+    auto request = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      if constexpr (T < NSTEP) wino_frag<PQ, Geo::plane(T) * PLANE + CC * KC * PQ, Geo::kgi(T), Geo::colq(T)>(fb[T & 1], baddr);
+    };
+    auto step = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      constexpr int WS = Geo::wslot(T), KG = Geo::kgi(T);
+      if constexpr (Geo::slot_first(T)) {
+        if constexpr (WS + PD < WSLOTS) wload4(a[(PAR + WS + PD) % NSET], wa + (WS + PD) * 4096, hf);
+        else if (wnext >= 0) wload4(a[(PAR + WS + PD) % NSET], wnext + (WS + PD - WSLOTS) * 4096, std::integral_constant<int, NHF>{});
+      }
+      {
+        float(&b)[4] = fb[T & 1];
+        if constexpr (T + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      }
+      const float4 av = a[(PAR + WS) % NSET][KG];
+      constexpr int AC = Geo::acc(T);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) M[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[AC], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      request(std::integral_constant<int, T + 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    request(std::integral_constant<int, 0>{});
+    request(std::integral_constant<int, 1>{});
+    wino_static_for<0, NSTEP>(step);
+  };
+  auto stage = [&](int st_, auto par, auto hf) {
+    constexpr int HF = decltype(hf)::value;
+    __syncthreads();                                       // B_s: plane set s & 1 is complete, the other one may be overwritten
+    const unsigned baddr = plbase + (unsigned)((s_ & 1) * PLFMAX_) * 4u + lanefrag;
+    ++s_;
+    constexpr auto c0_ = std::integral_constant<int, 0>{};
+    if constexpr (HALVES > 1) {
+      const int wa = wt + (st_ / HALVES) * WSLOTS * 4096;
+      const int wnext = HF + 1 < HALVES ? wa : (st_ + 1 < nst ? wa + WSLOTS * 4096 : -1);
+      mfma_chunk(baddr, wa, wnext, par, c0_, hf);
+    } else if constexpr (CPS == 1) {
+      const int wa = wt + st_ * WSLOTS * 4096;
+      const int wnext = st_ + 1 < nst ? wa + WSLOTS * 4096 : -1;
+      mfma_chunk(baddr, wa, wnext, par, c0_, c0_);
+    } else {
+      static_assert(CPS == 1 || (WSLOTS & 1) == 0, "two chunks per stage need an even slot count");
+      const int wa = wt + (st_ * CPS) * WSLOTS * 4096;
+      mfma_chunk(baddr, wa, wa + WSLOTS * 4096, par, c0_, c0_);
+      const int wnext = st_ + 1 < nst ? wa + 2 * WSLOTS * 4096 : -1;
+      mfma_chunk(baddr, wa + WSLOTS * 4096, wnext, par, std::integral_constant<int, CPS - 1>{}, c0_);
+    }
+  };
+  if constexpr (HALVES > 1) {
+    constexpr int U = (HALVES * WSLOTS) % NSET == 0 ? HALVES : 2 * HALVES;
+    static_assert((U * WSLOTS) % NSET == 0 && U <= 4, "weight ring does not close");
+    for (int st_ = 0; st_ < nst; st_ += U) {
+      stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      stage(st_ + 1, std::integral_constant<int, WSLOTS % NSET>{}, std::integral_constant<int, 1 % HALVES>{});
+      if constexpr (U == 4) {
+        stage(st_ + 2, std::integral_constant<int, (2 * WSLOTS) % NSET>{}, std::integral_constant<int, 2 % HALVES>{});
+        stage(st_ + 3, std::integral_constant<int, (3 * WSLOTS) % NSET>{}, std::integral_constant<int, 3 % HALVES>{});
+      }
+    }
+  } else if constexpr ((WSLOTS & 1) == 0) {
+    for (int st_ = 0; st_ < nst; ++st_) stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  } else {
+    for (int st_ = 0; st_ < nst; st_ += 2) {
+      stage(st_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      stage(st_ + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    }
+  }
+}
+
+template <int NRT, int PERM>
+__global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 g) {
+  using AG = Acc3Geo<NRT, PERM>;
+  using G3 = typename AG::G3;
+  using G7 = typename AG::G7;
+  using G11 = typename AG::G11;
+  constexpr int NWT = G11::NWT, NACC = 8;
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  float* const raw = wl;
+  float* const pl = wl + AG::RAWMAX;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WinoArgs& p3 = g.a[0];
+  const WinoArgs& p7 = g.a[1];
+  const WinoArgs& p11 = g.a[2];
+  const int total = g.total, stride = gridDim.x, v0 = blockIdx.x;
+  if (v0 >= total) return;
+  const int my_tiles = (total - v0 + stride - 1) / stride;
+  const int L = p3.L;
+  auto locate = [&](int v, int& w0_, int& bz_, int& by_) {
+    const int tl = xcd_linear(v, total, p3.xcd);
+    const int t = tl / p3.ntn;
+    bz_ = t / p3.gy;
+    w0_ = (tl - t * p3.ntn) * NWT;
+    by_ = t - bz_ * p3.gy;
+  };
+  int s_ = 0;                                              // stage counter of the workgroup: plane set = s & 1 on both sides
+
+  if (wave >= 4) {
+    // ================================================================= producers
+    const int pw_ = wave - 4;
+    if (p3.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
+    float4 v3[Acc3Prod<G3>::NV], v7[Acc3Prod<G7>::NV], v11[Acc3Prod<G11>::NV];
+    int w0, bz, by;
+    locate(v0, w0, bz, by);
+    acc3_issue<G3>(v3, p3, bz, 4 * w0 + G3::XOFF, 0, lane, pw_);
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      int w0n = w0, bzn = bz, byn = by;
+      const bool more = ti + 1 < my_tiles;
+      if (more) locate(v0 + (ti + 1) * stride, w0n, bzn, byn);
+      acc3_produce<G3>(p3, v3, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_, [&]() { acc3_issue<G7>(v7, p7, bz, 4 * w0 + G7::XOFF, 0, lane, pw_); });
+      acc3_produce<G7>(p7, v7, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_, [&]() { acc3_issue<G11>(v11, p11, bz, 4 * w0 + G11::XOFF, 0, lane, pw_); });
+      acc3_produce<G11>(p11, v11, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_,
+                        [&]() { if (more) acc3_issue<G3>(v3, p3, bzn, 4 * w0n + G3::XOFF, 0, lane, pw_); });
+      w0 = w0n; bz = bzn; by = byn;
+    }
+    return;
+  }
+
+  // =================================================================== consumers: row tile rt, column tile ct of the workgroup
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int rt = NRT == 4 ? wave : (NRT == 2 ? (wave & 1) : 0), ct = NRT == 4 ? 0 : (NRT == 2 ? (wave >> 1) : wave);
+  const int uu = ct * 32 + l31;
+  const unsigned plbase = (unsigned)(size_t)pl;
+  const unsigned wlane = (unsigned)lane * 16u;
+  f32x16 M[NACC];
+  const unsigned ylb = (unsigned)p3.y_ld * 4u;
+  unsigned yo4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) yo4[i] = (unsigned)((4 * hi + i) * p3.y_ld + 4 * uu) * 4u;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int w0, bz, by;
+    locate(v0 + ti * stride, w0, bz, by);
+    const int n0 = 4 * w0, ne = n0 + 4 * uu;
+    const int mt = by * NRT + rt;
+    const bool row_ok = mt < p3.mtiles;
+    const int mtc = row_ok ? mt : p3.mtiles - 1;
+    {   // the bias starts in M1 (part of all four outputs): the sum of the three members' biases
+      const float* b3 = p3.bias + mtc * 32 + 4 * hi;
+      const float* b7 = p7.bias + mtc * 32 + 4 * hi;
+      const float* b11 = p11.bias + mtc * 32 + 4 * hi;
+#pragma unroll
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = (i & 3) + 8 * (i >> 2);
+          M[q][i] = q == 1 ? (b3[r] + b7[r]) + b11[r] : 0.f;
+        }
+    }
+    acc3_consume<G3, NACC>(p3, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p3.nchunks * G3::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G3::PQ + uu) * 4u);
+    acc3_consume<G7, NACC>(p7, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p7.nchunks * G7::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G7::PQ + uu) * 4u);
+    acc3_consume<G11, NACC>(p11, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p11.nchunks * G11::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G11::PQ + uu) * 4u);
+    // ---- output transform + epilogue: y = (A^T M + res_3 + res_7 + res_11) / div, sixteen-byte stores
+    if (row_ok && ne < L) {
+      char* const ybase = reinterpret_cast<char*>(p3.y + (long long)bz * p3.y_bs + (long long)(mt * 32) * p3.y_ld + n0);
+      const long long roff3 = (long long)bz * p3.res_bs + (long long)(mt * 32 + 4 * hi) * p3.res_ld + ne;
+      const long long roff7 = (long long)bz * p7.res_bs + (long long)(mt * 32 + 4 * hi) * p7.res_ld + ne;
+      const long long roff11 = (long long)bz * p11.res_bs + (long long)(mt * 32 + 4 * hi) * p11.res_ld + ne;
+      const float dv = p3.div, rc = 1.0f / dv;
+      const bool dodiv = (p3.flags & F_DIV) != 0;
+      auto dv1 = [&](float x) { const float q = x * rc; return __builtin_fmaf(__builtin_fmaf(-q, dv, x), rc, q); };
+      auto quarter = [&](auto q_c) {
+        constexpr int Q = decltype(q_c)::value;
+        float4 r3[4], r7[4], r11[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          r3[r] = *reinterpret_cast<const float4*>(p3.res + roff3 + (long long)(8 * Q + r) * p3.res_ld);
+          r7[r] = *reinterpret_cast<const float4*>(p7.res + roff7 + (long long)(8 * Q + r) * p7.res_ld);
+          r11[r] = *reinterpret_cast<const float4*>(p11.res + roff11 + (long long)(8 * Q + r) * p11.res_ld);
+        }
+        float4 vo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * Q + r;
+          const float t1 = M[1][i] + M[2][i], t2 = M[1][i] - M[2][i], t3 = M[3][i] + M[4][i], t4 = M[3][i] - M[4][i];
+          const float y0 = M[0][i] + (t1 + t3);
+          const float y1 = __builtin_fmaf(2.f, t4, t2) + M[6][i];
+          const float y2 = __builtin_fmaf(4.f, t3, t1) + M[7][i];
+          const float y3 = __builtin_fmaf(8.f, t4, t2) + M[5][i];
+          vo[r] = make_float4(y0, y1, y2, y3);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vo[r].x = ((vo[r].x + r3[r].x) + r7[r].x) + r11[r].x;
+          vo[r].y = ((vo[r].y + r3[r].y) + r7[r].y) + r11[r].y;
+          vo[r].z = ((vo[r].z + r3[r].z) + r7[r].z) + r11[r].z;
+          vo[r].w = ((vo[r].w + r3[r].w) + r7[r].w) + r11[r].w;
+          if (dodiv) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q) * ylb + yo4[r]) = vo[r];
+      };
+      quarter(std::integral_constant<int, 0>{});
+      quarter(std::integral_constant<int, 1>{});
+      quarter(std::integral_constant<int, 2>{});
+      quarter(std::integral_constant<int, 3>{});
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launch
+template <int NRT, int PERM>
+static int acc3_launch_n(const WinoAcc3& g, hipStream_t st) {
+  using AG = Acc3Geo<NRT, PERM>;
+  static_assert(AG::LDS_BYTES <= 160 * 1024, "tile does not fit");
+  auto kern = conv_wino4_acc3_kernel<NRT, PERM>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const unsigned grid = (unsigned)std::min<long long>(g.total, (long long)device_cu_count());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)AG::LDS_BYTES, st, g);
+  return SVOC_OK;
+}
+// members in chain order (k = 3, 7, 11, dilation 1, epilogue flags of a plain residual), one tile space of `total` tiles; in_perm: 0, or
+// the dilation (3 / 5) of the convolutions that wrote the members' inputs window-major; a[0] carries the output, F_DIV and div
+int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, long long total, hipStream_t st) {
+  WinoAcc3 g;
+  for (int i = 0; i < 3; ++i) g.a[i] = a[i];
+  g.a[0].flags |= a[2].flags & F_DIV;                       // the division by the number of chains rides on the last member
+  g.a[0].div = a[2].div;
+  g.total = (int)total;
+#define SVOC_W4M(P) (NRT == 4 ? acc3_launch_n<4, P>(g, st) : (NRT == 2 ? acc3_launch_n<2, P>(g, st) : acc3_launch_n<1, P>(g, st)))
+  if (in_perm == 5) return SVOC_W4M(5);
+  if (in_perm == 3) return SVOC_W4M(3);
+  return SVOC_W4M(0);
+#undef SVOC_W4M
+}
+bool wino4_acc3_enabled() {
+  static const bool on = !(getenv("SVOC_W4_ACC3") && atoi(getenv("SVOC_W4_ACC3")) == 0);      // SVOC_W4_ACC3=0: three read-modify-write members
+  return on;
+}
+
+}  // namespace svoc

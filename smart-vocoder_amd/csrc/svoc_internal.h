@@ -237,7 +237,8 @@ bool prof_enabled();
 int prof_begin(hipStream_t st, const std::string& desc, double flops);
 void prof_end(hipStream_t st, int idx);
 // one GEMM-family kernel launch computing nconv convolutions; exec_flops = 2 x the multiply-adds the matrix pipe really issues
-// for them (Winograd kernels: 2/3, 5/7, 8/11 of the direct form for k = 3, 7, 11; < 0: same as flops)
+// for them (shares of the direct form for k = 3, 7, 11: F(4,3) 1/2, 4/7, 6.5/11 (default); F(2,3) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8;
+// F(2,5) WN in_layers 3/5; < 0: same as flops)
 void stats_add_conv(double flops, int nconv = 1, double exec_flops = -1.0);
 double stats_exec_flops();
 void stats_add_other();
