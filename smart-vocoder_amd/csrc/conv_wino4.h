@@ -20,11 +20,13 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef W4_NPS3_MAX_NRT
 #define W4_NPS3_MAX_NRT 4                                  // three plane sets for every layout whose LDS budget allows them
 #endif
-template <int K, int D, int NRT = 4, int PERM = 0>
+// KSDIV: channels per stage divided by KSDIV (conv_wino4_acc.hip stages its k = 3 member half as wide so that three plane sets fit)
+template <int K, int D, int NRT = 4, int PERM = 0, int KSDIV = 1>
 struct W4Geo {
   static_assert(PERM == 0 || D == 1, "a window-major input belongs to an undilated convolution (the c2 behind a dilated c1)");
   static constexpr int NCT = 4 / NRT;                     // column tiles (of 32 windows) per workgroup
-  static constexpr int KS = NRT == 1 ? (K == 3 ? 16 : 8) : (NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32));   // channels per stage
+  static constexpr int KS = (NRT == 1 ? (K == 3 ? 16 : 8) : (NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32))) / KSDIV;   // channels per stage
+  static_assert(KS >= 8, "a stage is at least one k-group");
   static constexpr int CPS = KS >= KC ? KS / KC : 1;      // weight chunks per stage
   static constexpr int HALVES = KS < KC ? KC / KS : 1;    // stages per weight chunk
   static constexpr int KGS = KS < KC ? KS / 8 : 4;        // k-groups (of 8 channels = 4 k-steps) per stage and chunk

@@ -36,7 +36,10 @@ struct Acc3Geo {
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int RAWMAX = cmax(G3::RAW_FLOATS, cmax(G7::RAW_FLOATS, G11::RAW_FLOATS));
   static constexpr int PLFMAX = cmax(G3::PLF, cmax(G7::PLF, G11::PLF));
-  static constexpr int LDS_BYTES = (RAWMAX + 2 * PLFMAX) * 4;
+  // Two plane sets.  (Three - with the k = 3 member staged half as wide, W4Geo's KSDIV, so that they fit - measured SLOWER: accumulate
+  // launches 1769 -> 1800 / 1108 -> 1137 / 795 -> 826 us at C = 128 / 64 / 32: the k = 3 stages get too short for their barriers.)
+  static constexpr int NPS = 2;
+  static constexpr int LDS_BYTES = (RAWMAX + NPS * PLFMAX) * 4;
   static_assert(G3::NWT == G7::NWT && G7::NWT == G11::NWT, "one tile space");
 };
 
@@ -88,7 +91,7 @@ __device__ __forceinline__ void acc3_issue(float4 (&v)[Acc3Prod<Geo>::NV], const
 // One member of one tile on the producer side: publish (lrelu, padding) -> request the next stage -> transform -> barrier, per stage.
 // `v` holds the raw rows of the member's stage 0 on entry (requested by the caller's previous member).  next(): requests the raw
 // rows of whatever follows this member's last stage.
-template <class Geo, class Next>
+template <class Geo, int NPS, class Next>
 __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3Prod<Geo>::NV], float* const raw, float* const pl, const int PLFMAX_,
                                             const int w0, const int bz, int& s_, const int lane, const int pw_, Next&& next) {
   using P = Acc3Prod<Geo>;
@@ -168,8 +171,8 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
     // ---- request the next stage's raw rows
     if (ch + 1 < nst) acc3_issue<Geo>(v, p, bz, xs, ch + 1, lane, pw_);
     else next();
-    // ---- transform own rows into plane set s & 1
-    float* const pb = pl + (s_ & 1) * PLFMAX_;
+    // ---- transform own rows into plane set s mod NPS (s_ holds that index; it wraps here)
+    float* const pb = pl + (s_ & 0xff) * PLFMAX_;
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
@@ -195,15 +198,17 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
         if constexpr (ND > 0) { o[6 * PLANE] = d1; o[7 * PLANE] = d2; o[8 * PLANE] = d3; o[9 * PLANE] = d4; }
       }
     }
-    __syncthreads();                                       // B_s: plane set s & 1 complete
-    ++s_;
+    // B_s: plane set complete.  Three sets: the barrier behind stage s is B_{s-1} (started = a stage has been produced before), the
+    // last one follows the tile loop (conv_wino4.hip)
+    if (NPS == 2 || (s_ >> 8)) __syncthreads();
+    s_ = ((s_ & 0xff) + 1 == NPS ? 0 : (s_ & 0xff) + 1) | 0x100;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ consumer side
 // One member of one tile: its stages' MFMA streams into the shared accumulators (conv_wino4.hip's stream: fragment reads two steps
 // ahead at immediate LDS offsets, weights through buffer loads with SGPR slot offsets, one or three slots ahead).
-template <class Geo, int NACC>
+template <class Geo, int NACC, int NPS>
 __device__ __forceinline__ void acc3_consume(const WinoArgs& p, f32x16 (&M)[NACC], const unsigned plbase, const int PLFMAX_, const int wt, int& s_,
                                             const unsigned wlane, const unsigned lanefrag) {
   constexpr int PQ = Geo::PQ, WSLOTS = Geo::WSLOTS, PLANE = Geo::PLANE, NSTEP = Geo::NSTEP, CPS = Geo::CPS, HALVES = Geo::HALVES, KGS = Geo::KGS;
@@ -260,8 +265,8 @@ __device__ __forceinline__ void acc3_consume(const WinoArgs& p, f32x16 (&M)[NACC
   auto stage = [&](int st_, auto par, auto hf) {
     constexpr int HF = decltype(hf)::value;
     __syncthreads();                                       // B_s: plane set s & 1 is complete, the other one may be overwritten
-    const unsigned baddr = plbase + (unsigned)((s_ & 1) * PLFMAX_) * 4u + lanefrag;
-    ++s_;
+    const unsigned baddr = plbase + (unsigned)(s_ * PLFMAX_) * 4u + lanefrag;
+    s_ = s_ + 1 == NPS ? 0 : s_ + 1;
     constexpr auto c0_ = std::integral_constant<int, 0>{};
     if constexpr (HALVES > 1) {
       const int wa = wt + (st_ / HALVES) * WSLOTS * 4096;
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
     w0_ = (tl - t * p3.ntn) * NWT;
     by_ = t - bz_ * p3.gy;
   };
-  int s_ = 0;                                              // stage counter of the workgroup: plane set = s & 1 on both sides
+  int s_ = 0;                                              // plane set of the next stage (the producers keep a "started" flag in bit 8)
 
   if (wave >= 4) {
     // ================================================================= producers
@@ -341,12 +346,13 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
       int w0n = w0, bzn = bz, byn = by;
       const bool more = ti + 1 < my_tiles;
       if (more) locate(v0 + (ti + 1) * stride, w0n, bzn, byn);
-      acc3_produce<G3>(p3, v3, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_, [&]() { acc3_issue<G7>(v7, p7, bz, 4 * w0 + G7::XOFF, 0, lane, pw_); });
-      acc3_produce<G7>(p7, v7, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_, [&]() { acc3_issue<G11>(v11, p11, bz, 4 * w0 + G11::XOFF, 0, lane, pw_); });
-      acc3_produce<G11>(p11, v11, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_,
+      acc3_produce<G3, AG::NPS>(p3, v3, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_, [&]() { acc3_issue<G7>(v7, p7, bz, 4 * w0 + G7::XOFF, 0, lane, pw_); });
+      acc3_produce<G7, AG::NPS>(p7, v7, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_, [&]() { acc3_issue<G11>(v11, p11, bz, 4 * w0 + G11::XOFF, 0, lane, pw_); });
+      acc3_produce<G11, AG::NPS>(p11, v11, raw, pl, AG::PLFMAX, w0, bz, s_, lane, pw_,
                         [&]() { if (more) acc3_issue<G3>(v3, p3, bzn, 4 * w0n + G3::XOFF, 0, lane, pw_); });
       w0 = w0n; bz = bzn; by = byn;
     }
+    if constexpr (AG::NPS == 3) __syncthreads();
     return;
   }
 
@@ -380,9 +386,9 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
           M[q][i] = q == 1 ? (b3[r] + b7[r]) + b11[r] : 0.f;
         }
     }
-    acc3_consume<G3, NACC>(p3, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p3.nchunks * G3::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G3::PQ + uu) * 4u);
-    acc3_consume<G7, NACC>(p7, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p7.nchunks * G7::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G7::PQ + uu) * 4u);
-    acc3_consume<G11, NACC>(p11, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p11.nchunks * G11::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G11::PQ + uu) * 4u);
+    acc3_consume<G3, NACC, AG::NPS>(p3, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p3.nchunks * G3::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G3::PQ + uu) * 4u);
+    acc3_consume<G7, NACC, AG::NPS>(p7, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p7.nchunks * G7::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G7::PQ + uu) * 4u);
+    acc3_consume<G11, NACC, AG::NPS>(p11, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p11.nchunks * G11::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G11::PQ + uu) * 4u);
     // ---- output transform + epilogue: y = (A^T M + res_3 + res_7 + res_11) / div, sixteen-byte stores
     if (row_ok && ne < L) {
       char* const ybase = reinterpret_cast<char*>(p3.y + (long long)bz * p3.y_bs + (long long)(mt * 32) * p3.y_ld + n0);
@@ -392,6 +398,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
       const float dv = p3.div, rc = 1.0f / dv;
       const bool dodiv = (p3.flags & F_DIV) != 0;
       auto dv1 = [&](float x) { const float q = x * rc; return __builtin_fmaf(__builtin_fmaf(-q, dv, x), rc, q); };
+      // (requesting the residuals of quarter Q + 1 behind quarter Q's output transform: 14-19 spilled registers, no gain - measured)
       auto quarter = [&](auto q_c) {
         constexpr int Q = decltype(q_c)::value;
         float4 r3[4], r7[4], r11[4];
