@@ -1236,7 +1236,9 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     lds = std::max(lds, l);
   }
   if (!f4 && pws[0]->mtiles < 2) return 1;                  // C = 32 exists in F(4,3) form only
-  if ((f4 ? total4 : total) / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
+  // (the threshold counts the F(2,3) kernels' 64- / 128-column tiles whichever form runs: round 3's measured break-even for the
+  // grouped launches - counting the F(4,3) tiles instead sent the 1 x 200 C = 128 / 64 stages to the direct kernels, +0.5 ms)
+  if (total / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
   const int in_perm = as[0].wperm_in, out_perm = as[0].wperm_out;
   for (int i = 1; i < n; ++i) if (as[i].wperm_in != in_perm || as[i].wperm_out != out_perm) return 1;
   if (query) return f4 ? 0 : 1;

@@ -51,6 +51,11 @@ def _worker(rank, world, port, B, T, q):
     back = parallel.gather_waveforms(m[:, :1, :], B, dst=0)
     if rank == 0:
         ok = ok and torch.equal(back, mel[:, :1, :])
+    # gather into a caller-owned buffer: filled in place for an even split (no concatenation), copied into otherwise
+    out = torch.full((B, 1, T), float("nan")) if rank == 0 else None
+    back2 = parallel.gather_waveforms(m[:, :1, :], B, dst=0, out=out)
+    if rank == 0:
+        ok = ok and back2.data_ptr() == out.data_ptr() and torch.equal(out, mel[:, :1, :])
     # sharded infer == single-process infer
     net = _FakeNet()
     o = parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
@@ -102,3 +107,31 @@ def test_shard_bounds_and_sort():
     ln = torch.tensor([5, 9, 2, 9])
     order, inv = parallel.sort_by_length(ln)
     assert ln[order].tolist() == [9, 9, 5, 2] and torch.equal(ln[order][inv], ln)
+
+
+def test_pack_layout_is_aligned_and_disjoint():
+    """One rank's packed chunk (parallel.scatter_batch): regions ordered widest element type first, every region aligned for its
+    type, no overlap, chunk a multiple of 16 bytes."""
+    from smart_vocoder_amd import parallel
+    for nmax in (1, 3, 16):
+        tails, dts = [(80, 7), (), (192, 7)], [torch.float32, torch.int64, torch.float32]
+        layout, chunk = parallel._pack_layout(tails, dts, nmax)
+        assert chunk % 16 == 0
+        spans = sorted(layout)
+        for (o0, n0), (o1, _) in zip(spans, spans[1:]):
+            assert o0 + n0 <= o1
+        assert spans[-1][0] + spans[-1][1] <= chunk
+        for (off, nb), tail, dt in zip(layout, tails, dts):
+            assert off % 16 == 0 and nb == nmax * int(torch.Size(tail).numel()) * torch.tensor([], dtype=dt).element_size()
+
+
+def test_decoder_receptive_frames_follow_the_config():
+    """the halo of length-bucketed shards comes from the configuration, not from a constant of the iitp model."""
+    from smart_vocoder_amd import models
+    m = cases.IITP_MODEL
+    assert models.decoder_receptive_frames(m["resblock"], m["resblock_kernel_sizes"], m["resblock_dilation_sizes"], m["upsample_rates"],
+                                           m["upsample_kernel_sizes"]) == 16
+    # smaller first upsampling rate -> the ResBlock stacks reach further in frames
+    assert models.decoder_receptive_frames("1", [3, 7, 11], [[1, 3, 5]] * 3, [4, 4, 4, 4], [8, 8, 8, 8]) > 16
+    # ResBlock2 (dilated convolutions only) reaches less far than ResBlock1
+    assert models.decoder_receptive_frames("2", [3, 7, 11], [[1, 3]] * 3, [8, 8, 2, 2], [16, 16, 4, 4]) < 16
