@@ -36,6 +36,7 @@ struct WNStack {
   int H = 0, K = 0, DR = 1, NL = 0, gin = 0;
   std::vector<std::unique_ptr<PackedConv>> in_l, rs_l;
   std::vector<std::unique_ptr<DevBuf>> in_f25;            // in_layers in Winograd F(2,5) form where wn_fused.hip serves the shape
+  std::vector<std::unique_ptr<DevBuf>> rs16;              // res_skip layers 0 .. NL-2 as 16x16x4 A operands (wn_small.hip: short inputs)
   std::unique_ptr<PackedConv> cond;
   DevBuf ws;
 
@@ -53,6 +54,10 @@ struct WNStack {
       if (i < NL - 1) { rp.Cout = 2 * H; rp.split_at = H; } else { rp.Cout = H; }
       rs_l.emplace_back(new PackedConv());
       SVOC_TRY(pack_conv_named(*rs_l.back(), rp, tab, prefix + "res_skip_layers." + std::to_string(i), st));
+      if (i < NL - 1) {
+        rs16.emplace_back(new DevBuf());
+        if (K == 5 && d == 1) SVOC_TRY(pack_wn_rs16_named(*rs16.back(), H, rp.Cout, tab, prefix + "res_skip_layers." + std::to_string(i), st));
+      }
       d *= DR;
     }
     if (gin > 0) {
@@ -64,7 +69,7 @@ struct WNStack {
   }
 
   size_t need(int B, int T, int g_T) const {
-    return (size_t)(3LL * H * pad4(T) * B + 2LL * H * NL * (g_T > 0 ? pad4(g_T) : 0) * B) * sizeof(float);
+    return (size_t)(4LL * H * pad4(T) * B + 2LL * H * NL * (g_T > 0 ? pad4(g_T) : 0) * B) * sizeof(float);
   }
   int reserve(int B, int T, int g_T) { return ws.ensure(need(B, T, g_T)); }
 
@@ -79,7 +84,8 @@ struct WNStack {
     float* xa = ws.f();
     float* xb = xa + per * B;
     float* acts = xb + per * B;
-    float* gc = acts + per * B;
+    float* acts2 = acts + per * B;
+    float* gc = acts2 + per * B;
     if (g) {
       if (!cond) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "WN: g given but the module has gin_channels == 0");
       if (g_T != 1 && g_T != T) SVOC_FAIL(SVOC_ERR_SHAPE, "WN: g must have 1 or T=%d frames, got %d", T, g_T);
@@ -91,6 +97,30 @@ struct WNStack {
     }
     // x is ping-ponged between xa and xb: layer i reads `src` (with a (k-1)d/2 halo) and writes `dst`
     const float* src = x; long long src_bs = x_bs; int src_ld = x_ld;
+    // Short inputs (wn_small.hip): ONE launch per layer - the previous layer's res_skip at the head of the kernel that computes the
+    // F(2,5) in_layer and the gate - and the last layer's res_skip as a convolution behind the chain
+    {
+      bool chain = wn_small_enabled() && wn_layer_prefers_unfused(B, T) && K == 5 && DR == 1;
+      for (int i = 0; i < NL && chain; ++i) chain = in_f25[i]->p != nullptr && (i == NL - 1 || rs16[i]->p != nullptr);
+      if (chain) {
+        float* ab[2] = {acts, acts2};
+        for (int i = 0; i < NL; ++i) {
+          float* dst = (i & 1) ? xb : xa;
+          const float* gl = g ? gc + (long long)i * 2 * H * gTp : nullptr;
+          const int r = launch_wn_small_layer(*in_l[i], in_f25[i]->f(), i > 0 ? rs16[i - 1]->f() : nullptr, i > 0 ? rs_l[i - 1]->flops_per_col : 0.0,
+                                              src, src_bs, src_ld, i > 0 ? ab[(i - 1) & 1] : nullptr, per, Tp, dst, per, Tp, out, out_bs, out_ld,
+                                              ab[i & 1], per, Tp, mask, mask_bs, gl, gper, gTp, g_T == 1 ? 0 : 1, i == 1 ? 1 : 0, B, T, st);
+          if (r != 0) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "WN: the short-input layer kernel refused a shape it had accepted");
+          if (i > 0) { src = dst; src_bs = per; src_ld = Tp; }
+        }
+        ConvArgs a = mk_args();                             // res_skip of the last layer: out = (out + rs) * mask (modules.py:173-175)
+        set_in(a, ab[(NL - 1) & 1], per, Tp, T);
+        a.Ncols = T;
+        a.mask = mask; a.mask_bs = mask_bs;
+        set_out(a.out[0], out, out_bs, out_ld, H, (NL == 1 ? 0u : (unsigned)F_ACC) | F_OUTMASK);
+        return launch_conv(*rs_l[NL - 1], a, B, st);
+      }
+    }
     for (int i = 0; i < NL; ++i) {
       const bool last = i == NL - 1;
       float* dst = (i & 1) ? xb : xa;

@@ -218,6 +218,14 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
                           int B, int T, hipStream_t st, const float* wpf = nullptr);
 // F(2,5) image of an in_layer (H = 192, k = 5, dilation 1; wn_layer_f25_kernel), left empty when the form does not apply
 bool wn_f25_enabled();
+bool wn_layer_prefers_unfused(int B, int T);              // short inputs: fewer 32-column tiles than half the CUs (wn_fused.hip's size gate)
+// wn_small.hip: short inputs, one launch per layer: res_skip of the previous layer + F(2,5) in_layer + gate; 1 = does not apply
+bool wn_small_enabled();
+int pack_wn_rs16_named(DevBuf& img, int H, int Cout, const TensorTable& tab, const std::string& prefix, hipStream_t st);
+int launch_wn_small_layer(const PackedConv& in_l, const float* wpf, const float* wrs, double rs_flops_per_col, const float* x, long long x_bs,
+                          int x_ld, const float* ap, long long ap_bs, int ap_ld, float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs,
+                          int out_ld, float* ao, long long ao_bs, int ao_ld, const float* mask, long long mask_bs, const float* gadd,
+                          long long gadd_bs, int gadd_ld, int gadd_ts, int skip_first, int B, int T, hipStream_t st);
 int pack_wn_f25_named(DevBuf& img, int H, int K, int dil, const TensorTable& tab, const std::string& prefix, hipStream_t st);
 
 // ------------------------------------------------------------------ small kernels (misc_kernels.hip)

@@ -845,6 +845,11 @@ __global__ void wnf_scale_kernel(const float* __restrict__ v, const float* __res
   if (threadIdx.x == 0) scale[i] = g[i] / sqrtf(red[0]);
 }
 
+bool wn_layer_prefers_unfused(int B, int T) {
+  static const bool small_on = !(getenv("SVOC_WN_SMALL") && atoi(getenv("SVOC_WN_SMALL")) == 0);
+  static const int tiles = getenv("SVOC_WN_SMALL_TILES") ? atoi(getenv("SVOC_WN_SMALL_TILES")) : 0;      // tunable: 32-column tiles below which a layer is "short"
+  return small_on && (long long)variant_batch(B) * ((T + 31) / 32) < (tiles > 0 ? tiles : device_cu_count() / 2);
+}
 bool wn_f25_enabled() {
   static const bool on = !(getenv("SVOC_WN_F25") && atoi(getenv("SVOC_WN_F25")) == 0);      // SVOC_WN_F25=0: the direct-form layer kernels
   return on;
@@ -906,8 +911,7 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
       // (76 us at H=192, k=5 whatever the batch).  With fewer than ncu/2 such workgroups the chip is mostly idle and
       // the layer is latency-bound: run in_layer and res_skip as two K-split convolutions instead (conv_ksplit_kernel:
       // one row pair per workgroup, K split over its four waves: 42 + 84 workgroups with 240 / 24-MFMA chains at 1 x 200).
-    static const bool small_on = !(getenv("SVOC_WN_SMALL") && atoi(getenv("SVOC_WN_SMALL")) == 0);
-    if (small_on && (long long)variant_batch(B) * ((T + 31) / 32) < ncu / 2) return 1;
+    if (wn_layer_prefers_unfused(B, T)) return 1;
   }
   const int NR = ((long long)variant_batch(B) * ((T + 63) / 64) >= 2LL * ncu) ? 2 : 1;
   const int NA = NR * 32;

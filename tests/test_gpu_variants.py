@@ -14,6 +14,7 @@ listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run check
   SVOC_W4_ACC3=0                 the accumulate launch as three read-modify-write members instead of one set of accumulators
   SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv
   SVOC_W4_PERM=0                 dilated F(4,3) convolutions store their rows in natural order (four scattered dwords per lane)
+  SVOC_WN_SMALL_F25=0            short inputs: WN layers as two K-split convolutions instead of one launch per layer (wn_small.hip)
   SVOC_WN_F25=0                  WN in_layers in direct form (K-split layer kernel) instead of Winograd F(2,5)
   SVOC_W4_ACCUM=0                the chains' last convolutions as three launches instead of one accumulate launch
   SVOC_WINO_WM=2                 2x2 wave layout (64-row tiles) for the Winograd kernels at C >= 128
@@ -62,6 +63,7 @@ VARIANTS = {
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
     "winograd_f43_natural_rows": ({"SVOC_W4_PERM": "0"}, DEC),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),
+    "wn_short_inputs_two_convolutions": ({"SVOC_WN_SMALL_F25": "0"}, SMALL + " or test_coupling or test_flow"),
     "winograd_2x2": ({"SVOC_WINO_F4": "0", "SVOC_WINO_WM": "2"}, DEC),
     "wn_no_ksplit": ({"SVOC_WN_KSPLIT": "0"}, WNS),
     "wn_generic_loops": ({"SVOC_WN_CT": "0"}, WNS),

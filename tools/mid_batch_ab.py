@@ -12,7 +12,7 @@ net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}, strict=False)
 net = net.cuda().eval()
 tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("SVOC_")) or "default"
-for (B, T) in ((2, 512), (4, 512), (8, 256), (8, 512), (4, 1024)):
+for (B, T) in ((2, 512), (4, 512), (6, 512), (8, 512), (4, 1024), (12, 512)):
     mel = torch.from_numpy(sw.synthetic_mel(1, B, T)).cuda(); eps = torch.from_numpy(sw.synthetic_eps(1, B, T)).cuda()
     ln = torch.full((B,), T, dtype=torch.int64).cuda()
     for _ in range(4):
