@@ -48,7 +48,11 @@ struct W4Geo {
   static constexpr int NWT = 32 * NCT;                    // windows per workgroup tile
   static constexpr int W = 4 * NWT;                       // D = 1: output columns per workgroup tile
   static constexpr int NE = NWT + (G - 1) * D;            // windows staged per row and stage
-  static constexpr int PQ = NE;                           // plane row stride
+  // plane row stride: NE rounded up so that a plane (KS rows) is a multiple of 64 floats - the producers' six to ten stores of a window
+  // (one per plane, PLANE floats apart) then pair up as ds_write2st64_b32 (offsets in units of 256 bytes): half the store instructions
+  // of the producer-bound 64- / 32-row layouts (round 4; the 128-row layout's planes happened to be multiples of 64 already)
+  static constexpr int PQA = KS >= 64 ? 1 : 64 / KS;
+  static constexpr int PQ = (NE + PQA - 1) / PQA * PQA;
   static constexpr int XOFF = -((PADT * D + 3) & ~3);     // D = 1: raw tile starts at 4 w0 + XOFF (multiple of 4)
   static constexpr int LEAD = -XOFF - PADT * D;           // D = 1: raw index of d0 of window w0
   // raw tile columns.  D = 1: d5 of the last window + 1.  D > 1: first sample f(w0) = 4 D b0 + ph0 - PADT D rounded down to a
