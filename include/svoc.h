@@ -294,9 +294,12 @@ int svoc_fold_weight_norm(void* stream, const float* weight_v, const float* weig
 int svoc_conv1d(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias,
                 const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation,
                 float pre_slope);
-/* The same operation for kernel_size 3 / 7 / 11, dilation 1 / 3 / 5, Cin >= 64, channel counts multiples of 32 and
- * L % 4 == 0, computed in Winograd form (F(4,3), csrc/conv_wino4.hip; F(2,3), csrc/conv_wino.hip, with SVOC_WINO_F4=0): what the
- * decoder's C >= 64 stages run.
+/* The same operation for kernel_size 3 / 7 / 11, dilation 1 / 3 / 5, channel counts multiples of 32 (Cin >= 64, or Cin = Cout = 32)
+ * and L % 4 == 0, computed in Winograd form: F(4,3) (csrc/conv_wino4.hip: Cout in 128- / 64-row blocks with an even number of
+ * 32-channel chunks, or the single 32 x 32 block of the last MRF stage) - what every ResBlock convolution of the decoder runs;
+ * F(2,3) (csrc/conv_wino.hip) for the other shapes and with SVOC_WINO_F4=0.  svoc_stats_executed_flops tells which form ran.
+ * (Inside the decoder the grouped launches additionally hand tensors over window-major between a dilated convolution and the one
+ * behind it, and merge the three chains' last convolutions: csrc/conv_wino4.hip, csrc/conv_wino4_acc.hip - not reachable from here.)
  * Unit-test entry; returns SVOC_ERR_UNSUPPORTED for other shapes. */
 int svoc_conv1d_winograd(void* stream, const float* x, const float* weight_v, const float* weight_g, const float* bias,
                          const float* residual, float* y, int B, int Cin, int Cout, int L, int kernel_size, int dilation,

@@ -847,6 +847,30 @@ def test_c5_full_size(M, net):
     assert rms <= 1e-3 and rms / ref <= 1e-4, ("middle slice", rms, rms / ref)
 
 
+def test_large_batch_awkward_length_vs_oracle(M, net):
+    """9 x 509 frames: large enough for the grouped F(4,3) launches, the window-major hand-over and the merged accumulate launch,
+    with stage lengths (4072, 32576, 65152, 130304) that are multiples of neither 12 nor 20 - the last q block of every dilated
+    row is partial, edge tiles take the clamped paths.  Oracle: the last 64 frames of a ragged utterance and of a full one, and 64
+    frames from the middle of a third, each with 192 frames of real context (receptive field 128)."""
+    Bn, Tn = 9, 509
+    mel = sw.synthetic_mel(1007, Bn, Tn); eps = sw.synthetic_eps(1007, Bn, Tn)
+    ln = np.full((Bn,), Tn, dtype=np.int64); ln[3] = 401
+    o1 = net.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=0.667, eps=T(eps).cuda())[0]
+    assert o1.shape == (Bn, 1, Tn * 256) and torch.isfinite(o1).all()
+    sd = sdT(cases.full_model_weights())
+    for b, f0 in ((3, 401 - 64), (8, Tn - 64), (5, 230)):
+        end = int(ln[b]); ctx = 192
+        a, e2 = max(0, f0 - ctx), min(Tn, f0 + 64 + ctx)
+        valid = max(0, min(end, e2) - a)
+        with torch.no_grad():
+            o_ref, *_ = O.infer(sd, T(mel[b:b + 1, :, a:e2]), torch.tensor([valid]), T(eps[b:b + 1, :, a:e2]), 0.667)
+        got = o1[b, 0, f0 * 256:(f0 + 64) * 256].cpu().numpy()
+        want = o_ref[0, 0, (f0 - a) * 256:(f0 - a + 64) * 256].numpy()
+        err = got - want
+        rms, ref = float(np.sqrt((err ** 2).mean())), float(np.sqrt((want ** 2).mean()))
+        assert rms <= 1e-3 and rms / ref <= 1e-4, (b, f0, rms, rms / ref)
+
+
 def test_c3_full_size_with_speaker_conditioning(M):
     """BASELINE.json configs[2] (iitp_base_ms, batch 32 x 512): SynthesizerTrn.infer hard-codes g=None (models.py:332), so
     the speaker-conditioned path is exercised where the reference can run it, at module level, at FULL size:
