@@ -24,6 +24,7 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 template <int K, int D, int NRT = 4, int PERM = 0, int KSDIV = 1>
 struct W4Geo {
   static_assert(PERM == 0 || D == 1, "a window-major input belongs to an undilated convolution (the c2 behind a dilated c1)");
+  static constexpr int DIL = D;
   static constexpr int NCT = 4 / NRT;                     // column tiles (of 32 windows) per workgroup
   static constexpr int KS = (NRT == 1 ? (K == 3 ? 16 : 8) : (NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32))) / KSDIV;   // channels per stage
   static_assert(KS >= 8, "a stage is at least one k-group");

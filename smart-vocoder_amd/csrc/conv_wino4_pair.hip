@@ -1,0 +1,423 @@
+// One ResBlock1 iteration - c1 (dilation D1) -> lrelu -> c2 (dilation 1) -> + x (reference modules.py:212-219) - of the C = 32 MRF stage
+// in ONE launch, both convolutions in Winograd F(4,3) form, the intermediate tile kept in LDS (round 4).
+//
+// Conv by conv (conv_wino4.hip, one row tile per workgroup) the C = 32 stage moves five tensor passes per iteration (x in, c1 out, c1 in,
+// x as residual, y out) where the fused direct-form kernel of round 1 moved two, and its k = 3 members are HBM-bound.  With one row tile
+// a workgroup holds ALL 32 channels of its columns, so the c1 tile can feed the c2 of the same workgroup: the consumers' c1 epilogue
+// writes lrelu(c1 + bias) - zero outside [0, L), c2's padding - into an LDS tile that IS the raw tile of c2 (32 rows x 4 NWC1 columns,
+// 64 KB; c1's own raw staging rows alias its head, they are dead by then), the producers transform c2's stages from it, and c2's
+// epilogue adds x from global (L2-hot: c1's producers have just read it) and stores.  Per tile: c1 computes NWC1 = (128 / D1) D1
+// windows from the q-block-aligned column m0 at or below c2's raw origin; c2 keeps NW2 windows (124 ... 117 of 128 lanes), the largest
+// count whose raw columns lie inside c1's; tiles advance by 4 NW2 columns (c1 recomputes the 2 x halo: 3 - 9 %).  One extra workgroup
+// barrier per tile (the intermediate tile is complete) and one exposed producer pass (c2's first stage) against what is saved: c1's
+// 16-byte stores, c2's global staging and 3 of 5 tensor passes.  Eight-channel stages for every member (k = 3 too: the 16-channel
+// planes would not fit beside the intermediate tile); two plane sets.
+#include "svoc_internal.h"
+#include "wino_common.h"
+#include "conv_wino4.h"
+#include "conv_wino4_consume.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace svoc {
+
+struct PairMember {
+  const float* x; long long x_bs; int x_ld;                // input = residual [B][32][x_ld]
+  float* y; long long y_bs; int y_ld;                       // output
+  const float* wp1; const float* bias1;                     // c1: F(4,3) image, bias
+  const float* wp2; const float* bias2;                     // c2
+};
+struct PairGroup { PairMember m[3]; int end[3]; int L; int B; int xcd; unsigned flags; float slope; };   // members k = 11, 7, 3; end[i] = first tile id behind member i
+
+template <int K, int D1>
+struct PairGeo {
+  static constexpr int KD = K == 3 ? 2 : 1;                 // eight channels per stage for every member
+  using G1 = W4Geo<K, D1, 1, 0, KD>;
+  using G2 = W4Geo<K, 1, 1, 0, KD>;
+  static_assert(G1::KS == 8 && G2::KS == 8, "eight-channel stages");
+  static constexpr int NWC1 = (128 / D1) * D1;              // c1 windows per tile: whole q blocks
+  static constexpr int COLS1 = 4 * NWC1;                    // columns of the intermediate tile
+  static constexpr int NW2 = (COLS1 - 4 * D1 + 4 - G2::LEAD - 6) / 4 - G2::G + 2;      // c2 windows kept per tile
+  static constexpr int NE2 = NW2 + G2::G - 1;               // c2 plane entries needed
+  static constexpr int W2 = 4 * NW2;                        // tile step in output columns
+  static constexpr int MIDS = COLS1;                        // row stride of the intermediate tile
+  static constexpr int MID_FLOATS = 32 * MIDS;
+  static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+  static constexpr int PLFMAX = cmax(G1::PLF, G2::PLF);
+  static_assert(G1::RAW_FLOATS <= MID_FLOATS, "c1's raw staging rows alias the head of the intermediate tile");
+  static_assert((4 * D1 - 4) + G2::LEAD + 4 * (NE2 - 1) + 6 <= COLS1, "c2's raw columns lie inside c1's");
+  static constexpr int LDS_FLOATS = MID_FLOATS + 2 * PLFMAX;
+};
+
+template <int K, int D1>
+__device__ __forceinline__ void pair_member(const PairMember& pm, const PairGroup& g, const int first, const int vend, const int blk, const int G_) {
+  using PG = PairGeo<K, D1>;
+  using G1 = typename PG::G1;
+  using G2 = typename PG::G2;
+  constexpr int NWC1 = PG::NWC1, NW2 = PG::NW2, NE2 = PG::NE2, W2 = PG::W2, MIDS = PG::MIDS, PLFMAX = PG::PLFMAX, NACC = 8;
+  constexpr int PADT = G1::PADT;
+  if (vend <= first) return;
+  int v0 = blk - first % G_;
+  if (v0 < 0) v0 += G_;
+  v0 += first;
+  if (v0 >= vend) return;
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  float* const mid = wl;                                    // intermediate tile [32][MIDS]; c1's raw rows [8][RAW1] alias its head
+  float* const raw = wl;
+  float* const pl = wl + PG::MID_FLOATS;                    // two plane sets of PLFMAX floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = g.L;
+  const int ntn = (L + W2 - 1) / W2;
+  const int ntiles_all = vend - first;
+  const int my_tiles = (vend - v0 + G_ - 1) / G_;
+  // tile v -> (batch element, first output column n2 of c2, origin m0 of c1 / of the intermediate tile, offset of c2's raw origin in it)
+  auto locate = [&](int v, int& bz_, int& n2_, int& m0_, int& off2_) {
+    const int tl = xcd_linear(v - first, ntiles_all, g.xcd);
+    bz_ = tl / ntn;
+    n2_ = (tl - bz_ * ntn) * W2;
+    const int xs2 = n2_ + G2::XOFF;                         // c2's raw origin: a multiple of four, >= -8
+    const int b0 = (xs2 + 4 * D1 * 4) / (4 * D1) - 4;       // floor(xs2 / 4 D1)
+    m0_ = 4 * D1 * b0;
+    off2_ = xs2 - m0_;
+  };
+  // c1's raw tile for the tile whose windows start at column m0: first raw column xs (multiple of four), raw index of window 0's d0
+  auto origin1 = [&](int m0_, int& xs_, int& lead_) {
+    const int f0 = m0_ - PADT * D1;
+    xs_ = f0 & ~3;
+    lead_ = f0 - xs_;
+  };
+  int s_ = 0;                                               // plane set of the next stage (both sides count stages alike)
+
+  if (wave >= 4) {
+    // ================================================================= producers
+    const int pw_ = wave - 4;
+    if (g.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
+    constexpr int RPW = 2, RAW1 = G1::RAW, R4 = RAW1 / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
+    constexpr int NE1 = G1::NE, NIW1 = RPW * NE1, TPW1 = (NIW1 + 63) / 64, PQ1 = G1::PQ, PLANE1 = G1::PLANE, ND = G1::ND;
+    constexpr int NIW2 = RPW * NE2, TPW2 = (NIW2 + 63) / 64, PQ2 = G2::PQ, PLANE2 = G2::PLANE, LEAD2 = G2::LEAD;
+    const long long ldb = (long long)pm.x_ld * 4;
+    const float slope = g.slope;
+    unsigned goff[SPW];
+    float* rdst[SPW];
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      const int it = min(lane + 64 * u, NGW - 1);
+      const int row = RPW * pw_ + it / R4, g4 = it % R4;
+      goff[u] = (unsigned)(row * pm.x_ld + 4 * g4) * 4u;
+      rdst[u] = raw + row * RAW1 + 4 * g4;
+    }
+    int t1off[TPW1], t1dst[TPW1];                            // c1 transform items: raw offset of d0 (without the tile's lead), plane entry
+#pragma unroll
+    for (int u = 0; u < TPW1; ++u) {
+      const int it = min(lane + 64 * u, NIW1 - 1);
+      const int row = RPW * pw_ + it / NE1, e = it % NE1;
+      const int qe = e / D1, pe = e - qe * D1;
+      t1off[u] = row * RAW1 + 4 * D1 * qe + pe;
+      t1dst[u] = row * PQ1 + e;
+    }
+    int t2src[TPW2], t2dst[TPW2];                            // c2 transform items: row and window of the intermediate tile, plane entry
+#pragma unroll
+    for (int u = 0; u < TPW2; ++u) {
+      const int it = min(lane + 64 * u, NIW2 - 1);
+      const int row = RPW * pw_ + it / NE2, e = it % NE2;
+      t2src[u] = row * MIDS + 4 * e;
+      t2dst[u] = row * PQ2 + e;
+    }
+    float4 v[SPW];
+    auto issue = [&](int bz_, int xs_, int ch) {
+      const char* cb = reinterpret_cast<const char*>(pm.x + (long long)bz_ * pm.x_bs) + (long long)ch * 8 * ldb;
+      if (xs_ >= 0 && xs_ + RAW1 <= L) {
+        const char* ct = cb + (long long)xs_ * 4;
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) v[u] = *reinterpret_cast<const float4*>(ct + goff[u]);
+      } else {
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) {
+          const int it = min(l_ + 64 * u, NGW - 1);
+          const int row = RPW * pw_ + it / R4, tg = xs_ + 4 * (it % R4);
+          v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)((tg >= 0 && tg + 3 < L) ? tg : 0) * 4);
+        }
+      }
+    };
+    int bz, n2, m0, off2, xs1, lead1;
+    locate(v0, bz, n2, m0, off2);
+    origin1(m0, xs1, lead1);
+    issue(bz, xs1, 0);
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      int bzn = bz, n2n = n2, m0n = m0, off2n = off2, xs1n = xs1, lead1n = lead1;
+      const bool more = ti + 1 < my_tiles;
+      if (more) { locate(v0 + (ti + 1) * G_, bzn, n2n, m0n, off2n); origin1(m0n, xs1n, lead1n); }
+      const bool interior = xs1 >= 0 && xs1 + RAW1 <= L;
+      // ---------------- phase A: c1's four stages (8 channels each) from global
+      for (int ch = 0; ch < 4; ++ch) {
+        if (interior) {
+#pragma unroll
+          for (int u = 0; u < SPW; ++u) {
+            if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
+              float4 q = v[u];
+              wino_lrelu4(q, slope);
+              *reinterpret_cast<float4*>(rdst[u]) = q;
+            }
+          }
+        } else {                                             // L is a multiple of four: a 16-byte group is inside the row or padding
+          int l_ = lane;
+          asm volatile("" : "+v"(l_));
+#pragma unroll
+          for (int u = 0; u < SPW; ++u) {
+            if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
+              const int tg = xs1 + 4 * ((l_ + 64 * u) % R4);
+              float4 q = v[u];
+              if (tg < 0 || tg + 3 >= L) q = make_float4(0.f, 0.f, 0.f, 0.f);
+              wino_lrelu4(q, slope);
+              *reinterpret_cast<float4*>(rdst[u]) = q;
+            }
+          }
+        }
+        if (ch + 1 < 4) issue(bz, xs1, ch + 1);
+        float* const pb = pl + s_ * PLFMAX;
+#pragma unroll
+        for (int u = 0; u < TPW1; ++u) {
+          if (64 * (u + 1) <= NIW1 || lane < NIW1 - 64 * u) {
+            const float* r = raw + t1off[u] + lead1;
+            float* o = pb + t1dst[u];
+            float d0, d1, d2, d3, d4, d5;
+            if constexpr (D1 == 1) {                         // lead1 is 3 (k = 3, 11) or 1 (k = 7): the compile-time forms of conv_wino4.hip
+              if constexpr (G1::LEAD == 3) {
+                const float4 fm = *reinterpret_cast<const float4*>(r + 1);
+                d0 = r[0]; d1 = fm.x; d2 = fm.y; d3 = fm.z; d4 = fm.w; d5 = r[5];
+              } else {
+                const float4 fa = *reinterpret_cast<const float4*>(r - 1), fb = *reinterpret_cast<const float4*>(r + 3);
+                d0 = fa.y; d1 = fa.z; d2 = fa.w; d3 = fb.x; d4 = fb.y; d5 = fb.z;
+              }
+            } else {
+              d0 = r[0]; d1 = r[D1]; d2 = r[2 * D1]; d3 = r[3 * D1]; d4 = r[4 * D1]; d5 = r[5 * D1];
+            }
+            const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);
+            const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+            o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+            o[PLANE1] = a_ + b_;
+            o[2 * PLANE1] = a_ - b_;
+            o[3 * PLANE1] = c_ + e_;
+            o[4 * PLANE1] = c_ - e_;
+            o[5 * PLANE1] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+            if constexpr (ND > 0) { o[6 * PLANE1] = d1; o[7 * PLANE1] = d2; o[8 * PLANE1] = d3; o[9 * PLANE1] = d4; }
+          }
+        }
+        __syncthreads();                                     // B_s: plane set complete
+        s_ ^= 1;
+      }
+      __syncthreads();                                       // X: the consumers have written the intermediate tile
+      // ---------------- phase B: c2's four stages from the intermediate tile; the next tile's first raw rows are requested meanwhile
+      if (more) issue(bzn, xs1n, 0);
+      for (int ch = 0; ch < 4; ++ch) {
+        float* const pb = pl + s_ * PLFMAX;
+        const float* const mrow = mid + ch * 8 * MIDS + off2;
+#pragma unroll
+        for (int u = 0; u < TPW2; ++u) {
+          if (64 * (u + 1) <= NIW2 || lane < NIW2 - 64 * u) {
+            const float* r = mrow + t2src[u];
+            float* o = pb + t2dst[u];
+            float d0, d1, d2, d3, d4, d5;
+            if constexpr (LEAD2 == 3) {
+              const float4 fm = *reinterpret_cast<const float4*>(r + 4);
+              d0 = r[3]; d1 = fm.x; d2 = fm.y; d3 = fm.z; d4 = fm.w; d5 = r[8];
+            } else {
+              const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
+              d0 = fa.y; d1 = fa.z; d2 = fa.w; d3 = fb.x; d4 = fb.y; d5 = fb.z;
+            }
+            const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);
+            const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+            o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+            o[PLANE2] = a_ + b_;
+            o[2 * PLANE2] = a_ - b_;
+            o[3 * PLANE2] = c_ + e_;
+            o[4 * PLANE2] = c_ - e_;
+            o[5 * PLANE2] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+            if constexpr (ND > 0) { o[6 * PLANE2] = d1; o[7 * PLANE2] = d2; o[8 * PLANE2] = d3; o[9 * PLANE2] = d4; }
+          }
+        }
+        __syncthreads();
+        s_ ^= 1;
+      }
+      bz = bzn; n2 = n2n; m0 = m0n; off2 = off2n; xs1 = xs1n; lead1 = lead1n;
+    }
+    return;
+  }
+
+  // =================================================================== consumers: column tile `wave` of the workgroup (one row tile)
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int uu = wave * 32 + l31;                           // this lane's window of the tile
+  const unsigned plbase = (unsigned)(size_t)pl;
+  const unsigned wlane = (unsigned)lane * 16u;
+  f32x16 M[NACC];
+  WinoArgs p1{}, p2{};
+  p1.wp = pm.wp1; p1.nchunks = 1;
+  p2.wp = pm.wp2; p2.nchunks = 1;
+  const float slope = g.slope;
+  auto init_bias = [&](const float* bias) {                 // the bias starts in M1 (part of all four outputs)
+    const float* bq = bias + 4 * hi;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) M[q][i] = q == 1 ? bq[(i & 3) + 8 * (i >> 2)] : 0.f;
+  };
+  auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
+    constexpr int Q = decltype(q_c)::value;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * Q + r;
+      const float t1 = M[1][i] + M[2][i], t2 = M[1][i] - M[2][i], t3 = M[3][i] + M[4][i], t4 = M[3][i] - M[4][i];
+      float y0 = M[0][i] + (t1 + t3);
+      float y1 = __builtin_fmaf(2.f, t4, t2);
+      float y2 = __builtin_fmaf(4.f, t3, t1);
+      float y3 = __builtin_fmaf(8.f, t4, t2) + M[5][i];
+      if constexpr (G1::ND > 0) { y1 += M[6][i]; y2 += M[7][i]; }
+      vo[r] = make_float4(y0, y1, y2, y3);
+    }
+  };
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int bz, n2, m0, off2;
+    locate(v0 + ti * G_, bz, n2, m0, off2);
+    // ---------------- phase A: c1 into the accumulators
+    init_bias(pm.bias1);
+    acc3_consume<G1, NACC, 2>(p1, M, plbase, PLFMAX, 0, s_, wlane, (unsigned)(hi * G1::PQ + uu) * 4u);
+    // ---- epilogue A: lrelu(c1) -> the intermediate tile, zero outside [0, L).  Window uu = q block uu / D1, phase uu % D1: its four
+    // outputs are D1 columns apart
+    if (uu < NWC1) {
+      const int bq = uu / D1, ph = uu - bq * D1;
+      const int c0 = 4 * D1 * bq + ph;                       // column of output 0 inside the tile
+      const int n0 = m0 + c0;
+      auto quarter = [&](auto q_c) {
+        constexpr int Q = decltype(q_c)::value;
+        float4 vo[4];
+        ytrans(q_c, vo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          wino_lrelu4(vo[r], slope);
+          float* d = mid + (8 * Q + 4 * hi + r) * MIDS + c0;
+          if constexpr (D1 == 1) {
+            if (n0 < 0 || n0 >= L) vo[r] = make_float4(0.f, 0.f, 0.f, 0.f);      // L and n0 are multiples of four
+            *reinterpret_cast<float4*>(d) = vo[r];
+          } else {
+            d[0] = (n0 >= 0 && n0 < L) ? vo[r].x : 0.f;
+            d[D1] = (n0 + D1 >= 0 && n0 + D1 < L) ? vo[r].y : 0.f;
+            d[2 * D1] = (n0 + 2 * D1 >= 0 && n0 + 2 * D1 < L) ? vo[r].z : 0.f;
+            d[3 * D1] = (n0 + 3 * D1 >= 0 && n0 + 3 * D1 < L) ? vo[r].w : 0.f;
+          }
+        }
+      };
+      quarter(std::integral_constant<int, 0>{});
+      quarter(std::integral_constant<int, 1>{});
+      quarter(std::integral_constant<int, 2>{});
+      quarter(std::integral_constant<int, 3>{});
+    }
+    __syncthreads();                                         // X: the intermediate tile is complete
+    // ---------------- phase B: c2, then + x and store
+    init_bias(pm.bias2);
+    acc3_consume<G2, NACC, 2>(p2, M, plbase, PLFMAX, 0, s_, wlane, (unsigned)(hi * G2::PQ + uu) * 4u);
+    const int ne = n2 + 4 * uu;
+    if (uu < NW2 && ne < L) {
+      char* const ybase = reinterpret_cast<char*>(pm.y + (long long)bz * pm.y_bs + (long long)(4 * hi) * pm.y_ld + ne);
+      const char* const rbase = reinterpret_cast<const char*>(pm.x + (long long)bz * pm.x_bs + (long long)(4 * hi) * pm.x_ld + ne);
+      const size_t ylb = (size_t)pm.y_ld * 4, rlb = (size_t)pm.x_ld * 4;
+      auto quarter = [&](auto q_c) {
+        constexpr int Q = decltype(q_c)::value;
+        float4 rv[4], vo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * Q + r) * rlb);
+        ytrans(q_c, vo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w;
+          *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q + r) * ylb) = vo[r];
+        }
+      };
+      quarter(std::integral_constant<int, 0>{});
+      quarter(std::integral_constant<int, 1>{});
+      quarter(std::integral_constant<int, 2>{});
+      quarter(std::integral_constant<int, 3>{});
+    }
+  }
+}
+
+template <int D1>
+__global__ void __launch_bounds__(512, 2) conv_wino4_pair_kernel(const PairGroup g) {
+  const int b = blockIdx.x, G_ = gridDim.x;
+  pair_member<11, D1>(g.m[0], g, 0, g.end[0], b, G_);
+  __syncthreads();
+  pair_member<7, D1>(g.m[1], g, g.end[0], g.end[1], b, G_);
+  __syncthreads();
+  pair_member<3, D1>(g.m[2], g, g.end[1], g.end[2], b, G_);
+}
+
+template <int D1>
+static int pair_launch_d(PairGroup& g, hipStream_t st) {
+  constexpr int lds = PairGeo<11, D1>::cmax(PairGeo<11, D1>::LDS_FLOATS, PairGeo<11, D1>::cmax(PairGeo<7, D1>::LDS_FLOATS, PairGeo<3, D1>::LDS_FLOATS)) * 4;
+  static_assert(lds <= 160 * 1024, "tile does not fit");
+  const int w2[3] = {PairGeo<11, D1>::W2, PairGeo<7, D1>::W2, PairGeo<3, D1>::W2};
+  long long total = 0;
+  for (int i = 0; i < 3; ++i) {
+    total += (long long)((g.L + w2[i] - 1) / w2[i]) * g.B;
+    if (total > 0x7fffffffLL) return 1;
+    g.end[i] = (int)total;
+  }
+  auto kern = conv_wino4_pair_kernel<D1>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, st, g);
+  return SVOC_OK;
+}
+
+bool wino4_pair_enabled() {
+  static const bool on = wino4_c32_enabled() && !(getenv("SVOC_W4_PAIR") && atoi(getenv("SVOC_W4_PAIR")) == 0);      // SVOC_W4_PAIR=0: conv by conv
+  return on;
+}
+// tiles a launch would have (the engine's size gate)
+long long wino4_pair_tiles(int L, int B, int D1) {
+  const int w = D1 == 1 ? PairGeo<11, 1>::W2 : (D1 == 3 ? PairGeo<11, 3>::W2 : PairGeo<11, 5>::W2);
+  return 3LL * B * ((L + w - 1) / w);
+}
+// The three chains' c1 (dilation D1) -> c2 pairs of one MRF step at C = 32; members k = 11, 7, 3.  1 = not eligible.
+int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2, const float* const* x, float* const* y, long long bs, int ld,
+                      int B, int L, int D1, float slope, hipStream_t st) {
+  if (!wino4_pair_enabled() || B <= 0 || (L & 3) || (ld & 3) || (bs & 3) || !(D1 == 1 || D1 == 3 || D1 == 5)) return 1;
+  static const int ks[3] = {11, 7, 3};
+  PairGroup g{};
+  double flops = 0, exec = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (!pw1[i] || !pw2[i] || pw1[i]->K != ks[i] || pw2[i]->K != ks[i] || pw1[i]->Cin != 32 || pw1[i]->Cout != 32 || pw2[i]->Cin != 32 ||
+        pw2[i]->Cout != 32 || !pw1[i]->wp4.p || !pw2[i]->wp4.p) return 1;
+    if ((reinterpret_cast<uintptr_t>(x[i]) & 15) || (reinterpret_cast<uintptr_t>(y[i]) & 15)) return 1;
+    g.m[i].x = x[i]; g.m[i].x_bs = bs; g.m[i].x_ld = ld;
+    g.m[i].y = y[i]; g.m[i].y_bs = bs; g.m[i].y_ld = ld;
+    g.m[i].wp1 = pw1[i]->wp4.f(); g.m[i].bias1 = pw1[i]->bias.f();
+    g.m[i].wp2 = pw2[i]->wp4.f(); g.m[i].bias2 = pw2[i]->bias.f();
+    const double f = (pw1[i]->flops_per_col + pw2[i]->flops_per_col) * (double)B * (double)L;
+    const int G = (ks[i] + 1) / 4;
+    flops += f;
+    exec += f * (1.5 * G + (G - 1)) / (double)ks[i];
+  }
+  g.L = L; g.B = B; g.xcd = xcd_mapping_enabled(); g.slope = slope;
+  static const bool prio = !(getenv("SVOC_W4_PRIO") && atoi(getenv("SVOC_W4_PRIO")) == 0);
+  g.flags = prio ? 0x100u : 0u;
+  stats_add_conv(flops, 6, exec);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "wino4P Ci32   Co32   k11/7/3 c1(d%d)+c2 N%-7d B%-3d", D1, L, B);
+    prof_idx = prof_begin(st, d, flops);
+  }
+  const int rc = D1 == 1 ? pair_launch_d<1>(g, st) : (D1 == 3 ? pair_launch_d<3>(g, st) : pair_launch_d<5>(g, st));
+  prof_end(st, prof_idx);
+  if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+
+}  // namespace svoc

@@ -530,6 +530,27 @@ struct Generator {
         if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
         return SVOC_OK;
       };
+      // C = 32, every step but the last: c1 -> c2 of the three chains in ONE launch, the intermediate tile in LDS (conv_wino4_pair.hip)
+      if (C == 32 && nk == 3 && !last && wino4_pair_enabled() &&
+          wino4_pair_tiles(L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= 2LL * device_cu_count()) {
+        const PackedWino* p1[3]; const PackedWino* p2[3];
+        const float* xi[3]; float* yo[3];
+        for (int q = 0; q < nk; ++q) {
+          const int j = order[q];
+          float* A = bufs[3 + 2 * j];
+          float* Bf = bufs[4 + 2 * j];
+          p1[q] = rbs[stage * nk + j]->w1[it].get();
+          p2[q] = rbs[stage * nk + j]->w2[it].get();
+          xi[q] = cur[j];
+          yo[q] = (cur[j] == A) ? Bf : A;                   // never in place: neighbouring tiles read the input's halo
+        }
+        const int rp = launch_wino4_pair(p1, p2, xi, yo, bs, ld, B, L, rbs[stage * nk]->c1[it]->dil, 0.1f, st);
+        if (rp < 0) return rp;
+        if (rp == 0) {
+          for (int q = 0; q < nk; ++q) cur[order[q]] = yo[q];
+          continue;
+        }
+      }
       bool all_w = true, all_w2 = true;
       const PackedConv* pcs2[3];
       const PackedWino* pws2[3];
