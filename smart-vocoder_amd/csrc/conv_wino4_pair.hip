@@ -1,5 +1,5 @@
 // One ResBlock1 iteration - c1 (dilation D1) -> lrelu -> c2 (dilation 1) -> + x (reference modules.py:212-219) - of the C = 32 MRF stage
-// in ONE launch, both convolutions in Winograd F(4,3) form, the intermediate tile kept in LDS (round 4).
+// (and, NRT = 2, the undilated iteration of the C = 64 stage) in ONE launch, both convolutions in Winograd F(4,3) form, the intermediate tile kept in LDS (round 4).
 //
 // Conv by conv (conv_wino4.hip, one row tile per workgroup) the C = 32 stage moves five tensor passes per iteration (x in, c1 out, c1 in,
 // x as residual, y out) where the fused direct-form kernel of round 1 moved two, and its k = 3 members are HBM-bound.  With one row tile
@@ -30,20 +30,22 @@ struct PairMember {
   const float* wp2; const float* bias2;                     // c2
 };
 struct PairGroup { PairMember m[3]; int end[3]; int L; int B; int xcd; unsigned flags; float slope; };   // members k = 11, 7, 3; end[i] = first tile id behind member i
+// NRT = 1: C = 32 (1 x 4 consumers, 128 windows per tile); NRT = 2: C = 64 (2 x 2 consumers, 64 windows per tile, two 32-channel chunks)
 
-template <int K, int D1>
+template <int K, int D1, int NRT>
 struct PairGeo {
-  static constexpr int KD = K == 3 ? 2 : 1;                 // eight channels per stage for every member
-  using G1 = W4Geo<K, D1, 1, 0, KD>;
-  using G2 = W4Geo<K, 1, 1, 0, KD>;
-  static_assert(G1::KS == 8 && G2::KS == 8, "eight-channel stages");
-  static constexpr int NWC1 = (128 / D1) * D1;              // c1 windows per tile: whole q blocks
+  static constexpr int KD = K == 3 ? 2 : 1;                 // 8 (C = 32) / 16 (C = 64) channels per stage for every member: four stages per phase
+  using G1 = W4Geo<K, D1, NRT, 0, KD>;
+  using G2 = W4Geo<K, 1, NRT, 0, KD>;
+  static constexpr int KS = G1::KS, ROWS = 32 * NRT, NWT = G1::NWT;
+  static_assert(G1::KS == 8 * NRT && G2::KS == 8 * NRT && ROWS / KS == 4, "four stages per phase");
+  static constexpr int NWC1 = (NWT / D1) * D1;              // c1 windows per tile: whole q blocks
   static constexpr int COLS1 = 4 * NWC1;                    // columns of the intermediate tile
   static constexpr int NW2 = (COLS1 - 4 * D1 + 4 - G2::LEAD - 6) / 4 - G2::G + 2;      // c2 windows kept per tile
   static constexpr int NE2 = NW2 + G2::G - 1;               // c2 plane entries needed
   static constexpr int W2 = 4 * NW2;                        // tile step in output columns
   static constexpr int MIDS = COLS1;                        // row stride of the intermediate tile
-  static constexpr int MID_FLOATS = 32 * MIDS;
+  static constexpr int MID_FLOATS = ROWS * MIDS;
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int PLFMAX = cmax(G1::PLF, G2::PLF);
   static_assert(G1::RAW_FLOATS <= MID_FLOATS, "c1's raw staging rows alias the head of the intermediate tile");
@@ -51,20 +53,20 @@ struct PairGeo {
   static constexpr int LDS_FLOATS = MID_FLOATS + 2 * PLFMAX;
 };
 
-template <int K, int D1>
+template <int K, int D1, int NRT>
 __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGroup& g, const int first, const int vend, const int blk, const int G_) {
-  using PG = PairGeo<K, D1>;
+  using PG = PairGeo<K, D1, NRT>;
   using G1 = typename PG::G1;
   using G2 = typename PG::G2;
   constexpr int NWC1 = PG::NWC1, NW2 = PG::NW2, NE2 = PG::NE2, W2 = PG::W2, MIDS = PG::MIDS, PLFMAX = PG::PLFMAX, NACC = 8;
-  constexpr int PADT = G1::PADT;
+  constexpr int PADT = G1::PADT, KS = PG::KS;
   if (vend <= first) return;
   int v0 = blk - first % G_;
   if (v0 < 0) v0 += G_;
   v0 += first;
   if (v0 >= vend) return;
   extern __shared__ __attribute__((aligned(16))) float wl[];
-  float* const mid = wl;                                    // intermediate tile [32][MIDS]; c1's raw rows [8][RAW1] alias its head
+  float* const mid = wl;                                    // intermediate tile [C][MIDS]; c1's raw rows [KS][RAW1] alias its head
   float* const raw = wl;
   float* const pl = wl + PG::MID_FLOATS;                    // two plane sets of PLFMAX floats
   const int tid = threadIdx.x;
@@ -96,7 +98,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     // ================================================================= producers
     const int pw_ = wave - 4;
     if (g.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
-    constexpr int RPW = 2, RAW1 = G1::RAW, R4 = RAW1 / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
+    constexpr int RPW = KS / 4, RAW1 = G1::RAW, R4 = RAW1 / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
     constexpr int NE1 = G1::NE, NIW1 = RPW * NE1, TPW1 = (NIW1 + 63) / 64, PQ1 = G1::PQ, PLANE1 = G1::PLANE, ND = G1::ND;
     constexpr int NIW2 = RPW * NE2, TPW2 = (NIW2 + 63) / 64, PQ2 = G2::PQ, PLANE2 = G2::PLANE, LEAD2 = G2::LEAD;
     const long long ldb = (long long)pm.x_ld * 4;
@@ -129,7 +131,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     }
     float4 v[SPW];
     auto issue = [&](int bz_, int xs_, int ch) {
-      const char* cb = reinterpret_cast<const char*>(pm.x + (long long)bz_ * pm.x_bs) + (long long)ch * 8 * ldb;
+      const char* cb = reinterpret_cast<const char*>(pm.x + (long long)bz_ * pm.x_bs) + (long long)ch * KS * ldb;
       if (xs_ >= 0 && xs_ + RAW1 <= L) {
         const char* ct = cb + (long long)xs_ * 4;
 #pragma unroll
@@ -217,7 +219,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
       if (more) issue(bzn, xs1n, 0);
       for (int ch = 0; ch < 4; ++ch) {
         float* const pb = pl + s_ * PLFMAX;
-        const float* const mrow = mid + ch * 8 * MIDS + off2;
+        const float* const mrow = mid + ch * KS * MIDS + off2;
 #pragma unroll
         for (int u = 0; u < TPW2; ++u) {
           if (64 * (u + 1) <= NIW2 || lane < NIW2 - 64 * u) {
@@ -250,18 +252,20 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     return;
   }
 
-  // =================================================================== consumers: column tile `wave` of the workgroup (one row tile)
+  // =================================================================== consumers: row tile rt, column tile ct of the workgroup
   const int l31 = lane & 31, hi = lane >> 5;
-  const int uu = wave * 32 + l31;                           // this lane's window of the tile
+  const int rt = NRT == 2 ? (wave & 1) : 0, ct = NRT == 2 ? (wave >> 1) : wave;
+  const int uu = ct * 32 + l31;                             // this lane's window of the tile
   const unsigned plbase = (unsigned)(size_t)pl;
   const unsigned wlane = (unsigned)lane * 16u;
   f32x16 M[NACC];
   WinoArgs p1{}, p2{};
-  p1.wp = pm.wp1; p1.nchunks = 1;
-  p2.wp = pm.wp2; p2.nchunks = 1;
+  p1.wp = pm.wp1; p1.nchunks = NRT;
+  p2.wp = pm.wp2; p2.nchunks = NRT;
+  const int wt1 = __builtin_amdgcn_readfirstlane(rt * NRT * G1::WSLOTS * 4096), wt2 = __builtin_amdgcn_readfirstlane(rt * NRT * G2::WSLOTS * 4096);
   const float slope = g.slope;
   auto init_bias = [&](const float* bias) {                 // the bias starts in M1 (part of all four outputs)
-    const float* bq = bias + 4 * hi;
+    const float* bq = bias + 32 * rt + 4 * hi;
 #pragma unroll
     for (int q = 0; q < NACC; ++q)
 #pragma unroll
@@ -286,7 +290,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     locate(v0 + ti * G_, bz, n2, m0, off2);
     // ---------------- phase A: c1 into the accumulators
     init_bias(pm.bias1);
-    acc3_consume<G1, NACC, 2>(p1, M, plbase, PLFMAX, 0, s_, wlane, (unsigned)(hi * G1::PQ + uu) * 4u);
+    acc3_consume<G1, NACC, 2>(p1, M, plbase, PLFMAX, wt1, s_, wlane, (unsigned)(hi * G1::PQ + uu) * 4u);
     // ---- epilogue A: lrelu(c1) -> the intermediate tile, zero outside [0, L).  Window uu = q block uu / D1, phase uu % D1: its four
     // outputs are D1 columns apart
     if (uu < NWC1) {
@@ -300,7 +304,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           wino_lrelu4(vo[r], slope);
-          float* d = mid + (8 * Q + 4 * hi + r) * MIDS + c0;
+          float* d = mid + (32 * rt + 8 * Q + 4 * hi + r) * MIDS + c0;
           if constexpr (D1 == 1) {
             if (n0 < 0 || n0 >= L) vo[r] = make_float4(0.f, 0.f, 0.f, 0.f);      // L and n0 are multiples of four
             *reinterpret_cast<float4*>(d) = vo[r];
@@ -320,11 +324,11 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     __syncthreads();                                         // X: the intermediate tile is complete
     // ---------------- phase B: c2, then + x and store
     init_bias(pm.bias2);
-    acc3_consume<G2, NACC, 2>(p2, M, plbase, PLFMAX, 0, s_, wlane, (unsigned)(hi * G2::PQ + uu) * 4u);
+    acc3_consume<G2, NACC, 2>(p2, M, plbase, PLFMAX, wt2, s_, wlane, (unsigned)(hi * G2::PQ + uu) * 4u);
     const int ne = n2 + 4 * uu;
     if (uu < NW2 && ne < L) {
-      char* const ybase = reinterpret_cast<char*>(pm.y + (long long)bz * pm.y_bs + (long long)(4 * hi) * pm.y_ld + ne);
-      const char* const rbase = reinterpret_cast<const char*>(pm.x + (long long)bz * pm.x_bs + (long long)(4 * hi) * pm.x_ld + ne);
+      char* const ybase = reinterpret_cast<char*>(pm.y + (long long)bz * pm.y_bs + (long long)(32 * rt + 4 * hi) * pm.y_ld + ne);
+      const char* const rbase = reinterpret_cast<const char*>(pm.x + (long long)bz * pm.x_bs + (long long)(32 * rt + 4 * hi) * pm.x_ld + ne);
       const size_t ylb = (size_t)pm.y_ld * 4, rlb = (size_t)pm.x_ld * 4;
       auto quarter = [&](auto q_c) {
         constexpr int Q = decltype(q_c)::value;
@@ -346,28 +350,29 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
   }
 }
 
-template <int D1>
+template <int D1, int NRT>
 __global__ void __launch_bounds__(512, 2) conv_wino4_pair_kernel(const PairGroup g) {
   const int b = blockIdx.x, G_ = gridDim.x;
-  pair_member<11, D1>(g.m[0], g, 0, g.end[0], b, G_);
+  pair_member<11, D1, NRT>(g.m[0], g, 0, g.end[0], b, G_);
   __syncthreads();
-  pair_member<7, D1>(g.m[1], g, g.end[0], g.end[1], b, G_);
+  pair_member<7, D1, NRT>(g.m[1], g, g.end[0], g.end[1], b, G_);
   __syncthreads();
-  pair_member<3, D1>(g.m[2], g, g.end[1], g.end[2], b, G_);
+  pair_member<3, D1, NRT>(g.m[2], g, g.end[1], g.end[2], b, G_);
 }
 
-template <int D1>
+template <int D1, int NRT>
 static int pair_launch_d(PairGroup& g, hipStream_t st) {
-  constexpr int lds = PairGeo<11, D1>::cmax(PairGeo<11, D1>::LDS_FLOATS, PairGeo<11, D1>::cmax(PairGeo<7, D1>::LDS_FLOATS, PairGeo<3, D1>::LDS_FLOATS)) * 4;
+  using P11 = PairGeo<11, D1, NRT>;
+  constexpr int lds = P11::cmax(P11::LDS_FLOATS, P11::cmax(PairGeo<7, D1, NRT>::LDS_FLOATS, PairGeo<3, D1, NRT>::LDS_FLOATS)) * 4;
   static_assert(lds <= 160 * 1024, "tile does not fit");
-  const int w2[3] = {PairGeo<11, D1>::W2, PairGeo<7, D1>::W2, PairGeo<3, D1>::W2};
+  const int w2[3] = {P11::W2, PairGeo<7, D1, NRT>::W2, PairGeo<3, D1, NRT>::W2};
   long long total = 0;
   for (int i = 0; i < 3; ++i) {
     total += (long long)((g.L + w2[i] - 1) / w2[i]) * g.B;
     if (total > 0x7fffffffLL) return 1;
     g.end[i] = (int)total;
   }
-  auto kern = conv_wino4_pair_kernel<D1>;
+  auto kern = conv_wino4_pair_kernel<D1, NRT>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, st, g);
@@ -379,20 +384,26 @@ bool wino4_pair_enabled() {
   return on;
 }
 // tiles a launch would have (the engine's size gate)
-long long wino4_pair_tiles(int L, int B, int D1) {
-  const int w = D1 == 1 ? PairGeo<11, 1>::W2 : (D1 == 3 ? PairGeo<11, 3>::W2 : PairGeo<11, 5>::W2);
+long long wino4_pair_tiles(int C, int L, int B, int D1) {
+  const int w = C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1>::W2 : (D1 == 3 ? PairGeo<11, 3, 1>::W2 : PairGeo<11, 5, 1>::W2))
+                        : (D1 == 1 ? PairGeo<11, 1, 2>::W2 : (D1 == 3 ? PairGeo<11, 3, 2>::W2 : PairGeo<11, 5, 2>::W2));
   return 3LL * B * ((L + w - 1) / w);
 }
-// The three chains' c1 (dilation D1) -> c2 pairs of one MRF step at C = 32; members k = 11, 7, 3.  1 = not eligible.
+// The three chains' c1 (dilation D1) -> c2 pairs of one MRF step at C = 32 / 64; members k = 11, 7, 3.  1 = not eligible.
 int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2, const float* const* x, float* const* y, long long bs, int ld,
                       int B, int L, int D1, float slope, hipStream_t st) {
   if (!wino4_pair_enabled() || B <= 0 || (L & 3) || (ld & 3) || (bs & 3) || !(D1 == 1 || D1 == 3 || D1 == 5)) return 1;
   static const int ks[3] = {11, 7, 3};
+  static const bool c64 = !(getenv("SVOC_W4_PAIR64") && atoi(getenv("SVOC_W4_PAIR64")) == 0);      // SVOC_W4_PAIR64=0: the C = 64 stage conv by conv
+  const int C = pw1[0] ? pw1[0]->Cin : 0;
+  // C = 64 (64-window tiles: the halo costs more lanes): measured -97 us for the d = 1 pair, -8 us for the d = 3 pair (c2 keeps 57 of 64
+  // windows there) - only the first is taken
+  if (!(C == 32 || (C == 64 && c64 && D1 == 1))) return 1;
   PairGroup g{};
   double flops = 0, exec = 0;
   for (int i = 0; i < 3; ++i) {
-    if (!pw1[i] || !pw2[i] || pw1[i]->K != ks[i] || pw2[i]->K != ks[i] || pw1[i]->Cin != 32 || pw1[i]->Cout != 32 || pw2[i]->Cin != 32 ||
-        pw2[i]->Cout != 32 || !pw1[i]->wp4.p || !pw2[i]->wp4.p) return 1;
+    if (!pw1[i] || !pw2[i] || pw1[i]->K != ks[i] || pw2[i]->K != ks[i] || pw1[i]->Cin != C || pw1[i]->Cout != C || pw2[i]->Cin != C ||
+        pw2[i]->Cout != C || !pw1[i]->wp4.p || !pw2[i]->wp4.p) return 1;
     if ((reinterpret_cast<uintptr_t>(x[i]) & 15) || (reinterpret_cast<uintptr_t>(y[i]) & 15)) return 1;
     g.m[i].x = x[i]; g.m[i].x_bs = bs; g.m[i].x_ld = ld;
     g.m[i].y = y[i]; g.m[i].y_bs = bs; g.m[i].y_ld = ld;
@@ -410,10 +421,11 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "wino4P Ci32   Co32   k11/7/3 c1(d%d)+c2 N%-7d B%-3d", D1, L, B);
+    snprintf(d, sizeof(d), "wino4P Ci%-4d Co%-4d k11/7/3 c1(d%d)+c2 N%-7d B%-3d", C, C, D1, L, B);
     prof_idx = prof_begin(st, d, flops);
   }
-  const int rc = D1 == 1 ? pair_launch_d<1>(g, st) : (D1 == 3 ? pair_launch_d<3>(g, st) : pair_launch_d<5>(g, st));
+  const int rc = C == 32 ? (D1 == 1 ? pair_launch_d<1, 1>(g, st) : (D1 == 3 ? pair_launch_d<3, 1>(g, st) : pair_launch_d<5, 1>(g, st)))
+                         : (D1 == 1 ? pair_launch_d<1, 2>(g, st) : (D1 == 3 ? pair_launch_d<3, 2>(g, st) : pair_launch_d<5, 2>(g, st)));
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
   SVOC_HIP(hipGetLastError());

@@ -530,9 +530,9 @@ struct Generator {
         if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
         return SVOC_OK;
       };
-      // C = 32, every step but the last: c1 -> c2 of the three chains in ONE launch, the intermediate tile in LDS (conv_wino4_pair.hip)
-      if (C == 32 && nk == 3 && !last && wino4_pair_enabled() &&
-          wino4_pair_tiles(L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= 2LL * device_cu_count()) {
+      // C = 32 / 64, every step but the last: c1 -> c2 of the three chains in ONE launch, the intermediate tile in LDS (conv_wino4_pair.hip)
+      if ((C == 32 || C == 64) && nk == 3 && !last && wino4_pair_enabled() &&
+          wino4_pair_tiles(C, L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= 2LL * device_cu_count()) {
         const PackedWino* p1[3]; const PackedWino* p2[3];
         const float* xi[3]; float* yo[3];
         for (int q = 0; q < nk; ++q) {

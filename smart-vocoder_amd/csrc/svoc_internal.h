@@ -189,11 +189,11 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
 int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int n, int B, int dil, hipStream_t st, bool query = false);
 int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st, bool query = false);   // chain order k = 3, 7, 11
 
-// conv_wino4_pair.hip: c1 (dilation D1) -> c2 of one ResBlock1 iteration at C = 32 in one launch for the three chains (members
+// conv_wino4_pair.hip: c1 (dilation D1) -> c2 of one ResBlock1 iteration at C = 32 / 64 in one launch for the three chains (members
 // k = 11, 7, 3; y != x); 1 = not eligible
 bool wino4_c32_enabled();
 bool wino4_pair_enabled();
-long long wino4_pair_tiles(int L, int B, int D1);
+long long wino4_pair_tiles(int C, int L, int B, int D1);
 int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2, const float* const* x, float* const* y, long long bs, int ld,
                       int B, int L, int D1, float slope, hipStream_t st);
 

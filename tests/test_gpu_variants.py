@@ -12,6 +12,7 @@ listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run check
   SVOC_WINO_F4=0 SVOC_WINO_WS=0  four-wave F(2,3) Winograd kernels
   SVOC_W4_PRIO=0                 F(4,3) producers at the consumers' priority
   SVOC_W4_ACC3=0                 the accumulate launch as three read-modify-write members instead of one set of accumulators
+  SVOC_W4_PAIR64=0               C = 64 stage: the undilated ResBlock iteration conv by conv as well (the pair kernel at C = 32 only)
   SVOC_W4_PAIR=0                 C = 32 stage: c1 and c2 of a ResBlock iteration as two grouped launches instead of one (conv_wino4_pair.hip)
   SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv
   SVOC_W4_PERM=0                 dilated F(4,3) convolutions store their rows in natural order (four scattered dwords per lane)
@@ -62,6 +63,7 @@ VARIANTS = {
     "mrf_accumulate_one_by_one": ({"SVOC_W4_ACCUM": "0"}, DEC),
     "mrf_accumulate_three_members": ({"SVOC_W4_ACC3": "0"}, DEC),
     "c32_conv_by_conv": ({"SVOC_W4_PAIR": "0"}, DEC),
+    "c64_conv_by_conv": ({"SVOC_W4_PAIR64": "0"}, DEC),
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
     "winograd_f43_natural_rows": ({"SVOC_W4_PERM": "0"}, DEC),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),

@@ -1,5 +1,5 @@
 cd /root/repo
-O=gpurun_out/r04p; mkdir -p $O
+O=gpurun_out/r04q; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "rb1 or generator or infer_vs_reference or c2_full" 2>&1 | tail -4 > $O/tests.txt
 python tools/step_ab.py > $O/ab_new.json 2> $O/ab.err
 SVOC_W4_PAIR=0 python tools/step_ab.py > $O/ab_old.json 2>> $O/ab.err
