@@ -110,8 +110,9 @@ def cpu_baseline(sd_np, seed, keep=None):
 def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     """Per-launch duration of the dominant kernel, measured live with HIP events on the launch stream by the library's
     event profiler (every GEMM-family launch bracketed by hipEventRecord): the grouped launch of the C=128 stage's
-    three undilated convolutions k=11/7/3 (conv_wino4_group_kernel<1,4>, Winograd F(4,3) form; conv_wino_ws_group_kernel<1>,
-    F(2,3), when SVOC_WINO_F4=0; conv_group_kernel when SVOC_WINO=0).  Runs after the timed region."""
+    three undilated convolutions k=11/7/3 (conv_wino4_group_kernel<1,4,0,true>: k=11/7 in Winograd F(4,4) form, k=3 in F(4,3);
+    F(4,3) throughout when SVOC_W4_F44=0; conv_wino_ws_group_kernel<1>, F(2,3), when SVOC_WINO_F4=0; conv_group_kernel when
+    SVOC_WINO=0).  Runs after the timed region."""
     from smart_vocoder_amd import _native
     _native.profile_enable(True)
     with torch.no_grad():
@@ -127,7 +128,8 @@ def dominant_kernel_probe(net, mel, ln, eps, steps=2):
         f = line.split()
         n, total_ms, mean_us, tfl = int(f[-4]), float(f[-3]), float(f[-2]), float(f[-1])
         if best is None or total_ms > best["total_ms"]:
-            best = dict(desc=" ".join(f[:-4]), n=n, total_ms=total_ms, mean_us=mean_us, tflops=tfl, wino=line.startswith("winoG "), wino4=line.startswith("wino4G "))
+            best = dict(desc=" ".join(f[:-4]), n=n, total_ms=total_ms, mean_us=mean_us, tflops=tfl, wino=line.startswith("winoG "), wino4=line.startswith("wino4G "),
+                        f44="F(4,4)" in line)
     return best, rep
 
 
@@ -400,9 +402,10 @@ def main():
                            "winograd_form_floor_ms": stats["executed_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "direct_form_floor_ms": stats["conv_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group|_accum)_kernel (Winograd F(4,3), every ResBlock convolution of the decoder), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, wn_layer_fused(_ks)_kernel (fallbacks: resblock_fused_ct_kernel, conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group|_acc3|_pair)_kernel (Winograd F(4,4) for k=7/11 at C>=128, F(4,3) otherwise: every ResBlock convolution of the decoder), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, wn_layer_fused(_ks)_kernel (fallbacks: resblock_fused_ct_kernel, conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
                            "note": "achieved/frac = executed 2*MAC / time (<= peak). Shares of the direct form's multiply-adds issued per kernel size k=3/7/11: "
-                                   "F(4,3) (default) 1/2, 4/7, 6.5/11; F(2,3) (fall-back) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8; everything else 1. "
+                                   "F(4,3) (default) 1/2, 4/7, 6.5/11; F(4,4) (C>=128 stages, k=7/11) 3.5/7, 5.25/11 (merged accumulate launch: k=3 1.75/3); "
+                                   "F(2,3) (fall-back) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8; F(2,5) WN in_layers 3/5; everything else 1. "
                                    "achieved_direct_form/frac_direct_form = algorithmic direct-form 2*MAC (SURVEY.md 8d) / time, NOT bounded by the peak; "
                                    "winograd_form_floor_ms = executed FLOPs of one step at 157.3 TFLOP/s",
                            "gemm_launches_per_step": stats["conv_launches"] / args.steps,
@@ -412,10 +415,11 @@ def main():
                            "gpu_ms_per_step_rank0": gpu_ms / args.steps}
         if dom:
             # the launch with the largest share of the step.  achieved / frac = the multiply-adds its MFMAs really executed
-            # ((6.5 + 4 + 1.5) / (11 + 7 + 3) of the direct form in F(4,3); F(2,3): (8 + 5 + 2) / 21) over its launch time
-            executed = 12.0 / 21.0 if dom["wino4"] else (15.0 / 21.0 if dom["wino"] else 1.0)
+            # ((5.25 + 3.5 + 1.5) / (11 + 7 + 3) of the direct form with k=11/7 in F(4,4); (6.5 + 4 + 1.5) / 21 in F(4,3); F(2,3):
+            # (8 + 5 + 2) / 21) over its launch time
+            executed = (10.25 / 21.0 if dom["f44"] else 12.0 / 21.0) if dom["wino4"] else (15.0 / 21.0 if dom["wino"] else 1.0)
             res["roofline"]["dominant_kernel"] = {
-                "name": ("conv_wino4_group_kernel<1,4> " if dom["wino4"] else
+                "name": (("conv_wino4_group_kernel<1,4,0,true> " if dom["f44"] else "conv_wino4_group_kernel<1,4> ") if dom["wino4"] else
                          (("conv_wino_group_kernel<1> " if os.environ.get("SVOC_WINO_WS") == "0" else "conv_wino_ws_group_kernel<1> ")
                           if dom["wino"] else "conv_group_kernel<2,2,2,2> ")) + dom["desc"],
                 "launches_measured": dom["n"], "avg_launch_us": dom["mean_us"],

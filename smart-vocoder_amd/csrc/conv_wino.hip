@@ -948,13 +948,14 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
 // conv_wino4.hip: the F(4,3) form
 bool wino4_enabled();
 bool wino4_c32_enabled();
-int wino4_slots(int K);
+bool wino44_enabled();
+int wino4_slots(int K, bool f44);
 int wino4_ntn(int L, int D, int NRT);
-int pack_wino4_image(float* wp4, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
-int wino4_launch(const WinoArgs& w, int K, int D, int NC, long long total, hipStream_t st);
-int wino4_launch_group(const WinoGroup& g, int D, int NC, int in_perm, int out_perm, long long total, hipStream_t st);
-int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, long long total, hipStream_t st);
-int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, long long total, hipStream_t st);      // conv_wino4_acc.hip
+int pack_wino4_image(float* wp4, int Cin, int Cout, int K, bool f44, const float* w_or_v, const float* scale, hipStream_t st);
+int wino4_launch(const WinoArgs& w, int K, int D, int NC, bool f44, long long total, hipStream_t st);
+int wino4_launch_group(const WinoGroup& g, int D, int NC, int in_perm, int out_perm, bool f44, long long total, hipStream_t st);
+int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, bool f44, long long total, hipStream_t st);
+int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, bool f44, long long total, hipStream_t st);      // conv_wino4_acc.hip
 bool wino4_acc3_enabled();
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
@@ -985,10 +986,19 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
   hipLaunchKernelGGL(wino_bias_kernel, dim3((pw.mtiles * 32 + 255) / 256), dim3(256), 0, st, bias, pw.bias.f(), Cout, pw.mtiles * 32);
   // F(4,3) image: 64- or 128-row blocks with even chunk counts, or the single 32 x 32 block of the last MRF stage
   if (wino4_enabled() && ((pw.mtiles % 2 == 0 && (pw.nchunks & 1) == 0) || (pw.mtiles == 1 && pw.nchunks == 1))) {
-    const long long total4 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K) * 4 * 256;
+    // 128-row layout: k = 7 / 11 in F(4,4) form (conv_wino4.h); k = 3 keeps F(4,3) and gets a second image for the merged accumulate launch
+    const bool l128 = wino44_enabled() && pw.mtiles % 4 == 0;
+    pw.f44 = l128 && K >= 7;
+    const long long total4 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K, pw.f44) * 4 * 256;
     SVOC_TRY(pw.wp4.ensure((size_t)(total4 + 1024) * sizeof(float)));
     SVOC_HIP(hipMemsetAsync(pw.wp4.f() + total4, 0, 1024 * sizeof(float), st));
-    SVOC_TRY(pack_wino4_image(pw.wp4.f(), Cin, Cout, K, w_or_v, g ? scale.f() : nullptr, st));
+    SVOC_TRY(pack_wino4_image(pw.wp4.f(), Cin, Cout, K, pw.f44, w_or_v, g ? scale.f() : nullptr, st));
+    if (l128 && K == 3) {
+      const long long total44 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K, true) * 4 * 256;
+      SVOC_TRY(pw.wp44.ensure((size_t)(total44 + 1024) * sizeof(float)));
+      SVOC_HIP(hipMemsetAsync(pw.wp44.f() + total44, 0, 1024 * sizeof(float), st));
+      SVOC_TRY(pack_wino4_image(pw.wp44.f(), Cin, Cout, K, true, w_or_v, g ? scale.f() : nullptr, st));
+    }
   }
   SVOC_HIP(hipGetLastError());
   SVOC_HIP(hipStreamSynchronize(st));                      // `scale` is freed on return
@@ -1100,7 +1110,8 @@ static int wino_ws_launch_group(const WinoGroup& g, long long total, hipStream_t
 static double wino_exec_ratio(int K) { const int G = (K + 1) / 4; return (2.0 * G + (G - 1)) / (double)K; }
 
 // F(4,3) form (conv_wino4.hip): four-row-tile blocks; dilation 1 additionally needs 16-byte aligned rows of a length that is a multiple of four
-static double wino4_exec_ratio(int K) { const int G = (K + 1) / 4; return (1.5 * G + (G - 1)) / (double)K; }
+// (F(4,4) form, conv_wino4.h: seven products per four outputs and four-tap group, no left-over taps: k = 7: 3.5/7, k = 11: 5.25/11)
+static double wino4_exec_ratio(int K, bool f44) { const int G = (K + 1) / 4; return (f44 ? 1.75 * G : 1.5 * G + (G - 1)) / (double)K; }
 static int wino4_nc(const PackedWino& pw) { return pw.mtiles % 4 == 0 ? 4 : (pw.mtiles == 1 ? 1 : 2); }      // row tiles per workgroup: 128-, 64- or 32-row blocks
 static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const WinoArgs& w, WinoArgs& w4) {
   if (!wino4_enabled() || !pw.wp4.p || !(dil == 1 || dil == 3 || dil == 5) || (dil == 1 && (a.Ncols & 3))) return false;
@@ -1135,16 +1146,17 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
   WinoArgs w4;
   const bool f4 = wino4_args(pw, a, dil, w, w4);
   if (!f4 && pw.mtiles < 2) return 1;                       // C = 32 exists in F(4,3) form only
-  stats_add_conv(flops, 1, flops * (f4 ? wino4_exec_ratio(pw.K) : wino_exec_ratio(pw.K)));
+  stats_add_conv(flops, 1, flops * (f4 ? wino4_exec_ratio(pw.K, pw.f44) : wino_exec_ratio(pw.K)));
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%d", f4 ? "wino4" : "wino ", pw.Cin, pw.Cout, pw.K, dil, a.Ncols, B, WM, 4 / WM);
+    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%-2d d%-2d N%-7d B%-3d %dx%d%s", f4 ? "wino4" : "wino ", pw.Cin, pw.Cout, pw.K, dil, a.Ncols, B, WM, 4 / WM,
+             f4 && pw.f44 ? " F(4,4)" : "");
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
   if (f4) {
-    rc = wino4_launch(w4, pw.K, dil, wino4_nc(pw), (long long)w4.ntn * w4.gy * B, st);
+    rc = wino4_launch(w4, pw.K, dil, wino4_nc(pw), pw.f44, (long long)w4.ntn * w4.gy * B, st);
     prof_end(st, prof_idx);
     if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
     SVOC_HIP(hipGetLastError());
@@ -1187,23 +1199,28 @@ int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, in
     if (t != total || total > 0x7fffffffLL || as[i].out[0].y != as[0].out[0].y) return 1;      // one tile space, one output tensor
     g4.end[i] = (int)total; g4.k[i] = pws[i]->K;
     flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
-    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K);
   }
+  // F(4,4) members (128-row layout): k = 7 / 11 carry that image; the merged launch needs k = 3 in the same form (its second image)
+  const bool f44 = pws[1]->f44 && pws[2]->f44;
+  if (pws[1]->f44 != pws[2]->f44 || pws[0]->f44) return 1;
   if (total * 3 / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
   const int in_perm = as[0].wperm_in;
   if (as[1].wperm_in != in_perm || as[2].wperm_in != in_perm) return 1;
   if (query) return 0;
-  stats_add_conv(flops, 3, exec4);
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "wino4A Ci%-4d Co%-4d k3+7+11 accumulate N%-7d B%-3d", pws[0]->Cin, pws[0]->Cout, as[0].Ncols, B);
+    snprintf(d, sizeof(d), "wino4A Ci%-4d Co%-4d k3+7+11 accumulate N%-7d B%-3d%s", pws[0]->Cin, pws[0]->Cout, as[0].Ncols, B, f44 ? " F(4,4)" : "");
     prof_idx = prof_begin(st, d, flops);
   }
   // one set of accumulators for the three members (conv_wino4_acc.hip) when every member is a plain residual convolution
-  const bool merged = wino4_acc3_enabled() && (g4.a[0].flags & (F_RES | F_ACC | F_DIV)) == F_RES &&
+  const bool merged = wino4_acc3_enabled() && (g4.a[0].flags & (F_RES | F_ACC | F_DIV)) == F_RES && (!f44 || pws[0]->wp44.p) &&
                       (g4.a[1].flags & (F_RES | F_ACC)) == (F_RES | F_ACC) && (g4.a[2].flags & (F_RES | F_ACC)) == (F_RES | F_ACC);
-  const int rc = merged ? wino4_launch_acc3(g4.a, wino4_nc(*pws[0]), in_perm, total, st) : wino4_launch_accum(g4, wino4_nc(*pws[0]), in_perm, total, st);
+  if (merged && f44) g4.a[0].wp = pws[0]->wp44.f();         // one set of accumulators: the k = 3 member in F(4,4) form as well
+  for (int i = 0; i < 3; ++i)
+    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K, i == 0 ? (merged && f44) : f44);
+  stats_add_conv(flops, 3, exec4);
+  const int rc = merged ? wino4_launch_acc3(g4.a, wino4_nc(*pws[0]), in_perm, f44, total, st) : wino4_launch_accum(g4, wino4_nc(*pws[0]), in_perm, f44, total, st);
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
   SVOC_HIP(hipGetLastError());
@@ -1226,7 +1243,7 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     g.k[i] = pws[i]->K;
     flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols;
     exec_flops += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino_exec_ratio(pws[i]->K);
-    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K);
+    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K, pws[i]->f44);
     f4 = f4 && wino4_nc(*pws[i]) == wino4_nc(*pws[0]) && wino4_args(*pws[i], as[i], dil, g.a[i], g4.a[i]);
     if (f4) { total4 += (long long)g4.a[i].ntn * g4.a[i].gy * B; g4.end[i] = (int)total4; g4.k[i] = pws[i]->K; }
     const int K = pws[i]->K;
@@ -1236,6 +1253,8 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     lds = std::max(lds, l);
   }
   if (!f4 && pws[0]->mtiles < 2) return 1;                  // C = 32 exists in F(4,3) form only
+  const bool f44 = f4 && pws[0]->f44;                       // k = 11 and k = 7 in F(4,4) form, k = 3 in F(4,3) (pack_wino)
+  if (f4 && (pws[1]->f44 != pws[0]->f44 || pws[2]->f44)) return 1;
   // (the threshold counts the F(2,3) kernels' 64- / 128-column tiles whichever form runs: round 3's measured break-even for the
   // grouped launches - counting the F(4,3) tiles instead sent the 1 x 200 C = 128 / 64 stages to the direct kernels, +0.5 ms)
   if (total / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
@@ -1248,12 +1267,12 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%d/%d/%d d%d N%-7d B%-3d %dx%d", f4 ? "wino4G" : "winoG", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, dil,
-             as[0].Ncols, B, WM, 4 / WM);
+    snprintf(d, sizeof(d), "%s Ci%-4d Co%-4d k%d/%d/%d d%d N%-7d B%-3d %dx%d%s", f4 ? "wino4G" : "winoG", pws[0]->Cin, pws[0]->Cout, pws[0]->K, pws[1]->K, n > 2 ? pws[2]->K : 0, dil,
+             as[0].Ncols, B, WM, 4 / WM, f44 ? " F(4,4)" : "");
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
-  if (f4) rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), in_perm, out_perm, total4, st);
+  if (f4) rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), in_perm, out_perm, f44, total4, st);
   else if (wino_ws_on() && WM == 4 && dil <= 3 && n == 3 && pws[0]->K == 11 && pws[1]->K == 7 && pws[2]->K == 3 && (pws[1]->nchunks & 1) == 0)
     rc = dil == 1 ? wino_ws_launch_group<1>(g, total, st) : wino_ws_launch_group<3>(g, total, st);
   else if (WM == 4) rc = dil == 1 ? wino_launch_group<1, 4>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 4>(g, total, lds, st) : wino_launch_group<5, 4>(g, total, lds, st));

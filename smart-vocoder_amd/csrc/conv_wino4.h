@@ -21,12 +21,26 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #define W4_NPS3_MAX_NRT 4                                  // three plane sets for every layout whose LDS budget allows them
 #endif
 // KSDIV: channels per stage divided by KSDIV (conv_wino4_acc.hip stages its k = 3 member half as wide so that three plane sets fit)
-template <int K, int D, int NRT = 4, int PERM = 0, int KSDIV = 1>
+//
+// F44 (round 4): the groups are FOUR-tap groups at tap offsets 0, 4, 8 in minimal F(4,4) form - four outputs from the seven inputs
+// d_j = x[4q - pad + 4g + j] with SEVEN products (Cook-Toom on the points 0, +-1, +-2, +-1/2; the last group of k = 7 / 11 carries a
+// zero fourth tap), no left-over taps: 7 G products per window instead of 6 G + 4 (G - 1) - k = 7: 14 instead of 16, k = 11: 21 instead
+// of 26 (k = 3: 7 instead of 6, used only where a k = 3 member has to share accumulators with the others).  The window step still
+// equals the group spacing, so every group reads the same seven planes V_p[c][q + g]:
+//     V0 = (d0 - d6) + 5.25 (d4 - d2)                                   U0 = w0
+//     V1,2 = (d2 + d6 - 4.25 d4) +- (d1 + d5 - 4.25 d3)                 U1,2 = -2/9 ((w0 + w2) +- (w1 + w3))
+//     V3,4 = (d6 + 0.25 d2 - 1.25 d4) +- (0.5 d1 - 2.5 d3 + 2 d5)       U3,4 = 1/90 ((w0 + 4 w2) +- (2 w1 + 8 w3))
+//     V5,6 = (d6 + 4 d2 - 5 d4) +- (2 d1 - 2.5 d3 + 0.5 d5)             U5,6 = 32/45 ((w0 + w2 / 4) +- (w1 / 2 + w3 / 8))
+//     y_i = sum_p a_p^i M_p,  a = (0, 1, -1, 2, -2, 1/2, -1/2),  M_p = sum_c U_p[c] V_p[c]
+// fp32 error of one C = 192 convolution against float64: 1.03e-6 relative RMS (F(4,3): 0.86e-6, direct form 0.26e-6; tools/wino_numerics.py).
+template <int K, int D, int NRT = 4, int PERM = 0, int KSDIV = 1, bool F44_ = false>
 struct W4Geo {
+  static constexpr bool F44 = F44_;
+  static constexpr int NV = F44 ? 7 : 6;                  // transformed planes = products per group and window
   static_assert(PERM == 0 || D == 1, "a window-major input belongs to an undilated convolution (the c2 behind a dilated c1)");
   static constexpr int DIL = D;
   static constexpr int NCT = 4 / NRT;                     // column tiles (of 32 windows) per workgroup
-  static constexpr int KS = (NRT == 1 ? (K == 3 ? 16 : 8) : (NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1) ? 64 : 32))) / KSDIV;   // channels per stage
+  static constexpr int KS = (NRT == 1 ? (K == 3 ? 16 : 8) : (NRT == 2 ? (K == 3 ? 32 : 16) : ((K == 3 && D == 1 && !F44_) ? 64 : 32))) / KSDIV;   // channels per stage (F44: seven slots per chunk, one chunk per stage)
   static_assert(KS >= 8, "a stage is at least one k-group");
   static constexpr int CPS = KS >= KC ? KS / KC : 1;      // weight chunks per stage
   static constexpr int HALVES = KS < KC ? KC / KS : 1;    // stages per weight chunk
@@ -36,11 +50,11 @@ struct W4Geo {
   // loaded L2 round trip (round 4: 77-84 cycles per MFMA in the C = 32 streams) - so those run a ring of four sets, three slots ahead.
   static constexpr int NSET = KGS == 4 ? 2 : 4;
   static constexpr int PD = NSET - 1;                     // slots ahead
-  static constexpr int G = (K + 1) / 4;                   // three-tap groups at tap offsets 0, 4, 8
-  static constexpr int ND = G - 1;                        // left-over single taps (3, 7)
+  static constexpr int G = (K + 1) / 4;                   // three-tap (F44: four-tap) groups at tap offsets 0, 4, 8
+  static constexpr int ND = F44 ? 0 : G - 1;              // left-over single taps (3, 7)
   static constexpr int PADT = (K - 1) / 2;                // padding in taps (columns: PADT * D)
-  static constexpr int WSLOTS = 6 * G + ND;               // weight slots per 32-channel chunk
-  static constexpr int NGS = 6 * G * KGS;                 // steps (4 MFMAs each) of the groups; a tap adds 4 * KGS steps
+  static constexpr int WSLOTS = NV * G + ND;              // weight slots per 32-channel chunk
+  static constexpr int NGS = NV * G * KGS;                // steps (4 MFMAs each) of the groups; a tap adds 4 * KGS steps
   static constexpr int NSTEP = NGS + 4 * KGS * ND;
   // Windows are numbered along a row: window w = D * b + ph (q block b, phase ph) owns the outputs 4 D b + ph + r D, r = 0..3.  A
   // workgroup tile is NWT = 32 NCT CONSECUTIVE windows [w0, w0 + NWT): with D = 1 that is the output range [4 w0, 4 w0 + 4 NWT); with
@@ -56,11 +70,11 @@ struct W4Geo {
   static constexpr int PQ = (NE + PQA - 1) / PQA * PQA;
   static constexpr int XOFF = -((PADT * D + 3) & ~3);     // D = 1: raw tile starts at 4 w0 + XOFF (multiple of 4)
   static constexpr int LEAD = -XOFF - PADT * D;           // D = 1: raw index of d0 of window w0
-  // raw tile columns.  D = 1: d5 of the last window + 1.  D > 1: first sample f(w0) = 4 D b0 + ph0 - PADT D rounded down to a
-  // multiple of 4 (lead <= 3); f grows by at most 4 NE + 5 D over NE windows and a window spans 5 D more
-  static constexpr int RAW = D == 1 ? ((LEAD + 4 * (NE - 1) + 5 + 1 + 3) & ~3) : ((4 * NE + 10 * D + 4 + 3) & ~3);
-  static constexpr int NPL = ND > 0 ? 10 : 6;             // V0..V5 (+ X0..X3)
-  static constexpr int NACC = ND > 0 ? 8 : 6;
+  // raw tile columns.  D = 1: d5 (F44: d6) of the last window + 1.  D > 1: first sample f(w0) = 4 D b0 + ph0 - PADT D rounded down to a
+  // multiple of 4 (lead <= 3); f grows by at most 4 NE + 5 D over NE windows and a window spans 5 D (F44: 6 D) more
+  static constexpr int RAW = D == 1 ? ((LEAD + 4 * (NE - 1) + (NV - 1) + 1 + 3) & ~3) : ((4 * NE + (NV + 4) * D + 4 + 3) & ~3);
+  static constexpr int NPL = F44 ? 7 : (ND > 0 ? 10 : 6); // V0..V5 (+ X0..X3); F44: V0..V6
+  static constexpr int NACC = F44 ? 7 : (ND > 0 ? 8 : 6);
   static constexpr int PLANE = KS * PQ;
   static constexpr int PLF = NPL * PLANE;                 // floats per plane set
   // PERM = P > 0 (round 4): the INPUT rows are in the window-major order a dilation-P convolution's epilogue writes with 16-byte
@@ -82,9 +96,78 @@ struct W4Geo {
   static constexpr int kgi(int t) { return t % KGS; }                                    // k-group of the step inside the stage
   static constexpr bool slot_first(int t) { return t < NGS ? t % KGS == 0 : (t - NGS) % (4 * KGS) == 0; }
   static constexpr int wslot(int t) { return t < NGS ? t / KGS : 6 * G + (t - NGS) / (4 * KGS); }
-  static constexpr int plane(int t) { return t < NGS ? (t / KGS) % 6 : 6 + (tr(t) + 2) % 4; }
-  static constexpr int colq(int t) { return t < NGS ? (t / KGS) / 6 : (t - NGS) / (4 * KGS) + (tr(t) + 2) / 4; }
-  static constexpr int acc(int t) { return t < NGS ? (t / KGS) % 6 : (tr(t) == 0 ? 0 : (tr(t) == 3 ? 5 : 5 + tr(t))); }
+  static constexpr int plane(int t) { return t < NGS ? (t / KGS) % NV : 6 + (tr(t) + 2) % 4; }
+  static constexpr int colq(int t) { return t < NGS ? (t / KGS) / NV : (t - NGS) / (4 * KGS) + (tr(t) + 2) / 4; }
+  static constexpr int acc(int t) { return t < NGS ? (t / KGS) % NV : (tr(t) == 0 ? 0 : (tr(t) == 3 ? 5 : 5 + tr(t))); }
 };
+
+// ---- the transforms, shared by every kernel of the family (conv_wino4_kernels.h, conv_wino4_acc.hip, conv_wino4_pair.hip)
+// input transform of one window: d0 .. d5 (F44: d6) -> the planes of plane set `o` (this item's entry), PLANE floats apart
+template <class Geo>
+__device__ __forceinline__ void w4_input_transform(float* const o, const float d0, const float d1, const float d2, const float d3, const float d4,
+                                                   const float d5, const float d6) {
+  constexpr int PLANE = Geo::PLANE;
+  if constexpr (Geo::F44) {
+    const float e1 = __builtin_fmaf(-4.25f, d4, d2 + d6), o1 = __builtin_fmaf(-4.25f, d3, d1 + d5);
+    const float e2 = __builtin_fmaf(-1.25f, d4, __builtin_fmaf(0.25f, d2, d6)), o2 = __builtin_fmaf(2.f, d5, __builtin_fmaf(-2.5f, d3, 0.5f * d1));
+    const float e3 = __builtin_fmaf(-5.f, d4, __builtin_fmaf(4.f, d2, d6)), o3 = __builtin_fmaf(0.5f, d5, __builtin_fmaf(-2.5f, d3, 2.f * d1));
+    o[0] = __builtin_fmaf(5.25f, d4 - d2, d0 - d6);
+    o[PLANE] = e1 + o1;
+    o[2 * PLANE] = e1 - o1;
+    o[3 * PLANE] = e2 + o2;
+    o[4 * PLANE] = e2 - o2;
+    o[5 * PLANE] = e3 + o3;
+    o[6 * PLANE] = e3 - o3;
+  } else {
+    const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);      // d4 - 4 d2, d3 - 4 d1
+    const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+    o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+    o[PLANE] = a_ + b_;
+    o[2 * PLANE] = a_ - b_;
+    o[3 * PLANE] = c_ + e_;
+    o[4 * PLANE] = c_ - e_;
+    o[5 * PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    if constexpr (Geo::ND > 0) { o[6 * PLANE] = d1; o[7 * PLANE] = d2; o[8 * PLANE] = d3; o[9 * PLANE] = d4; }
+  }
+}
+// the window of item `r` (D = 1: r points at the sixteen-byte group LEAD columns ahead of d0, conv_wino4_kernels.h) -> planes
+template <class Geo>
+__device__ __forceinline__ void w4_transform_window(float* const o, const float* const r) {
+  constexpr int D = Geo::DIL, LEAD = Geo::LEAD;
+  if constexpr (D == 1 && LEAD == 3) {
+    const float4 fm = *reinterpret_cast<const float4*>(r + 4);
+    if constexpr (Geo::F44) {
+      const float2 ft = *reinterpret_cast<const float2*>(r + 8);
+      w4_input_transform<Geo>(o, r[3], fm.x, fm.y, fm.z, fm.w, ft.x, ft.y);
+    } else w4_input_transform<Geo>(o, r[3], fm.x, fm.y, fm.z, fm.w, r[8], 0.f);
+  } else if constexpr (D == 1) {
+    static_assert(D != 1 || LEAD == 3 || LEAD == 1, "window alignment");
+    const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
+    w4_input_transform<Geo>(o, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w);
+  } else {
+    w4_input_transform<Geo>(o, r[0], r[D], r[2 * D], r[3 * D], r[4 * D], r[5 * D], Geo::F44 ? r[6 * D] : 0.f);
+  }
+}
+// output transform of accumulator element i: the four outputs of the lane's window in row i
+template <class Geo, int NACC>
+__device__ __forceinline__ float4 w4_output_transform(const f32x16 (&M)[NACC], const int i) {
+  const float t1 = M[1][i] + M[2][i], t2 = M[1][i] - M[2][i], t3 = M[3][i] + M[4][i], t4 = M[3][i] - M[4][i];
+  if constexpr (Geo::F44) {
+    static_assert(NACC >= 7, "seven products");
+    const float t5 = M[5][i] + M[6][i], t6 = M[5][i] - M[6][i];
+    const float y0 = (M[0][i] + t1) + (t3 + t5);
+    const float y1 = __builtin_fmaf(0.5f, t6, __builtin_fmaf(2.f, t4, t2));
+    const float y2 = __builtin_fmaf(0.25f, t5, __builtin_fmaf(4.f, t3, t1));
+    const float y3 = __builtin_fmaf(0.125f, t6, __builtin_fmaf(8.f, t4, t2));
+    return make_float4(y0, y1, y2, y3);
+  } else {
+    const float y0 = M[0][i] + (t1 + t3);
+    float y1 = __builtin_fmaf(2.f, t4, t2);
+    float y2 = __builtin_fmaf(4.f, t3, t1);
+    const float y3 = __builtin_fmaf(8.f, t4, t2) + M[5][i];
+    if constexpr (Geo::ND > 0 || NACC == 8) { y1 += M[6][i]; y2 += M[7][i]; }
+    return make_float4(y0, y1, y2, y3);
+  }
+}
 
 }  // namespace svoc

@@ -29,11 +29,14 @@ namespace svoc {
 
 struct WinoAcc3 { WinoArgs a[3]; int total; };              // members k = 3, 7, 11 (chain order); one tile space; output / flags / div of a[0]
 
-template <int NRT, int PERM>
+// F44 (128-row layout): the three members in F(4,4) form (conv_wino4.h) - one set of SEVEN accumulators; the k = 3 member then issues
+// seven products per window instead of six (its second weight image, PackedWino::wp44): 42 products per window against 48
+template <int NRT, int PERM, bool F44 = false>
 struct Acc3Geo {
-  using G3 = W4Geo<3, 1, NRT, PERM>;
-  using G7 = W4Geo<7, 1, NRT, PERM>;
-  using G11 = W4Geo<11, 1, NRT, PERM>;
+  using G3 = W4Geo<3, 1, NRT, PERM, 1, F44>;
+  using G7 = W4Geo<7, 1, NRT, PERM, 1, F44>;
+  using G11 = W4Geo<11, 1, NRT, PERM, 1, F44>;
+  static constexpr int NACC = F44 ? 7 : 8;
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int RAWMAX = cmax(G3::RAW_FLOATS, cmax(G7::RAW_FLOATS, G11::RAW_FLOATS));
   static constexpr int PLFMAX = cmax(G3::PLF, cmax(G7::PLF, G11::PLF));
@@ -97,7 +100,7 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
                                             const int w0, const int bz, int& s_, const int lane, const int pw_, Next&& next) {
   using P = Acc3Prod<Geo>;
   constexpr int PERM = P::PERM, RAWS = P::RAWS, PORG = P::PORG, RPW = P::RPW, R4 = P::R4, NGW = P::NGW, SPW = P::SPW, NGWP = P::NGWP, SPWP = P::SPWP;
-  constexpr int NE = Geo::NE, PQ = Geo::PQ, PLANE = Geo::PLANE, LEAD = Geo::LEAD, ND = Geo::ND, NIW = P::NIW, TPW = P::TPW;
+  constexpr int NE = Geo::NE, PQ = Geo::PQ, NIW = P::NIW, TPW = P::TPW;
   const int L = p.L;
   const float slope = p.pre_slope;
   const int nst = p.nchunks * Geo::HALVES / Geo::CPS;
@@ -177,26 +180,7 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
-        const float* r = tsrc[u];
-        float* o = pb + tdst[u];
-        float d0, d1, d2, d3, d4, d5;
-        if constexpr (LEAD == 3) {
-          const float4 fm = *reinterpret_cast<const float4*>(r + 4);
-          d0 = r[3]; d1 = fm.x; d2 = fm.y; d3 = fm.z; d4 = fm.w; d5 = r[8];
-        } else {
-          static_assert(LEAD == 3 || LEAD == 1, "window alignment");
-          const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
-          d0 = fa.y; d1 = fa.z; d2 = fa.w; d3 = fb.x; d4 = fb.y; d5 = fb.z;
-        }
-        const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);
-        const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
-        o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-        o[PLANE] = a_ + b_;
-        o[2 * PLANE] = a_ - b_;
-        o[3 * PLANE] = c_ + e_;
-        o[4 * PLANE] = c_ - e_;
-        o[5 * PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
-        if constexpr (ND > 0) { o[6 * PLANE] = d1; o[7 * PLANE] = d2; o[8 * PLANE] = d3; o[9 * PLANE] = d4; }
+        w4_transform_window<Geo>(pb + tdst[u], tsrc[u]);
       }
     }
     // B_s: plane set complete.  Three sets: the barrier behind stage s is B_{s-1} (started = a stage has been produced before), the
@@ -206,13 +190,13 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
   }
 }
 
-template <int NRT, int PERM>
+template <int NRT, int PERM, bool F44 = false>
 __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 g) {
-  using AG = Acc3Geo<NRT, PERM>;
+  using AG = Acc3Geo<NRT, PERM, F44>;
   using G3 = typename AG::G3;
   using G7 = typename AG::G7;
   using G11 = typename AG::G11;
-  constexpr int NWT = G11::NWT, NACC = 8;
+  constexpr int NWT = G11::NWT, NACC = AG::NACC;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* const raw = wl;
   float* const pl = wl + AG::RAWMAX;
@@ -311,15 +295,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
         }
         float4 vo[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 4 * Q + r;
-          const float t1 = M[1][i] + M[2][i], t2 = M[1][i] - M[2][i], t3 = M[3][i] + M[4][i], t4 = M[3][i] - M[4][i];
-          const float y0 = M[0][i] + (t1 + t3);
-          const float y1 = __builtin_fmaf(2.f, t4, t2) + M[6][i];
-          const float y2 = __builtin_fmaf(4.f, t3, t1) + M[7][i];
-          const float y3 = __builtin_fmaf(8.f, t4, t2) + M[5][i];
-          vo[r] = make_float4(y0, y1, y2, y3);
-        }
+        for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<G11, NACC>(M, 4 * Q + r);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           vo[r].x = ((vo[r].x + r3[r].x) + r7[r].x) + r11[r].x;
@@ -340,11 +316,11 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
 }
 
 // ------------------------------------------------------------------------------------------------ launch
-template <int NRT, int PERM>
+template <int NRT, int PERM, bool F44 = false>
 static int acc3_launch_n(const WinoAcc3& g, hipStream_t st) {
-  using AG = Acc3Geo<NRT, PERM>;
+  using AG = Acc3Geo<NRT, PERM, F44>;
   static_assert(AG::LDS_BYTES <= 160 * 1024, "tile does not fit");
-  auto kern = conv_wino4_acc3_kernel<NRT, PERM>;
+  auto kern = conv_wino4_acc3_kernel<NRT, PERM, F44>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const unsigned grid = (unsigned)std::min<long long>(g.total, (long long)device_cu_count());
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)AG::LDS_BYTES, st, g);
@@ -352,13 +328,14 @@ static int acc3_launch_n(const WinoAcc3& g, hipStream_t st) {
 }
 // members in chain order (k = 3, 7, 11, dilation 1, epilogue flags of a plain residual), one tile space of `total` tiles; in_perm: 0, or
 // the dilation (3 / 5) of the convolutions that wrote the members' inputs window-major; a[0] carries the output, F_DIV and div
-int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, long long total, hipStream_t st) {
+int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, bool f44, long long total, hipStream_t st) {
   WinoAcc3 g;
   for (int i = 0; i < 3; ++i) g.a[i] = a[i];
   g.a[0].flags |= a[2].flags & F_DIV;                       // the division by the number of chains rides on the last member
   g.a[0].div = a[2].div;
   g.total = (int)total;
-#define SVOC_W4M(P) (NRT == 4 ? acc3_launch_n<4, P>(g, st) : (NRT == 2 ? acc3_launch_n<2, P>(g, st) : acc3_launch_n<1, P>(g, st)))
+  if (f44 && NRT != 4) return 1;
+#define SVOC_W4M(P) (NRT == 4 ? (f44 ? acc3_launch_n<4, P, true>(g, st) : acc3_launch_n<4, P>(g, st)) : (NRT == 2 ? acc3_launch_n<2, P>(g, st) : acc3_launch_n<1, P>(g, st)))
   if (in_perm == 5) return SVOC_W4M(5);
   if (in_perm == 3) return SVOC_W4M(3);
   return SVOC_W4M(0);

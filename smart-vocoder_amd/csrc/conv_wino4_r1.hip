@@ -1,0 +1,6 @@
+// F(4,3) kernels of the 32-row layout (NRT = 1: conv_wino4.h), instantiated here (conv_wino4_launch.h).
+#include "conv_wino4_launch.h"
+
+namespace svoc {
+SVOC_W4_INSTANTIATE(1)
+}  // namespace svoc

@@ -176,6 +176,8 @@ int launch_conv_group(const PackedConv* const* pcs, const ConvArgs* as, int n, i
 struct PackedWino {
   DevBuf wp, bias;
   DevBuf wp4;                     // F(4,3) image (conv_wino4.hip), present when that form is enabled and the shape is eligible
+  bool f44 = false;               // wp4 is in F(4,4) form (conv_wino4.h: k = 7 / 11 of the 128-row layout)
+  DevBuf wp44;                    // k = 3 of the 128-row layout: second image in F(4,4) form (the merged accumulate launch, whose members share accumulators)
   int Cin = 0, Cout = 0, K = 0, nchunks = 0, mtiles = 0, slots = 0;
   double flops_per_col = 0;       // algorithmic 2*MAC of the convolution per output column
 };
@@ -253,7 +255,7 @@ bool prof_enabled();
 int prof_begin(hipStream_t st, const std::string& desc, double flops);
 void prof_end(hipStream_t st, int idx);
 // one GEMM-family kernel launch computing nconv convolutions; exec_flops = 2 x the multiply-adds the matrix pipe really issues
-// for them (shares of the direct form for k = 3, 7, 11: F(4,3) 1/2, 4/7, 6.5/11 (default); F(2,3) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8;
+// for them (shares of the direct form for k = 3, 7, 11: F(4,3) 1/2, 4/7, 6.5/11 (default); F(4,4) -, 3.5/7, 5.25/11 (128-row layout); F(2,3) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8;
 // F(2,5) WN in_layers 3/5; < 0: same as flops)
 void stats_add_conv(double flops, int nconv = 1, double exec_flops = -1.0);
 double stats_exec_flops();

@@ -108,6 +108,13 @@ def _wino_f4_expected(C, co, k, d, L):
     return blocks and (d != 1 or L % 4 == 0)
 
 
+def _wino_f44_expected(C, co, k, d, L):
+    """F(4,4) (conv_wino4.h, round 4): the 128-row layout (Cout a multiple of 128) runs k = 7 / 11 as four-tap groups in seven
+    products each, no left-over taps; k = 3 and the 64- / 32-row layouts stay F(4,3).  SVOC_W4_F44=0: F(4,3) everywhere."""
+    import os
+    return _wino_f4_expected(C, co, k, d, L) and os.environ.get("SVOC_W4_F44") != "0" and ((co + 31) // 32) % 4 == 0 and k >= 7
+
+
 @pytest.mark.parametrize("C,co,k,d,L,B,res", [(128, 128, 3, 1, 4096, 2, True), (128, 128, 7, 1, 1000, 3, True), (128, 128, 11, 1, 4100, 1, False),
                                                (256, 256, 11, 1, 516, 2, True), (64, 96, 7, 1, 260, 2, False), (256, 256, 3, 1, 128, 1, True),
                                                (128, 128, 11, 1, 12, 1, True), (128, 128, 3, 3, 1000, 2, True), (128, 128, 7, 3, 4096, 1, True),
@@ -119,13 +126,16 @@ def _wino_f4_expected(C, co, k, d, L):
                                                (32, 32, 3, 1, 4096, 2, True), (32, 32, 7, 1, 1000, 3, True), (32, 32, 11, 1, 4100, 1, False),
                                                (32, 32, 3, 3, 1500, 2, True), (32, 32, 7, 3, 4096, 1, True), (32, 32, 11, 3, 756, 2, True),
                                                (32, 32, 3, 5, 1204, 1, False), (32, 32, 7, 5, 4100, 2, True), (32, 32, 11, 5, 2400, 2, True),
-                                               (32, 32, 11, 5, 40, 1, True), (32, 32, 11, 1, 12, 1, True), (32, 32, 7, 1, 516, 2, True)])
+                                               (32, 32, 11, 5, 40, 1, True), (32, 32, 11, 1, 12, 1, True), (32, 32, 7, 1, 516, 2, True),
+                                               (256, 256, 7, 1, 4, 1, True), (256, 256, 7, 5, 8, 2, True), (128, 256, 11, 1, 132, 2, False),
+                                               (256, 128, 7, 3, 1996, 1, False), (128, 128, 7, 5, 44, 3, False)])
 def test_conv1d_winograd(M, C, co, k, d, L, B, res):
     """lrelu -> Conv1d(k, dilation d) [+ residual] through the Winograd entry point against torch's direct convolution, AND which
     form ran, read from the executed-multiply-add counter: F(4,3) (conv_wino4.hip, the default: three-tap groups at tap offsets
     0/4/8 on shared transformed planes + left-over taps 3/7 on the de-interleaved planes; dilation through the polyphase view)
-    issues (1.5, 4, 6.5)/k of the direct form's multiply-adds for k = 3/7/11, the documented fall-back F(2,3) (conv_wino.hip:
-    odd row-block or chunk counts, SVOC_WINO_F4=0) issues (2, 5, 8)/k.
+    issues (1.5, 4, 6.5)/k of the direct form's multiply-adds for k = 3/7/11; F(4,4) (128-row blocks, k = 7/11: four-tap groups in
+    seven products, no left-over taps) issues (3.5, 5.25)/k; the documented fall-back F(2,3) (conv_wino.hip: odd row-block or chunk
+    counts, SVOC_WINO_F4=0) issues (2, 5, 8)/k.
     Shapes: every (k, d) of the model for the 128- / 64-row blocks and for the single 32-row block of the last MRF stage (C = 32,
     round 4: 1 x 4 consumers), ragged last tiles, inputs shorter than the halo, odd row-block counts (Cout = 96), lanes whose
     later outputs fall beyond the end (dilated tiles)."""
@@ -152,6 +162,8 @@ def test_conv1d_winograd(M, C, co, k, d, L, B, res):
     st = N.stats_get()
     G = (k + 1) // 4
     want = ((1.5 if _wino_f4_expected(C, co, k, d, L) else 2.0) * G + (G - 1)) / k
+    if _wino_f44_expected(C, co, k, d, L):
+        want = 1.75 * G / k
     assert st["conv_flops"] == 2.0 * C * co * k * B * L, st
     assert abs(st["executed_flops"] / st["conv_flops"] - want) < 1e-9, (st, want)
     check(f"winograd C{C} k{k} d{d} L{L}", y, ref)

@@ -11,6 +11,7 @@ listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run check
   SVOC_WINO_F4=0                 Winograd F(2,3) kernels (wave-specialised, two workgroups per CU) instead of F(4,3)
   SVOC_WINO_F4=0 SVOC_WINO_WS=0  four-wave F(2,3) Winograd kernels
   SVOC_W4_PRIO=0                 F(4,3) producers at the consumers' priority
+  SVOC_W4_F44=0                  128-row layout: k = 7 / 11 in F(4,3) form (six-product groups + left-over taps) instead of F(4,4)
   SVOC_W4_ACC3=0                 the accumulate launch as three read-modify-write members instead of one set of accumulators
   SVOC_W4_PAIR64=0               C = 64 stage: the undilated ResBlock iteration conv by conv as well (the pair kernel at C = 32 only)
   SVOC_W4_PAIR=0                 C = 32 stage: c1 and c2 of a ResBlock iteration as two grouped launches instead of one (conv_wino4_pair.hip)
@@ -60,6 +61,7 @@ VARIANTS = {
     "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
     "winograd_f23_4wave": ({"SVOC_WINO_F4": "0", "SVOC_WINO_WS": "0"}, DEC),
     "winograd_f43_equal_priority": ({"SVOC_W4_PRIO": "0"}, DEC),
+    "winograd_f43_128_rows": ({"SVOC_W4_F44": "0"}, DEC),
     "mrf_accumulate_one_by_one": ({"SVOC_W4_ACCUM": "0"}, DEC),
     "mrf_accumulate_three_members": ({"SVOC_W4_ACC3": "0"}, DEC),
     "c32_conv_by_conv": ({"SVOC_W4_PAIR": "0"}, DEC),
@@ -81,12 +83,42 @@ VARIANTS = {
 }
 
 
-@pytest.mark.parametrize("name", list(VARIANTS))
-def test_variant(name):
+def _jobs():
+    return max(1, int(os.environ.get("SVOC_VARIANT_JOBS", "4")))
+
+
+def _run_variant(name):
     e = dict(os.environ)
     env, sl = VARIANTS[name]
     e.update(env)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(cases.ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
-                        "-m", "gpu", "-p", "no:cacheprovider", "-k", sl], env=e, cwd=cases.ROOT, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=1200)
+    # the host threads are shared out between the concurrent variant processes: _jobs() x (all cores) OpenMP threads spin on each
+    # other in the oracle's convolutions (a first parallel run of this suite did not finish in 25 minutes)
+    nthr = str(max(2, (os.cpu_count() or 8) // (2 * _jobs())))
+    e.setdefault("OMP_NUM_THREADS", nthr)
+    e.setdefault("MKL_NUM_THREADS", nthr)
+    return subprocess.run([sys.executable, "-m", "pytest", os.path.join(cases.ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                           "-m", "gpu", "-p", "no:cacheprovider", "-k", sl], env=e, cwd=cases.ROOT, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True, timeout=1200)
+
+
+# The variant processes spend most of their time on the host (interpreter start, weight generation, the oracle's float64
+# convolutions), so SVOC_VARIANT_JOBS of them (default 4) run side by side: the first test starts them all, every test collects
+# its own result.  Parity only - nothing here is timed, so sharing the GPU is harmless.
+_POOL = None
+_FUTURES = {}
+
+
+def _futures():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=_jobs())
+        for n in VARIANTS:
+            _FUTURES[n] = _POOL.submit(_run_variant, n)
+    return _FUTURES
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_variant(name):
+    r = _futures()[name].result(timeout=3600)
     assert r.returncode == 0, r.stdout[-3000:]
