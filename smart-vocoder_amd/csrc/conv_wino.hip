@@ -949,6 +949,7 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
 bool wino4_enabled();
 bool wino4_c32_enabled();
 bool wino44_enabled();
+bool wino44_all_layouts();
 int wino4_slots(int K, bool f44);
 int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, bool f44, const float* w_or_v, const float* scale, hipStream_t st);
@@ -988,7 +989,7 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
   if (wino4_enabled() && ((pw.mtiles % 2 == 0 && (pw.nchunks & 1) == 0) || (pw.mtiles == 1 && pw.nchunks == 1))) {
     // 128-row layout: k = 7 / 11 in F(4,4) form (conv_wino4.h); k = 3 keeps F(4,3) and gets a second image for the merged accumulate launch
     const bool l128 = wino44_enabled() && pw.mtiles % 4 == 0;
-    pw.f44 = l128 && K >= 7;
+    pw.f44 = (l128 || wino44_all_layouts()) && K >= 7;
     const long long total4 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K, pw.f44) * 4 * 256;
     SVOC_TRY(pw.wp4.ensure((size_t)(total4 + 1024) * sizeof(float)));
     SVOC_HIP(hipMemsetAsync(pw.wp4.f() + total4, 0, 1024 * sizeof(float), st));

@@ -81,6 +81,12 @@ bool wino44_enabled() {
   static const bool on = wino4_enabled() && !(getenv("SVOC_W4_F44") && atoi(getenv("SVOC_W4_F44")) == 0);
   return on;
 }
+// SVOC_W4_F44=2 (measurements only, tools/wino_bench.py): k = 7 / 11 of the 64- and 32-row layouts in F(4,4) form as well - the
+// single-convolution kernels only; the grouped / pair / accumulate launches of those layouts refuse such images
+bool wino44_all_layouts() {
+  static const bool on = wino44_enabled() && getenv("SVOC_W4_F44") && atoi(getenv("SVOC_W4_F44")) == 2;
+  return on;
+}
 // SVOC_W4_C32=0: the C = 32 stage keeps the fused direct-form ResBlock kernel (resblock_fused.hip)
 bool wino4_c32_enabled() {
   static const bool on = wino4_enabled() && !(getenv("SVOC_W4_C32") && atoi(getenv("SVOC_W4_C32")) == 0);
@@ -96,7 +102,7 @@ int wino4_ntn(int L, int D, int NRT) {
 unsigned wino4_grid(long long total) { return (unsigned)std::min<long long>(total, (long long)device_cu_count()); }
 
 // conv_wino44.hip: the F(4,4) instantiations (128-row layout, k = 7 / 11)
-int wino44_launch(const WinoArgs& w, int K, int D, long long total, hipStream_t st);
+int wino44_launch(const WinoArgs& w, int K, int D, int NRT, long long total, hipStream_t st);
 int wino44_launch_group(const WinoGroup& g, int D, int in_perm, int out_perm, long long total, hipStream_t st);
 int wino44_launch_accum(const WinoGroup& g, int in_perm, long long total, hipStream_t st);
 
@@ -112,7 +118,7 @@ SVOC_W4_EXTERN(4) SVOC_W4_EXTERN(2) SVOC_W4_EXTERN(1)
 #undef SVOC_W4_EXTERN
 
 int wino4_launch(const WinoArgs& w, int K, int D, int NRT, bool f44, long long total, hipStream_t st) {
-  if (f44) return NRT == 4 ? wino44_launch(w, K, D, total, st) : 1;
+  if (f44) return wino44_launch(w, K, D, NRT, total, st);
   return NRT == 4 ? wino4_launch_nrt<4>(w, K, D, total, st) : (NRT == 2 ? wino4_launch_nrt<2>(w, K, D, total, st) : wino4_launch_nrt<1>(w, K, D, total, st));
 }
 // members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each); in_perm: 0, or the dilation (3 / 5) of the

@@ -9,24 +9,29 @@ namespace svoc {
 
 unsigned wino4_grid(long long total);
 
-template <int K, int D>
+template <int K, int D, int NRT = 4>
 static int wino44_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
-  using Geo = W4Geo<K, D, 4, 0, 1, true>;
+  using Geo = W4Geo<K, D, NRT, 0, 1, true>;
   static_assert(Geo::LDS_BYTES <= 160 * 1024, "tile does not fit");
   const unsigned grid = wino4_grid(total);
   if (w.dbg) {                                             // stamped build (tools/wino4_timeline.py)
-    auto kern = conv_wino4_kernel<K, D, 4, true, true>;
+    auto kern = conv_wino4_kernel<K, D, NRT, true, true>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)Geo::LDS_BYTES, st, w, (int)total);
   } else {
-    auto kern = conv_wino4_kernel<K, D, 4, false, true>;
+    auto kern = conv_wino4_kernel<K, D, NRT, false, true>;
     SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)Geo::LDS_BYTES, st, w, (int)total);
   }
   return SVOC_OK;
 }
-int wino44_launch(const WinoArgs& w, int K, int D, long long total, hipStream_t st) {
+int wino44_launch(const WinoArgs& w, int K, int D, int NRT, long long total, hipStream_t st) {
   int rc = 1;
+  if (NRT != 4) {                                          // SVOC_W4_F44=2: the undilated convolutions of the 64- / 32-row layouts (measurements)
+    if (D != 1 || !(K == 7 || K == 11)) return 1;
+    if (NRT == 2) return K == 7 ? wino44_launch_one<7, 1, 2>(w, total, st) : wino44_launch_one<11, 1, 2>(w, total, st);
+    return K == 7 ? wino44_launch_one<7, 1, 1>(w, total, st) : wino44_launch_one<11, 1, 1>(w, total, st);
+  }
 #define SVOC_W44(KK, DD) if (K == KK && D == DD) rc = wino44_launch_one<KK, DD>(w, total, st);
   SVOC_W44(7, 1) SVOC_W44(11, 1) SVOC_W44(7, 3) SVOC_W44(11, 3) SVOC_W44(7, 5) SVOC_W44(11, 5)
 #undef SVOC_W44

@@ -403,7 +403,7 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
   double flops = 0, exec = 0;
   for (int i = 0; i < 3; ++i) {
     if (!pw1[i] || !pw2[i] || pw1[i]->K != ks[i] || pw2[i]->K != ks[i] || pw1[i]->Cin != C || pw1[i]->Cout != C || pw2[i]->Cin != C ||
-        pw2[i]->Cout != C || !pw1[i]->wp4.p || !pw2[i]->wp4.p) return 1;
+        pw2[i]->Cout != C || !pw1[i]->wp4.p || !pw2[i]->wp4.p || pw1[i]->f44 || pw2[i]->f44) return 1;
     if ((reinterpret_cast<uintptr_t>(x[i]) & 15) || (reinterpret_cast<uintptr_t>(y[i]) & 15)) return 1;
     g.m[i].x = x[i]; g.m[i].x_bs = bs; g.m[i].x_ld = ld;
     g.m[i].y = y[i]; g.m[i].y_bs = bs; g.m[i].y_ld = ld;

@@ -12,8 +12,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 lib = N.lib()
 x = torch.randn(B, C, L, device="cuda") * 0.5
 y = torch.empty_like(x)
-for k in (3, 7, 11):
-    for d in (1, 3, 5):
+for k in [int(v) for v in os.environ.get("WB_K", "3,7,11").split(",")]:
+    for d in [int(v) for v in os.environ.get("WB_D", "1,3,5").split(",")]:
         v = torch.randn(C, C, k, device="cuda") / (C * k) ** 0.5
         g = torch.rand(C, 1, 1, device="cuda") + 0.5
         b = torch.randn(C, device="cuda") * 0.1
