@@ -949,7 +949,6 @@ __global__ void wino_bias_kernel(const float* __restrict__ bias, float* __restri
 bool wino4_enabled();
 bool wino4_c32_enabled();
 bool wino44_enabled();
-bool wino44_all_layouts();
 int wino4_slots(int K, bool f44);
 int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, bool f44, const float* w_or_v, const float* scale, hipStream_t st);
@@ -987,14 +986,13 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
   hipLaunchKernelGGL(wino_bias_kernel, dim3((pw.mtiles * 32 + 255) / 256), dim3(256), 0, st, bias, pw.bias.f(), Cout, pw.mtiles * 32);
   // F(4,3) image: 64- or 128-row blocks with even chunk counts, or the single 32 x 32 block of the last MRF stage
   if (wino4_enabled() && ((pw.mtiles % 2 == 0 && (pw.nchunks & 1) == 0) || (pw.mtiles == 1 && pw.nchunks == 1))) {
-    // 128-row layout: k = 7 / 11 in F(4,4) form (conv_wino4.h); k = 3 keeps F(4,3) and gets a second image for the merged accumulate launch
-    const bool l128 = wino44_enabled() && pw.mtiles % 4 == 0;
-    pw.f44 = (l128 || wino44_all_layouts()) && K >= 7;
+    // k = 7 / 11 in F(4,4) form (conv_wino4.h); k = 3 keeps F(4,3) and gets a second image for the merged accumulate launch
+    pw.f44 = wino44_enabled() && K >= 7;
     const long long total4 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K, pw.f44) * 4 * 256;
     SVOC_TRY(pw.wp4.ensure((size_t)(total4 + 1024) * sizeof(float)));
     SVOC_HIP(hipMemsetAsync(pw.wp4.f() + total4, 0, 1024 * sizeof(float), st));
     SVOC_TRY(pack_wino4_image(pw.wp4.f(), Cin, Cout, K, pw.f44, w_or_v, g ? scale.f() : nullptr, st));
-    if (l128 && K == 3) {
+    if (wino44_enabled() && K == 3) {
       const long long total44 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K, true) * 4 * 256;
       SVOC_TRY(pw.wp44.ensure((size_t)(total44 + 1024) * sizeof(float)));
       SVOC_HIP(hipMemsetAsync(pw.wp44.f() + total44, 0, 1024 * sizeof(float), st));

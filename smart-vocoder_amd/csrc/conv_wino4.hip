@@ -1,5 +1,5 @@
 // Winograd F(4,3) / F(4,4) convolutions (kernels: conv_wino4_kernels.h): weight transform + packing, and the dispatch to the
-// instantiations (F(4,3): conv_wino4_r4.hip / _r2.hip / _r1.hip, one per row-tile layout; F(4,4), 128-row layout: conv_wino44.hip).
+// instantiations (conv_wino4_r4.hip / _r2.hip / _r1.hip: one per row-tile layout in F(4,3) form; conv_wino44_r*.hip: k = 7 / 11 in F(4,4) form).
 #include "conv_wino4.h"
 
 #include <algorithm>
@@ -76,15 +76,9 @@ bool wino4_enabled() {
   static const bool on = !(getenv("SVOC_WINO_F4") && atoi(getenv("SVOC_WINO_F4")) == 0);      // SVOC_WINO_F4=0: the F(2,3) kernels
   return on;
 }
-// SVOC_W4_F44=0: k = 7 / 11 of the 128-row layout in F(4,3) form as well (six-product groups + left-over taps) instead of F(4,4)
+// SVOC_W4_F44=0: k = 7 / 11 in F(4,3) form as well (six-product groups + left-over taps) instead of F(4,4)
 bool wino44_enabled() {
   static const bool on = wino4_enabled() && !(getenv("SVOC_W4_F44") && atoi(getenv("SVOC_W4_F44")) == 0);
-  return on;
-}
-// SVOC_W4_F44=2 (measurements only, tools/wino_bench.py): k = 7 / 11 of the 64- and 32-row layouts in F(4,4) form as well - the
-// single-convolution kernels only; the grouped / pair / accumulate launches of those layouts refuse such images
-bool wino44_all_layouts() {
-  static const bool on = wino44_enabled() && getenv("SVOC_W4_F44") && atoi(getenv("SVOC_W4_F44")) == 2;
   return on;
 }
 // SVOC_W4_C32=0: the C = 32 stage keeps the fused direct-form ResBlock kernel (resblock_fused.hip)
@@ -101,38 +95,35 @@ int wino4_ntn(int L, int D, int NRT) {
 // one persistent workgroup per CU (eight waves of up to 256 registers)
 unsigned wino4_grid(long long total) { return (unsigned)std::min<long long>(total, (long long)device_cu_count()); }
 
-// conv_wino44.hip: the F(4,4) instantiations (128-row layout, k = 7 / 11)
-int wino44_launch(const WinoArgs& w, int K, int D, int NRT, long long total, hipStream_t st);
-int wino44_launch_group(const WinoGroup& g, int D, int in_perm, int out_perm, long long total, hipStream_t st);
-int wino44_launch_accum(const WinoGroup& g, int in_perm, long long total, hipStream_t st);
-
-// the F(4,3) instantiations, one translation unit per row-tile layout (conv_wino4_launch.h)
-template <int NRT> int wino4_launch_nrt(const WinoArgs& w, int K, int D, long long total, hipStream_t st);
-template <int NRT> int wino4_launch_group_nrt(const WinoGroup& g, int D, int in_perm, int out_perm, long long total, hipStream_t st);
-template <int NRT> int wino4_launch_accum_nrt(const WinoGroup& g, int in_perm, long long total, hipStream_t st);
-#define SVOC_W4_EXTERN(NRT)                                                                                               \
-  extern template int wino4_launch_nrt<NRT>(const WinoArgs&, int, int, long long, hipStream_t);                           \
-  extern template int wino4_launch_group_nrt<NRT>(const WinoGroup&, int, int, int, long long, hipStream_t);               \
-  extern template int wino4_launch_accum_nrt<NRT>(const WinoGroup&, int, long long, hipStream_t);
-SVOC_W4_EXTERN(4) SVOC_W4_EXTERN(2) SVOC_W4_EXTERN(1)
+// the instantiations, one translation unit per row-tile layout and form (conv_wino4_launch.h)
+template <int NRT, bool F44> int wino4_launch_nrt(const WinoArgs& w, int K, int D, long long total, hipStream_t st);
+template <int NRT, bool F44> int wino4_launch_group_nrt(const WinoGroup& g, int D, int in_perm, int out_perm, long long total, hipStream_t st);
+template <int NRT, bool F44> int wino4_launch_accum_nrt(const WinoGroup& g, int in_perm, long long total, hipStream_t st);
+#define SVOC_W4_EXTERN(NRT, F44)                                                                                          \
+  extern template int wino4_launch_nrt<NRT, F44>(const WinoArgs&, int, int, long long, hipStream_t);                      \
+  extern template int wino4_launch_group_nrt<NRT, F44>(const WinoGroup&, int, int, int, long long, hipStream_t);          \
+  extern template int wino4_launch_accum_nrt<NRT, F44>(const WinoGroup&, int, long long, hipStream_t);
+SVOC_W4_EXTERN(4, false) SVOC_W4_EXTERN(2, false) SVOC_W4_EXTERN(1, false) SVOC_W4_EXTERN(4, true) SVOC_W4_EXTERN(2, true) SVOC_W4_EXTERN(1, true)
 #undef SVOC_W4_EXTERN
+#define SVOC_W4_BY_LAYOUT(FN, ...)                                                                                        \
+  (f44 ? (NRT == 4 ? FN<4, true>(__VA_ARGS__) : (NRT == 2 ? FN<2, true>(__VA_ARGS__) : FN<1, true>(__VA_ARGS__)))         \
+       : (NRT == 4 ? FN<4, false>(__VA_ARGS__) : (NRT == 2 ? FN<2, false>(__VA_ARGS__) : FN<1, false>(__VA_ARGS__))))
 
+// f44: the weight image is in F(4,4) form (k = 7 / 11)
 int wino4_launch(const WinoArgs& w, int K, int D, int NRT, bool f44, long long total, hipStream_t st) {
-  if (f44) return wino44_launch(w, K, D, NRT, total, st);
-  return NRT == 4 ? wino4_launch_nrt<4>(w, K, D, total, st) : (NRT == 2 ? wino4_launch_nrt<2>(w, K, D, total, st) : wino4_launch_nrt<1>(w, K, D, total, st));
+  if (f44 && K < 7) return 1;
+  return SVOC_W4_BY_LAYOUT(wino4_launch_nrt, w, K, D, total, st);
 }
 // members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each); in_perm: 0, or the dilation (3 / 5) of the
-// convolutions that wrote the members' inputs window-major
+// convolutions that wrote the members' inputs window-major; f44: the k = 7 / 11 members' images are in F(4,4) form
 int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, bool f44, long long total, hipStream_t st) {
-  if (f44) return NRT == 4 ? wino44_launch_accum(g, in_perm, total, st) : 1;
-  return NRT == 4 ? wino4_launch_accum_nrt<4>(g, in_perm, total, st) : (NRT == 2 ? wino4_launch_accum_nrt<2>(g, in_perm, total, st) : wino4_launch_accum_nrt<1>(g, in_perm, total, st));
+  return SVOC_W4_BY_LAYOUT(wino4_launch_accum_nrt, g, in_perm, total, st);
 }
 // in_perm (D = 1): 0, or the dilation of the convolutions that wrote the members' inputs window-major; out_perm (D > 1): nonzero =
 // the members write window-major
 int wino4_launch_group(const WinoGroup& g, int D, int NRT, int in_perm, int out_perm, bool f44, long long total, hipStream_t st) {
-  if (f44) return NRT == 4 ? wino44_launch_group(g, D, in_perm, out_perm, total, st) : 1;
-  return NRT == 4 ? wino4_launch_group_nrt<4>(g, D, in_perm, out_perm, total, st)
-                  : (NRT == 2 ? wino4_launch_group_nrt<2>(g, D, in_perm, out_perm, total, st) : wino4_launch_group_nrt<1>(g, D, in_perm, out_perm, total, st));
+  return SVOC_W4_BY_LAYOUT(wino4_launch_group_nrt, g, D, in_perm, out_perm, total, st);
 }
+#undef SVOC_W4_BY_LAYOUT
 
 }  // namespace svoc

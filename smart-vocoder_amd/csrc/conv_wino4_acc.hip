@@ -29,11 +29,12 @@ namespace svoc {
 
 struct WinoAcc3 { WinoArgs a[3]; int total; };              // members k = 3, 7, 11 (chain order); one tile space; output / flags / div of a[0]
 
-// F44 (128-row layout): the three members in F(4,4) form (conv_wino4.h) - one set of SEVEN accumulators; the k = 3 member then issues
-// seven products per window instead of six (its second weight image, PackedWino::wp44): 42 products per window against 48
+// F44: the three members in F(4,4) form (conv_wino4.h) - one set of SEVEN accumulators; the k = 3 member then issues seven products
+// per window instead of six (its second weight image, PackedWino::wp44): 42 products per window against 48.  (One row tile: the k = 3
+// member's seven slots of 16-channel stages would not close the four-set weight ring within its two stages; it stages 8 channels.)
 template <int NRT, int PERM, bool F44 = false>
 struct Acc3Geo {
-  using G3 = W4Geo<3, 1, NRT, PERM, 1, F44>;
+  using G3 = W4Geo<3, 1, NRT, PERM, (F44 && NRT == 1) ? 2 : 1, F44>;
   using G7 = W4Geo<7, 1, NRT, PERM, 1, F44>;
   using G11 = W4Geo<11, 1, NRT, PERM, 1, F44>;
   static constexpr int NACC = F44 ? 7 : 8;
@@ -334,8 +335,8 @@ int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, bool f44, long lo
   g.a[0].flags |= a[2].flags & F_DIV;                       // the division by the number of chains rides on the last member
   g.a[0].div = a[2].div;
   g.total = (int)total;
-  if (f44 && NRT != 4) return 1;
-#define SVOC_W4M(P) (NRT == 4 ? (f44 ? acc3_launch_n<4, P, true>(g, st) : acc3_launch_n<4, P>(g, st)) : (NRT == 2 ? acc3_launch_n<2, P>(g, st) : acc3_launch_n<1, P>(g, st)))
+#define SVOC_W4M(P) (f44 ? (NRT == 4 ? acc3_launch_n<4, P, true>(g, st) : (NRT == 2 ? acc3_launch_n<2, P, true>(g, st) : acc3_launch_n<1, P, true>(g, st))) \
+                         : (NRT == 4 ? acc3_launch_n<4, P>(g, st) : (NRT == 2 ? acc3_launch_n<2, P>(g, st) : acc3_launch_n<1, P>(g, st))))
   if (in_perm == 5) return SVOC_W4M(5);
   if (in_perm == 3) return SVOC_W4M(3);
   return SVOC_W4M(0);

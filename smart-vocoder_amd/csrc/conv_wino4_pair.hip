@@ -1,5 +1,6 @@
 // One ResBlock1 iteration - c1 (dilation D1) -> lrelu -> c2 (dilation 1) -> + x (reference modules.py:212-219) - of the C = 32 MRF stage
-// (and, NRT = 2, the undilated iteration of the C = 64 stage) in ONE launch, both convolutions in Winograd F(4,3) form, the intermediate tile kept in LDS (round 4).
+// (and, NRT = 2, the undilated iteration of the C = 64 stage) in ONE launch, both convolutions in Winograd F(4,3) form (F44: k = 7 / 11 in
+// F(4,4) form, conv_wino4.h), the intermediate tile kept in LDS (round 4).
 //
 // Conv by conv (conv_wino4.hip, one row tile per workgroup) the C = 32 stage moves five tensor passes per iteration (x in, c1 out, c1 in,
 // x as residual, y out) where the fused direct-form kernel of round 1 moved two, and its k = 3 members are HBM-bound.  With one row tile
@@ -26,22 +27,24 @@ namespace svoc {
 struct PairMember {
   const float* x; long long x_bs; int x_ld;                // input = residual [B][32][x_ld]
   float* y; long long y_bs; int y_ld;                       // output
-  const float* wp1; const float* bias1;                     // c1: F(4,3) image, bias
+  const float* wp1; const float* bias1;                     // c1: F(4,3) (F44: k = 7 / 11 F(4,4)) image, bias
   const float* wp2; const float* bias2;                     // c2
 };
 struct PairGroup { PairMember m[3]; int end[3]; int L; int B; int xcd; unsigned flags; float slope; };   // members k = 11, 7, 3; end[i] = first tile id behind member i
 // NRT = 1: C = 32 (1 x 4 consumers, 128 windows per tile); NRT = 2: C = 64 (2 x 2 consumers, 64 windows per tile, two 32-channel chunks)
 
-template <int K, int D1, int NRT>
+template <int K, int D1, int NRT, bool F44_ = false>
 struct PairGeo {
   static constexpr int KD = K == 3 ? 2 : 1;                 // 8 (C = 32) / 16 (C = 64) channels per stage for every member: four stages per phase
-  using G1 = W4Geo<K, D1, NRT, 0, KD>;
-  using G2 = W4Geo<K, 1, NRT, 0, KD>;
+  static constexpr bool F44 = F44_ && K >= 7;               // k = 3 stays F(4,3)
+  using G1 = W4Geo<K, D1, NRT, 0, KD, F44>;
+  using G2 = W4Geo<K, 1, NRT, 0, KD, F44>;
+  static constexpr int SPAN = G2::NV;                       // samples of a window: 6 (F44: 7)
   static constexpr int KS = G1::KS, ROWS = 32 * NRT, NWT = G1::NWT;
   static_assert(G1::KS == 8 * NRT && G2::KS == 8 * NRT && ROWS / KS == 4, "four stages per phase");
   static constexpr int NWC1 = (NWT / D1) * D1;              // c1 windows per tile: whole q blocks
   static constexpr int COLS1 = 4 * NWC1;                    // columns of the intermediate tile
-  static constexpr int NW2 = (COLS1 - 4 * D1 + 4 - G2::LEAD - 6) / 4 - G2::G + 2;      // c2 windows kept per tile
+  static constexpr int NW2 = (COLS1 - 4 * D1 + 4 - G2::LEAD - SPAN) / 4 - G2::G + 2;   // c2 windows kept per tile
   static constexpr int NE2 = NW2 + G2::G - 1;               // c2 plane entries needed
   static constexpr int W2 = 4 * NW2;                        // tile step in output columns
   static constexpr int MIDS = COLS1;                        // row stride of the intermediate tile
@@ -49,16 +52,16 @@ struct PairGeo {
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int PLFMAX = cmax(G1::PLF, G2::PLF);
   static_assert(G1::RAW_FLOATS <= MID_FLOATS, "c1's raw staging rows alias the head of the intermediate tile");
-  static_assert((4 * D1 - 4) + G2::LEAD + 4 * (NE2 - 1) + 6 <= COLS1, "c2's raw columns lie inside c1's");
+  static_assert((4 * D1 - 4) + G2::LEAD + 4 * (NE2 - 1) + SPAN <= COLS1, "c2's raw columns lie inside c1's");
   static constexpr int LDS_FLOATS = MID_FLOATS + 2 * PLFMAX;
 };
 
-template <int K, int D1, int NRT>
+template <int K, int D1, int NRT, bool F44>
 __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGroup& g, const int first, const int vend, const int blk, const int G_) {
-  using PG = PairGeo<K, D1, NRT>;
+  using PG = PairGeo<K, D1, NRT, F44>;
   using G1 = typename PG::G1;
   using G2 = typename PG::G2;
-  constexpr int NWC1 = PG::NWC1, NW2 = PG::NW2, NE2 = PG::NE2, W2 = PG::W2, MIDS = PG::MIDS, PLFMAX = PG::PLFMAX, NACC = 8;
+  constexpr int NWC1 = PG::NWC1, NW2 = PG::NW2, NE2 = PG::NE2, W2 = PG::W2, MIDS = PG::MIDS, PLFMAX = PG::PLFMAX, NACC = G1::NACC;
   constexpr int PADT = G1::PADT, KS = PG::KS;
   if (vend <= first) return;
   int v0 = blk - first % G_;
@@ -99,8 +102,8 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     const int pw_ = wave - 4;
     if (g.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
     constexpr int RPW = KS / 4, RAW1 = G1::RAW, R4 = RAW1 / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
-    constexpr int NE1 = G1::NE, NIW1 = RPW * NE1, TPW1 = (NIW1 + 63) / 64, PQ1 = G1::PQ, PLANE1 = G1::PLANE, ND = G1::ND;
-    constexpr int NIW2 = RPW * NE2, TPW2 = (NIW2 + 63) / 64, PQ2 = G2::PQ, PLANE2 = G2::PLANE, LEAD2 = G2::LEAD;
+    constexpr int NE1 = G1::NE, NIW1 = RPW * NE1, TPW1 = (NIW1 + 63) / 64, PQ1 = G1::PQ;
+    constexpr int NIW2 = RPW * NE2, TPW2 = (NIW2 + 63) / 64, PQ2 = G2::PQ;
     const long long ldb = (long long)pm.x_ld * 4;
     const float slope = g.slope;
     unsigned goff[SPW];
@@ -186,29 +189,10 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
 #pragma unroll
         for (int u = 0; u < TPW1; ++u) {
           if (64 * (u + 1) <= NIW1 || lane < NIW1 - 64 * u) {
+            // d0 of the window sits at raw + t1off + lead1; D1 = 1: lead1 is 3 (k = 3, 11) or 1 (k = 7) = G1::LEAD, and the shared
+            // transform takes the sixteen-byte group LEAD columns ahead of d0 (the compile-time forms of conv_wino4.h)
             const float* r = raw + t1off[u] + lead1;
-            float* o = pb + t1dst[u];
-            float d0, d1, d2, d3, d4, d5;
-            if constexpr (D1 == 1) {                         // lead1 is 3 (k = 3, 11) or 1 (k = 7): the compile-time forms of conv_wino4.hip
-              if constexpr (G1::LEAD == 3) {
-                const float4 fm = *reinterpret_cast<const float4*>(r + 1);
-                d0 = r[0]; d1 = fm.x; d2 = fm.y; d3 = fm.z; d4 = fm.w; d5 = r[5];
-              } else {
-                const float4 fa = *reinterpret_cast<const float4*>(r - 1), fb = *reinterpret_cast<const float4*>(r + 3);
-                d0 = fa.y; d1 = fa.z; d2 = fa.w; d3 = fb.x; d4 = fb.y; d5 = fb.z;
-              }
-            } else {
-              d0 = r[0]; d1 = r[D1]; d2 = r[2 * D1]; d3 = r[3 * D1]; d4 = r[4 * D1]; d5 = r[5 * D1];
-            }
-            const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);
-            const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
-            o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-            o[PLANE1] = a_ + b_;
-            o[2 * PLANE1] = a_ - b_;
-            o[3 * PLANE1] = c_ + e_;
-            o[4 * PLANE1] = c_ - e_;
-            o[5 * PLANE1] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
-            if constexpr (ND > 0) { o[6 * PLANE1] = d1; o[7 * PLANE1] = d2; o[8 * PLANE1] = d3; o[9 * PLANE1] = d4; }
+            w4_transform_window<G1>(pb + t1dst[u], D1 == 1 ? r - G1::LEAD : r);
           }
         }
         __syncthreads();                                     // B_s: plane set complete
@@ -223,25 +207,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
 #pragma unroll
         for (int u = 0; u < TPW2; ++u) {
           if (64 * (u + 1) <= NIW2 || lane < NIW2 - 64 * u) {
-            const float* r = mrow + t2src[u];
-            float* o = pb + t2dst[u];
-            float d0, d1, d2, d3, d4, d5;
-            if constexpr (LEAD2 == 3) {
-              const float4 fm = *reinterpret_cast<const float4*>(r + 4);
-              d0 = r[3]; d1 = fm.x; d2 = fm.y; d3 = fm.z; d4 = fm.w; d5 = r[8];
-            } else {
-              const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
-              d0 = fa.y; d1 = fa.z; d2 = fa.w; d3 = fb.x; d4 = fb.y; d5 = fb.z;
-            }
-            const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);
-            const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
-            o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-            o[PLANE2] = a_ + b_;
-            o[2 * PLANE2] = a_ - b_;
-            o[3 * PLANE2] = c_ + e_;
-            o[4 * PLANE2] = c_ - e_;
-            o[5 * PLANE2] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
-            if constexpr (ND > 0) { o[6 * PLANE2] = d1; o[7 * PLANE2] = d2; o[8 * PLANE2] = d3; o[9 * PLANE2] = d4; }
+            w4_transform_window<G2>(pb + t2dst[u], mrow + t2src[u]);
           }
         }
         __syncthreads();
@@ -274,16 +240,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
   auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
     constexpr int Q = decltype(q_c)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 4 * Q + r;
-      const float t1 = M[1][i] + M[2][i], t2 = M[1][i] - M[2][i], t3 = M[3][i] + M[4][i], t4 = M[3][i] - M[4][i];
-      float y0 = M[0][i] + (t1 + t3);
-      float y1 = __builtin_fmaf(2.f, t4, t2);
-      float y2 = __builtin_fmaf(4.f, t3, t1);
-      float y3 = __builtin_fmaf(8.f, t4, t2) + M[5][i];
-      if constexpr (G1::ND > 0) { y1 += M[6][i]; y2 += M[7][i]; }
-      vo[r] = make_float4(y0, y1, y2, y3);
-    }
+    for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<G1, NACC>(M, 4 * Q + r);
   };
   for (int ti = 0; ti < my_tiles; ++ti) {
     int bz, n2, m0, off2;
@@ -350,29 +307,29 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
   }
 }
 
-template <int D1, int NRT>
+template <int D1, int NRT, bool F44>
 __global__ void __launch_bounds__(512, 2) conv_wino4_pair_kernel(const PairGroup g) {
   const int b = blockIdx.x, G_ = gridDim.x;
-  pair_member<11, D1, NRT>(g.m[0], g, 0, g.end[0], b, G_);
+  pair_member<11, D1, NRT, F44>(g.m[0], g, 0, g.end[0], b, G_);
   __syncthreads();
-  pair_member<7, D1, NRT>(g.m[1], g, g.end[0], g.end[1], b, G_);
+  pair_member<7, D1, NRT, F44>(g.m[1], g, g.end[0], g.end[1], b, G_);
   __syncthreads();
-  pair_member<3, D1, NRT>(g.m[2], g, g.end[1], g.end[2], b, G_);
+  pair_member<3, D1, NRT, F44>(g.m[2], g, g.end[1], g.end[2], b, G_);
 }
 
-template <int D1, int NRT>
+template <int D1, int NRT, bool F44>
 static int pair_launch_d(PairGroup& g, hipStream_t st) {
-  using P11 = PairGeo<11, D1, NRT>;
-  constexpr int lds = P11::cmax(P11::LDS_FLOATS, P11::cmax(PairGeo<7, D1, NRT>::LDS_FLOATS, PairGeo<3, D1, NRT>::LDS_FLOATS)) * 4;
+  using P11 = PairGeo<11, D1, NRT, F44>;
+  constexpr int lds = P11::cmax(P11::LDS_FLOATS, P11::cmax(PairGeo<7, D1, NRT, F44>::LDS_FLOATS, PairGeo<3, D1, NRT, F44>::LDS_FLOATS)) * 4;
   static_assert(lds <= 160 * 1024, "tile does not fit");
-  const int w2[3] = {P11::W2, PairGeo<7, D1, NRT>::W2, PairGeo<3, D1, NRT>::W2};
+  const int w2[3] = {P11::W2, PairGeo<7, D1, NRT, F44>::W2, PairGeo<3, D1, NRT, F44>::W2};
   long long total = 0;
   for (int i = 0; i < 3; ++i) {
     total += (long long)((g.L + w2[i] - 1) / w2[i]) * g.B;
     if (total > 0x7fffffffLL) return 1;
     g.end[i] = (int)total;
   }
-  auto kern = conv_wino4_pair_kernel<D1, NRT>;
+  auto kern = conv_wino4_pair_kernel<D1, NRT, F44>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, st, g);
@@ -384,9 +341,13 @@ bool wino4_pair_enabled() {
   return on;
 }
 // tiles a launch would have (the engine's size gate)
+bool wino44_enabled();
 long long wino4_pair_tiles(int C, int L, int B, int D1) {
-  const int w = C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1>::W2 : (D1 == 3 ? PairGeo<11, 3, 1>::W2 : PairGeo<11, 5, 1>::W2))
-                        : (D1 == 1 ? PairGeo<11, 1, 2>::W2 : (D1 == 3 ? PairGeo<11, 3, 2>::W2 : PairGeo<11, 5, 2>::W2));
+  const int w = wino44_enabled()
+                    ? (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1, true>::W2 : (D1 == 3 ? PairGeo<11, 3, 1, true>::W2 : PairGeo<11, 5, 1, true>::W2))
+                               : (D1 == 1 ? PairGeo<11, 1, 2, true>::W2 : (D1 == 3 ? PairGeo<11, 3, 2, true>::W2 : PairGeo<11, 5, 2, true>::W2)))
+                    : (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1>::W2 : (D1 == 3 ? PairGeo<11, 3, 1>::W2 : PairGeo<11, 5, 1>::W2))
+                               : (D1 == 1 ? PairGeo<11, 1, 2>::W2 : (D1 == 3 ? PairGeo<11, 3, 2>::W2 : PairGeo<11, 5, 2>::W2)));
   return 3LL * B * ((L + w - 1) / w);
 }
 // The three chains' c1 (dilation D1) -> c2 pairs of one MRF step at C = 32 / 64; members k = 11, 7, 3.  1 = not eligible.
@@ -403,7 +364,7 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
   double flops = 0, exec = 0;
   for (int i = 0; i < 3; ++i) {
     if (!pw1[i] || !pw2[i] || pw1[i]->K != ks[i] || pw2[i]->K != ks[i] || pw1[i]->Cin != C || pw1[i]->Cout != C || pw2[i]->Cin != C ||
-        pw2[i]->Cout != C || !pw1[i]->wp4.p || !pw2[i]->wp4.p || pw1[i]->f44 || pw2[i]->f44) return 1;
+        pw2[i]->Cout != C || !pw1[i]->wp4.p || !pw2[i]->wp4.p || pw1[i]->f44 != (wino44_enabled() && ks[i] >= 7) || pw2[i]->f44 != pw1[i]->f44) return 1;
     if ((reinterpret_cast<uintptr_t>(x[i]) & 15) || (reinterpret_cast<uintptr_t>(y[i]) & 15)) return 1;
     g.m[i].x = x[i]; g.m[i].x_bs = bs; g.m[i].x_ld = ld;
     g.m[i].y = y[i]; g.m[i].y_bs = bs; g.m[i].y_ld = ld;
@@ -412,7 +373,7 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
     const double f = (pw1[i]->flops_per_col + pw2[i]->flops_per_col) * (double)B * (double)L;
     const int G = (ks[i] + 1) / 4;
     flops += f;
-    exec += f * (1.5 * G + (G - 1)) / (double)ks[i];
+    exec += f * (pw1[i]->f44 ? 1.75 * G : 1.5 * G + (G - 1)) / (double)ks[i];
   }
   g.L = L; g.B = B; g.xcd = xcd_mapping_enabled(); g.slope = slope;
   static const bool prio = !(getenv("SVOC_W4_PRIO") && atoi(getenv("SVOC_W4_PRIO")) == 0);
@@ -421,11 +382,13 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "wino4P Ci%-4d Co%-4d k11/7/3 c1(d%d)+c2 N%-7d B%-3d", C, C, D1, L, B);
+    snprintf(d, sizeof(d), "wino4P Ci%-4d Co%-4d k11/7/3 c1(d%d)+c2 N%-7d B%-3d%s", C, C, D1, L, B, wino44_enabled() ? " F(4,4)" : "");
     prof_idx = prof_begin(st, d, flops);
   }
-  const int rc = C == 32 ? (D1 == 1 ? pair_launch_d<1, 1>(g, st) : (D1 == 3 ? pair_launch_d<3, 1>(g, st) : pair_launch_d<5, 1>(g, st)))
-                         : (D1 == 1 ? pair_launch_d<1, 2>(g, st) : (D1 == 3 ? pair_launch_d<3, 2>(g, st) : pair_launch_d<5, 2>(g, st)));
+#define SVOC_W4P(F) (C == 32 ? (D1 == 1 ? pair_launch_d<1, 1, F>(g, st) : (D1 == 3 ? pair_launch_d<3, 1, F>(g, st) : pair_launch_d<5, 1, F>(g, st))) \
+                             : (D1 == 1 ? pair_launch_d<1, 2, F>(g, st) : (D1 == 3 ? pair_launch_d<3, 2, F>(g, st) : pair_launch_d<5, 2, F>(g, st))))
+  const int rc = wino44_enabled() ? SVOC_W4P(true) : SVOC_W4P(false);
+#undef SVOC_W4P
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
   SVOC_HIP(hipGetLastError());

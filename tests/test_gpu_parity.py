@@ -109,10 +109,10 @@ def _wino_f4_expected(C, co, k, d, L):
 
 
 def _wino_f44_expected(C, co, k, d, L):
-    """F(4,4) (conv_wino4.h, round 4): the 128-row layout (Cout a multiple of 128) runs k = 7 / 11 as four-tap groups in seven
-    products each, no left-over taps; k = 3 and the 64- / 32-row layouts stay F(4,3).  SVOC_W4_F44=0: F(4,3) everywhere."""
+    """F(4,4) (conv_wino4.h, round 4): every shape the F(4,3) kernels take runs k = 7 / 11 as four-tap groups in seven products each,
+    no left-over taps; k = 3 stays F(4,3).  SVOC_W4_F44=0: F(4,3) everywhere."""
     import os
-    return _wino_f4_expected(C, co, k, d, L) and os.environ.get("SVOC_W4_F44") != "0" and ((co + 31) // 32) % 4 == 0 and k >= 7
+    return _wino_f4_expected(C, co, k, d, L) and os.environ.get("SVOC_W4_F44") != "0" and k >= 7
 
 
 @pytest.mark.parametrize("C,co,k,d,L,B,res", [(128, 128, 3, 1, 4096, 2, True), (128, 128, 7, 1, 1000, 3, True), (128, 128, 11, 1, 4100, 1, False),
@@ -133,7 +133,7 @@ def test_conv1d_winograd(M, C, co, k, d, L, B, res):
     """lrelu -> Conv1d(k, dilation d) [+ residual] through the Winograd entry point against torch's direct convolution, AND which
     form ran, read from the executed-multiply-add counter: F(4,3) (conv_wino4.hip, the default: three-tap groups at tap offsets
     0/4/8 on shared transformed planes + left-over taps 3/7 on the de-interleaved planes; dilation through the polyphase view)
-    issues (1.5, 4, 6.5)/k of the direct form's multiply-adds for k = 3/7/11; F(4,4) (128-row blocks, k = 7/11: four-tap groups in
+    issues (1.5, 4, 6.5)/k of the direct form's multiply-adds for k = 3/7/11; F(4,4) (the default for k = 7/11: four-tap groups in
     seven products, no left-over taps) issues (3.5, 5.25)/k; the documented fall-back F(2,3) (conv_wino.hip: odd row-block or chunk
     counts, SVOC_WINO_F4=0) issues (2, 5, 8)/k.
     Shapes: every (k, d) of the model for the 128- / 64-row blocks and for the single 32-row block of the last MRF stage (C = 32,

@@ -11,7 +11,7 @@ listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run check
   SVOC_WINO_F4=0                 Winograd F(2,3) kernels (wave-specialised, two workgroups per CU) instead of F(4,3)
   SVOC_WINO_F4=0 SVOC_WINO_WS=0  four-wave F(2,3) Winograd kernels
   SVOC_W4_PRIO=0                 F(4,3) producers at the consumers' priority
-  SVOC_W4_F44=0                  128-row layout: k = 7 / 11 in F(4,3) form (six-product groups + left-over taps) instead of F(4,4)
+  SVOC_W4_F44=0                  k = 7 / 11 in F(4,3) form (six-product groups + left-over taps) instead of F(4,4)
   SVOC_W4_ACC3=0                 the accumulate launch as three read-modify-write members instead of one set of accumulators
   SVOC_W4_PAIR64=0               C = 64 stage: the undilated ResBlock iteration conv by conv as well (the pair kernel at C = 32 only)
   SVOC_W4_PAIR=0                 C = 32 stage: c1 and c2 of a ResBlock iteration as two grouped launches instead of one (conv_wino4_pair.hip)
@@ -61,7 +61,7 @@ VARIANTS = {
     "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
     "winograd_f23_4wave": ({"SVOC_WINO_F4": "0", "SVOC_WINO_WS": "0"}, DEC),
     "winograd_f43_equal_priority": ({"SVOC_W4_PRIO": "0"}, DEC),
-    "winograd_f43_128_rows": ({"SVOC_W4_F44": "0"}, DEC),
+    "winograd_f43_for_k7_k11": ({"SVOC_W4_F44": "0"}, DEC),
     "mrf_accumulate_one_by_one": ({"SVOC_W4_ACCUM": "0"}, DEC),
     "mrf_accumulate_three_members": ({"SVOC_W4_ACC3": "0"}, DEC),
     "c32_conv_by_conv": ({"SVOC_W4_PAIR": "0"}, DEC),
