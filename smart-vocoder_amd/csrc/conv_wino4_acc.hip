@@ -191,7 +191,9 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
   }
 }
 
-template <int NRT, int PERM, bool F44 = false>
+// PIPE: the epilogue's residual loads are software-pipelined - quarter 0's twelve 16-byte loads are requested before the last member's
+// stages, quarter Q + 1's behind quarter Q's output transform (whose accumulator rows are dead by then)
+template <int NRT, int PERM, bool F44 = false, bool PIPE = false>
 __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 g) {
   using AG = Acc3Geo<NRT, PERM, F44>;
   using G3 = typename AG::G3;
@@ -274,44 +276,53 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
     }
     acc3_consume<G3, NACC, AG::NPS>(p3, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p3.nchunks * G3::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G3::PQ + uu) * 4u);
     acc3_consume<G7, NACC, AG::NPS>(p7, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p7.nchunks * G7::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G7::PQ + uu) * 4u);
+    const bool lane_ok = row_ok && ne < L;
+    const long long roff3 = (long long)bz * p3.res_bs + (long long)(mt * 32 + 4 * hi) * p3.res_ld + ne;
+    const long long roff7 = (long long)bz * p7.res_bs + (long long)(mt * 32 + 4 * hi) * p7.res_ld + ne;
+    const long long roff11 = (long long)bz * p11.res_bs + (long long)(mt * 32 + 4 * hi) * p11.res_ld + ne;
+    auto rq = [&](float4 (&rr)[12], const int Q) {          // the residuals of quarter Q: rows 8 Q + 4 hi + r of the three chains
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rr[r] = *reinterpret_cast<const float4*>(p3.res + roff3 + (long long)(8 * Q + r) * p3.res_ld);
+        rr[4 + r] = *reinterpret_cast<const float4*>(p7.res + roff7 + (long long)(8 * Q + r) * p7.res_ld);
+        rr[8 + r] = *reinterpret_cast<const float4*>(p11.res + roff11 + (long long)(8 * Q + r) * p11.res_ld);
+      }
+    };
+    float4 ra[12], rb[12];
+    if constexpr (PIPE) if (lane_ok) rq(ra, 0);
     acc3_consume<G11, NACC, AG::NPS>(p11, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p11.nchunks * G11::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G11::PQ + uu) * 4u);
     // ---- output transform + epilogue: y = (A^T M + res_3 + res_7 + res_11) / div, sixteen-byte stores
-    if (row_ok && ne < L) {
+    if (lane_ok) {
       char* const ybase = reinterpret_cast<char*>(p3.y + (long long)bz * p3.y_bs + (long long)(mt * 32) * p3.y_ld + n0);
-      const long long roff3 = (long long)bz * p3.res_bs + (long long)(mt * 32 + 4 * hi) * p3.res_ld + ne;
-      const long long roff7 = (long long)bz * p7.res_bs + (long long)(mt * 32 + 4 * hi) * p7.res_ld + ne;
-      const long long roff11 = (long long)bz * p11.res_bs + (long long)(mt * 32 + 4 * hi) * p11.res_ld + ne;
       const float dv = p3.div, rc = 1.0f / dv;
       const bool dodiv = (p3.flags & F_DIV) != 0;
       auto dv1 = [&](float x) { const float q = x * rc; return __builtin_fmaf(__builtin_fmaf(-q, dv, x), rc, q); };
-      // (requesting the residuals of quarter Q + 1 behind quarter Q's output transform: 14-19 spilled registers, no gain - measured)
-      auto quarter = [&](auto q_c) {
+      auto quarter = [&](auto q_c, float4 (&cur)[12], float4 (&nxt)[12]) {
         constexpr int Q = decltype(q_c)::value;
-        float4 r3[4], r7[4], r11[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          r3[r] = *reinterpret_cast<const float4*>(p3.res + roff3 + (long long)(8 * Q + r) * p3.res_ld);
-          r7[r] = *reinterpret_cast<const float4*>(p7.res + roff7 + (long long)(8 * Q + r) * p7.res_ld);
-          r11[r] = *reinterpret_cast<const float4*>(p11.res + roff11 + (long long)(8 * Q + r) * p11.res_ld);
-        }
+        if constexpr (!PIPE) rq(cur, Q);
         float4 vo[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<G11, NACC>(M, 4 * Q + r);
+        if constexpr (PIPE && Q < 3) {
+          __builtin_amdgcn_sched_barrier(0);                 // the next quarter's loads go out here, not behind this quarter's stores
+          rq(nxt, Q + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          vo[r].x = ((vo[r].x + r3[r].x) + r7[r].x) + r11[r].x;
-          vo[r].y = ((vo[r].y + r3[r].y) + r7[r].y) + r11[r].y;
-          vo[r].z = ((vo[r].z + r3[r].z) + r7[r].z) + r11[r].z;
-          vo[r].w = ((vo[r].w + r3[r].w) + r7[r].w) + r11[r].w;
+          vo[r].x = ((vo[r].x + cur[r].x) + cur[4 + r].x) + cur[8 + r].x;
+          vo[r].y = ((vo[r].y + cur[r].y) + cur[4 + r].y) + cur[8 + r].y;
+          vo[r].z = ((vo[r].z + cur[r].z) + cur[4 + r].z) + cur[8 + r].z;
+          vo[r].w = ((vo[r].w + cur[r].w) + cur[4 + r].w) + cur[8 + r].w;
           if (dodiv) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q) * ylb + yo4[r]) = vo[r];
       };
-      quarter(std::integral_constant<int, 0>{});
-      quarter(std::integral_constant<int, 1>{});
-      quarter(std::integral_constant<int, 2>{});
-      quarter(std::integral_constant<int, 3>{});
+      quarter(std::integral_constant<int, 0>{}, ra, rb);
+      quarter(std::integral_constant<int, 1>{}, rb, ra);
+      quarter(std::integral_constant<int, 2>{}, ra, rb);
+      quarter(std::integral_constant<int, 3>{}, rb, ra);
     }
   }
 }
@@ -321,7 +332,8 @@ template <int NRT, int PERM, bool F44 = false>
 static int acc3_launch_n(const WinoAcc3& g, hipStream_t st) {
   using AG = Acc3Geo<NRT, PERM, F44>;
   static_assert(AG::LDS_BYTES <= 160 * 1024, "tile does not fit");
-  auto kern = conv_wino4_acc3_kernel<NRT, PERM, F44>;
+  static const bool pipe = F44 && getenv("SVOC_W4_ACC3_PIPE") && atoi(getenv("SVOC_W4_ACC3_PIPE")) == 1;      // experiment
+  auto kern = pipe ? conv_wino4_acc3_kernel<NRT, PERM, F44, F44> : conv_wino4_acc3_kernel<NRT, PERM, F44, false>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const unsigned grid = (unsigned)std::min<long long>(g.total, (long long)device_cu_count());
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)AG::LDS_BYTES, st, g);
