@@ -192,7 +192,10 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
 }
 
 // PIPE: the epilogue's residual loads are software-pipelined - quarter 0's twelve 16-byte loads are requested before the last member's
-// stages, quarter Q + 1's behind quarter Q's output transform (whose accumulator rows are dead by then)
+// stages, quarter Q + 1's behind quarter Q's output transform (whose accumulator rows are dead by then).  With the seven accumulators of
+// the F(4,4) form there is room for the two sets of twelve registers (254 registers, 0-2 spilled; with F(4,3)'s eight the same code
+// spilled 14-19 and gained nothing): accumulate launches 772 / 1666 / 1030 / 776 -> 777 / 1650 / 1004 / 734 us at C = 256 / 128 / 64 / 32,
+// 16x512 step 26.49 -> 26.34 ms (profiles/r04_accumulate_pipelined_residuals_{on,off}.txt).  On with F44, off without.
 template <int NRT, int PERM, bool F44 = false, bool PIPE = false>
 __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 g) {
   using AG = Acc3Geo<NRT, PERM, F44>;
@@ -332,8 +335,7 @@ template <int NRT, int PERM, bool F44 = false>
 static int acc3_launch_n(const WinoAcc3& g, hipStream_t st) {
   using AG = Acc3Geo<NRT, PERM, F44>;
   static_assert(AG::LDS_BYTES <= 160 * 1024, "tile does not fit");
-  static const bool pipe = F44 && getenv("SVOC_W4_ACC3_PIPE") && atoi(getenv("SVOC_W4_ACC3_PIPE")) == 1;      // experiment
-  auto kern = pipe ? conv_wino4_acc3_kernel<NRT, PERM, F44, F44> : conv_wino4_acc3_kernel<NRT, PERM, F44, false>;
+  auto kern = conv_wino4_acc3_kernel<NRT, PERM, F44, F44>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
   const unsigned grid = (unsigned)std::min<long long>(g.total, (long long)device_cu_count());
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)AG::LDS_BYTES, st, g);
