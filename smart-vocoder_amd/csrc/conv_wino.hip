@@ -1114,6 +1114,7 @@ static double wino4_exec_ratio(int K, bool f44) { const int G = (K + 1) / 4; ret
 static int wino4_nc(const PackedWino& pw) { return pw.mtiles % 4 == 0 ? 4 : (pw.mtiles == 1 ? 1 : 2); }      // row tiles per workgroup: 128-, 64- or 32-row blocks
 static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const WinoArgs& w, WinoArgs& w4) {
   if (!wino4_enabled() || !pw.wp4.p || !(dil == 1 || dil == 3 || dil == 5) || (dil == 1 && (a.Ncols & 3))) return false;
+  if ((long long)pw.Cin * a.x_ld * 4 >= (1LL << 31)) return false;                 // the producers' staging loads: 32-bit offsets within one batch element
   const EpiOut& o = a.out[0];
   if (dil == 1) {                                           // contiguous outputs: 16-byte stores
     if ((reinterpret_cast<uintptr_t>(o.y) & 15) || (o.y_ld & 3) || (o.y_bs & 3)) return false;

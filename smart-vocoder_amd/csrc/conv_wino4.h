@@ -101,6 +101,22 @@ struct W4Geo {
   static constexpr int acc(int t) { return t < NGS ? (t / KGS) % NV : (tr(t) == 0 ? 0 : (tr(t) == 3 ? 5 : 5 + tr(t))); }
 };
 
+// Sixteen bytes at base + soff + voff: the per-lane part of the address is a 32-bit VGPR offset, everything else sits in SGPRs (buffer
+// descriptor + scalar offset), so the producers' staging loads cost no VALU address arithmetic (as pointers they were a 64-bit
+// v_lshl_add_u64 per load and stage).  base / soff wave-uniform, base + soff + voff within 2 GB of base (host: wino4_args).
+__device__ __forceinline__ float4 w4_load16(const void* base, const unsigned voff, const int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+  const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+  return *reinterpret_cast<const float4*>(&t);
+}
+
+// (o, e) -> (e + o, e - o) in one packed instruction: low result = high half + low half, high result = high half - low half
+__device__ __forceinline__ f32x2 w4_pk_sum_diff(const f32x2 oe) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(oe));
+  return r;
+}
+
 // ---- the transforms, shared by every kernel of the family (conv_wino4_kernels.h, conv_wino4_acc.hip, conv_wino4_pair.hip)
 // input transform of one window: d0 .. d5 (F44: d6) -> the planes of plane set `o` (this item's entry), PLANE floats apart
 template <class Geo>
@@ -108,24 +124,33 @@ __device__ __forceinline__ void w4_input_transform(float* const o, const float d
                                                    const float d5, const float d6) {
   constexpr int PLANE = Geo::PLANE;
   if constexpr (Geo::F44) {
-    const float e1 = __builtin_fmaf(-4.25f, d4, d2 + d6), o1 = __builtin_fmaf(-4.25f, d3, d1 + d5);
-    const float e2 = __builtin_fmaf(-1.25f, d4, __builtin_fmaf(0.25f, d2, d6)), o2 = __builtin_fmaf(2.f, d5, __builtin_fmaf(-2.5f, d3, 0.5f * d1));
-    const float e3 = __builtin_fmaf(-5.f, d4, __builtin_fmaf(4.f, d2, d6)), o3 = __builtin_fmaf(0.5f, d5, __builtin_fmaf(-2.5f, d3, 2.f * d1));
+    // Packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per issue slot): the samples pair up as (odd, even)
+    // = (d1, d2), (d3, d4), (d5, d6) - adjacent registers of the window's 16- and 8-byte LDS reads - so each (o_i, e_i) is two or three
+    // packed instructions and each (e_i + o_i, e_i - o_i) one: 14 VALU instructions per window instead of 23.  Every producer VALU
+    // instruction costs the matrix pipe of its SIMD ~6.5 cycles, which is what this buys back.
+    const f32x2 p12 = {d1, d2}, p34 = {d3, d4}, p56 = {d5, d6};
+    const f32x2 s1 = __builtin_elementwise_fma(p34, (f32x2){-4.25f, -4.25f}, p12 + p56);
+    const f32x2 s2 = __builtin_elementwise_fma(p56, (f32x2){2.f, 1.f}, __builtin_elementwise_fma(p34, (f32x2){-2.5f, -1.25f}, p12 * (f32x2){0.5f, 0.25f}));
+    const f32x2 s3 = __builtin_elementwise_fma(p56, (f32x2){0.5f, 1.f}, __builtin_elementwise_fma(p34, (f32x2){-2.5f, -5.f}, p12 * (f32x2){2.f, 4.f}));
+    const f32x2 v12 = w4_pk_sum_diff(s1), v34 = w4_pk_sum_diff(s2), v56 = w4_pk_sum_diff(s3);
     o[0] = __builtin_fmaf(5.25f, d4 - d2, d0 - d6);
-    o[PLANE] = e1 + o1;
-    o[2 * PLANE] = e1 - o1;
-    o[3 * PLANE] = e2 + o2;
-    o[4 * PLANE] = e2 - o2;
-    o[5 * PLANE] = e3 + o3;
-    o[6 * PLANE] = e3 - o3;
+    o[PLANE] = v12.x;
+    o[2 * PLANE] = v12.y;
+    o[3 * PLANE] = v34.x;
+    o[4 * PLANE] = v34.y;
+    o[5 * PLANE] = v56.x;
+    o[6 * PLANE] = v56.y;
   } else {
-    const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);      // d4 - 4 d2, d3 - 4 d1
-    const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+    // packed likewise: (b, a) = (d3 - 4 d1, d4 - 4 d2), (e, c) = (2 (d3 - d1), d4 - d2): 9 VALU instructions instead of 12
+    const f32x2 p12 = {d1, d2}, p34 = {d3, d4};
+    const f32x2 ba = __builtin_elementwise_fma(p12, (f32x2){-4.f, -4.f}, p34);
+    const f32x2 ec = __builtin_elementwise_fma(p34, (f32x2){2.f, 1.f}, p12 * (f32x2){-2.f, -1.f});
+    const f32x2 v12 = w4_pk_sum_diff(ba), v34 = w4_pk_sum_diff(ec);
     o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-    o[PLANE] = a_ + b_;
-    o[2 * PLANE] = a_ - b_;
-    o[3 * PLANE] = c_ + e_;
-    o[4 * PLANE] = c_ - e_;
+    o[PLANE] = v12.x;
+    o[2 * PLANE] = v12.y;
+    o[3 * PLANE] = v34.x;
+    o[4 * PLANE] = v34.y;
     o[5 * PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
     if constexpr (Geo::ND > 0) { o[6 * PLANE] = d1; o[7 * PLANE] = d2; o[8 * PLANE] = d3; o[9 * PLANE] = d4; }
   }

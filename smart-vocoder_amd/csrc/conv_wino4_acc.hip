@@ -69,7 +69,9 @@ __device__ __forceinline__ void acc3_issue(float4 (&v)[Acc3Prod<Geo>::NV], const
   const long long ldb = (long long)p.x_ld * 4;
   const int L = p.L;
   const bool interior = xs >= 0 && xs + P::RAW <= L;
-  const char* cb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs) + (long long)ch * P::KS * ldb;
+  // 32-bit per-lane offsets against the batch element's base, the stage's rows as a scalar offset (w4_load16: no 64-bit VALU arithmetic)
+  const float* const xb = p.x + (long long)bz * p.x_bs;
+  const int so = ch * P::KS * (int)ldb;
   int l_ = lane;
   asm volatile("" : "+v"(l_));                             // keeps the per-lane address arithmetic inside the call (not hoisted and kept live)
   if constexpr (PERM > 0) {
@@ -81,14 +83,14 @@ __device__ __forceinline__ void acc3_issue(float4 (&v)[Acc3Prod<Geo>::NV], const
       const int row = P::RPW * pw_ + it / Geo::PNG, g = it % Geo::PNG;
       int bb = bf + g / PERM;
       if (!interior) bb = min(max(bb, 0), pnblk_row - 1);
-      v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)(PERM * bb + g % PERM) * 16);
+      v[u] = w4_load16(xb, (unsigned)(row * p.x_ld + 4 * (PERM * bb + g % PERM)) * 4u, so);
     }
   } else {
 #pragma unroll
     for (int u = 0; u < P::SPW; ++u) {
       const int it = min(l_ + 64 * u, P::NGW - 1);
       const int row = P::RPW * pw_ + it / P::R4, tg = xs + 4 * (it % P::R4);
-      v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)((interior || (tg >= 0 && tg + 3 < L)) ? tg : 0) * 4);
+      v[u] = w4_load16(xb, (unsigned)(row * p.x_ld + ((interior || (tg >= 0 && tg + 3 < L)) ? tg : 0)) * 4u, so);
     }
   }
 }

@@ -154,9 +154,9 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       const char* cb = xb_ + (long long)ch * KS * ldb;
       if constexpr (PERM > 0) {
         if (interior_) {                                   // whole q blocks from the one that holds column xs
-          const char* ct = cb + (long long)(xs_ / (4 * PERM)) * (16 * PERM);
+          const int so = ch * KS * (int)ldb + (xs_ / (4 * PERM)) * (16 * PERM);
 #pragma unroll
-          for (int u = 0; u < SPWP; ++u) v[u] = *reinterpret_cast<const float4*>(ct + pgoff[u]);
+          for (int u = 0; u < SPWP; ++u) v[u] = w4_load16(xb_, pgoff[u], so);
         } else {                                           // edge tile: the same groups from blocks clamped into the row (zeroed by publish)
           const int bf = pfirst(xs_);
 #pragma unroll
@@ -166,9 +166,9 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
           }
         }
       } else if (interior_) {
-        const char* ct = cb + (long long)xs_ * 4;
+        const int so = ch * KS * (int)ldb + xs_ * 4;
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) v[u] = *reinterpret_cast<const float4*>(ct + goff[u]);
+        for (int u = 0; u < SPW; ++u) v[u] = w4_load16(xb_, goff[u], so);
       } else {
         int l_ = lane;
         asm volatile("" : "+v"(l_));

@@ -136,9 +136,10 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     auto issue = [&](int bz_, int xs_, int ch) {
       const char* cb = reinterpret_cast<const char*>(pm.x + (long long)bz_ * pm.x_bs) + (long long)ch * KS * ldb;
       if (xs_ >= 0 && xs_ + RAW1 <= L) {
-        const char* ct = cb + (long long)xs_ * 4;
+        const float* const xb = pm.x + (long long)bz_ * pm.x_bs;
+        const int so = ch * KS * (int)ldb + xs_ * 4;
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) v[u] = *reinterpret_cast<const float4*>(ct + goff[u]);
+        for (int u = 0; u < SPW; ++u) v[u] = w4_load16(xb, goff[u], so);
       } else {
         int l_ = lane;
         asm volatile("" : "+v"(l_));
@@ -354,6 +355,7 @@ long long wino4_pair_tiles(int C, int L, int B, int D1) {
 int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2, const float* const* x, float* const* y, long long bs, int ld,
                       int B, int L, int D1, float slope, hipStream_t st) {
   if (!wino4_pair_enabled() || B <= 0 || (L & 3) || (ld & 3) || (bs & 3) || !(D1 == 1 || D1 == 3 || D1 == 5)) return 1;
+  if (64LL * ld * 4 >= (1LL << 31)) return 1;               // the producers' staging loads: 32-bit offsets within one batch element
   static const int ks[3] = {11, 7, 3};
   static const bool c64 = !(getenv("SVOC_W4_PAIR64") && atoi(getenv("SVOC_W4_PAIR64")) == 0);      // SVOC_W4_PAIR64=0: the C = 64 stage conv by conv
   const int C = pw1[0] ? pw1[0]->Cin : 0;
