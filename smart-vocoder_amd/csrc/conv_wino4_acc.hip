@@ -129,14 +129,14 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
       pgb[u] = (g / PERM) | ((g % PERM) << 16);
     }
   }
-  const float* tsrc[TPW];
-  int tdst[TPW];
+  int tsrc[TPW], tdst[TPW];
 #pragma unroll
   for (int u = 0; u < TPW; ++u) {
     const int it = min(l_ + 64 * u, NIW - 1);
     const int row = RPW * pw_ + it / NE, e = it % NE;
-    tsrc[u] = raw + row * RAWS + PORG + 4 * e;
+    tsrc[u] = row * RAWS + PORG + 4 * e;
     tdst[u] = row * PQ + e;
+    asm volatile("" : "+v"(tsrc[u]), "+v"(tdst[u]));       // kept in registers over the member's stages, not re-computed at each (conv_wino4_kernels.h)
   }
   for (int ch = 0; ch < nst; ++ch) {
     // ---- publish own rows
@@ -183,7 +183,7 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
-        w4_transform_window<Geo>(pb + tdst[u], tsrc[u]);
+        w4_transform_window<Geo>(pb + tdst[u], raw + tsrc[u]);
       }
     }
     // B_s: plane set complete.  Three sets: the barrier behind stage s is B_{s-1} (started = a stage has been produced before), the

@@ -123,7 +123,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     const int pnblk_row = PERM > 0 ? (L + 4 * PERM - 1) / (4 * PERM) : 0;      // q blocks of a row
     // first q block a tile loads: the one that holds column xs (xs >= -4 PERM: the left halo is at most 8 columns)
     auto pfirst = [&](int xs_) -> int { return (xs_ + 4 * PERM) / (4 * PERM) - 1; };
-    const float* tsrc[TPW];                                // D = 1: the item's samples; D > 1: the item's raw row (the column follows the tile)
+    int tsrc[TPW];                                         // float offset inside `raw`: D = 1: the item's samples; D > 1: the item's raw row (the column follows the tile)
     int tdst[TPW];                                         // float offset of the item's entry inside plane 0 of a set
     int tent[TPW];                                         // D > 1: the item's entry index e
     int toff[TPW];                                         // D > 1: raw column of the item's d0 in the current tile
@@ -132,9 +132,13 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       const int it = min(lane + 64 * u, NIW - 1);
       const int row = RPW * pw_ + it / IPR, e = it % IPR;
       // D = 1: the sixteen-byte group that holds d1..d4 (LEAD = 3) or d0..d2 | d3..d5 (LEAD = 1) of the window starts at 4 e (+ 4)
-      tsrc[u] = D == 1 ? raw + row * RAWS + PORG + 4 * e : raw + row * RAWS;
+      tsrc[u] = D == 1 ? row * RAWS + PORG + 4 * e : row * RAWS;
       tdst[u] = row * PQ + e;
       tent[u] = e; toff[u] = 0;
+      // opaque from here on: left to itself the compiler RE-COMPUTES these per-lane constants (the divisions by the entries per row
+      // included) at every stage - ~40 VALU instructions per stage beside the transform's 70, each of which costs the SIMD's matrix
+      // pipe its issue time - instead of keeping them in two registers per item
+      asm volatile("" : "+v"(tsrc[u]), "+v"(tdst[u]));
     }
     // D > 1: entry e is window w0 + e = (q block b0 + (ph0 + e) / D, phase (ph0 + e) % D): its d0 sits 4 D qe + pe - ph0 samples
     // behind the tile's first sample
@@ -266,7 +270,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
 #pragma unroll
       for (int u = 0; u < TPW; ++u) {
         if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
-          w4_transform_window<Geo>(pb + tdst[u], D == 1 ? tsrc[u] : tsrc[u] + toff[u]);
+          w4_transform_window<Geo>(pb + tdst[u], D == 1 ? raw + tsrc[u] : raw + tsrc[u] + toff[u]);
         }
       }
       long long pb0 = 0;

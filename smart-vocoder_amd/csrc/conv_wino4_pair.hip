@@ -123,6 +123,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
       const int qe = e / D1, pe = e - qe * D1;
       t1off[u] = row * RAW1 + 4 * D1 * qe + pe;
       t1dst[u] = row * PQ1 + e;
+      asm volatile("" : "+v"(t1off[u]), "+v"(t1dst[u]));     // kept in registers, not re-computed at every stage (conv_wino4_kernels.h)
     }
     int t2src[TPW2], t2dst[TPW2];                            // c2 transform items: row and window of the intermediate tile, plane entry
 #pragma unroll
@@ -131,6 +132,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
       const int row = RPW * pw_ + it / NE2, e = it % NE2;
       t2src[u] = row * MIDS + 4 * e;
       t2dst[u] = row * PQ2 + e;
+      asm volatile("" : "+v"(t2src[u]), "+v"(t2dst[u]));
     }
     float4 v[SPW];
     auto issue = [&](int bz_, int xs_, int ch) {
