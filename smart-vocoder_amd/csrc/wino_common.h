@@ -52,7 +52,9 @@ __device__ __forceinline__ void wino_static_for(F&& f) {
   }
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// leaky relu of four values in 6 instructions (2 packed multiplies + 4 max; fmaxf() costs a canonicalising max more each)
+// leaky relu of four values in 6 instructions (2 packed multiplies + 4 max; fmaxf() costs a canonicalising max more each; round 4:
+// the select on the sign bit with integer compare / select pairs instead of the four v_max_f32 is 10 instructions and measured
+// SLOWER, 16x512 step 25.8 -> 26.7 ms: profiles/r04_producer_valu_diet.txt)
 __device__ __forceinline__ void wino_lrelu4(float4& q, const float slope) {
   const f32x2 s2 = {slope, slope};
   const f32x2 a = (f32x2){q.x, q.y} * s2, b = (f32x2){q.z, q.w} * s2;
