@@ -201,7 +201,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
         __syncthreads();                                     // B_s: plane set complete
         s_ ^= 1;
       }
-      __syncthreads();                                       // X: the consumers have written the intermediate tile
+      __syncthreads();                                       // X: the consumers have written the rows of c2's first stage into the intermediate tile
       // ---------------- phase B: c2's four stages from the intermediate tile; the next tile's first raw rows are requested meanwhile
       if (more) issue(bzn, xs1n, 0);
       for (int ch = 0; ch < 4; ++ch) {
@@ -253,12 +253,14 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     acc3_consume<G1, NACC, 2>(p1, M, plbase, PLFMAX, wt1, s_, wlane, (unsigned)(hi * G1::PQ + uu) * 4u);
     // ---- epilogue A: lrelu(c1) -> the intermediate tile, zero outside [0, L).  Window uu = q block uu / D1, phase uu % D1: its four
     // outputs are D1 columns apart
-    if (uu < NWC1) {
+    {
+      const bool act = uu < NWC1;
       const int bq = uu / D1, ph = uu - bq * D1;
       const int c0 = 4 * D1 * bq + ph;                       // column of output 0 inside the tile
       const int n0 = m0 + c0;
       auto quarter = [&](auto q_c) {
         constexpr int Q = decltype(q_c)::value;
+        if (!act) return;
         float4 vo[4];
         ytrans(q_c, vo);
 #pragma unroll
@@ -276,12 +278,17 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
           }
         }
       };
+      // X: c2's first stage stages channels 0 .. 8 NRT - 1 = the rows of quarters 0 .. NRT - 1 of row tile 0, so the producers are let go
+      // as soon as THOSE are written and transform c2's first stage while the consumers store the remaining quarters (rows 8 NRT ..,
+      // complete before the consumers arrive at that stage's barrier, behind which the producers turn to the next stage's rows).
+      // (A first version held the producers until the whole intermediate tile was written: the producer pass it exposed was 3-4 % of a tile.)
       quarter(std::integral_constant<int, 0>{});
+      if constexpr (NRT == 1) __syncthreads();
       quarter(std::integral_constant<int, 1>{});
+      if constexpr (NRT == 2) __syncthreads();
       quarter(std::integral_constant<int, 2>{});
       quarter(std::integral_constant<int, 3>{});
     }
-    __syncthreads();                                         // X: the intermediate tile is complete
     // ---------------- phase B: c2, then + x and store
     init_bias(pm.bias2);
     acc3_consume<G2, NACC, 2>(p2, M, plbase, PLFMAX, wt2, s_, wlane, (unsigned)(hi * G2::PQ + uu) * 4u);
