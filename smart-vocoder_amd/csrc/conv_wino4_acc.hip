@@ -43,6 +43,7 @@ struct Acc3Geo {
   static constexpr int PLFMAX = cmax(G3::PLF, cmax(G7::PLF, G11::PLF));
   // Two plane sets.  (Three - with the k = 3 member staged half as wide, W4Geo's KSDIV, so that they fit - measured SLOWER: accumulate
   // launches 1769 -> 1800 / 1108 -> 1137 / 795 -> 826 us at C = 128 / 64 / 32: the k = 3 stages get too short for their barriers.)
+  // With the seven planes of the F(4,4) form three sets fit as they are: 750 / 1611 / 965 / 684 -> 754 / 1614 / 967 / 706 us, not taken either.
   static constexpr int NPS = 2;
   static constexpr int LDS_BYTES = (RAWMAX + NPS * PLFMAX) * 4;
   static_assert(G3::NWT == G7::NWT && G7::NWT == G11::NWT, "one tile space");
