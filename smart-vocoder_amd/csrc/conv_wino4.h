@@ -48,6 +48,8 @@ struct W4Geo {
   // Weight registers: a slot of a stage is KGS float4 per lane = 4 KGS MFMAs.  With KGS = 4 the next slot is requested one slot
   // (1024 cycles of MFMAs) ahead in the other of two register sets; with KGS = 2 / 1 one slot is only 512 / 256 cycles - less than a
   // loaded L2 round trip (round 4: 77-84 cycles per MFMA in the C = 32 streams) - so those run a ring of four sets, three slots ahead.
+  // (k = 3 with KGS = 4 on the ring of four as well - its streams run at 75 cycles per MFMA against 68 for k = 7 / 11 - measured: alone
+  // 75.6 -> 74.1 at C = 128, 92.1 -> 85.7 at C = 64, inside the grouped launches nothing; not taken.)
   static constexpr int NSET = KGS == 4 ? 2 : 4;
   static constexpr int PD = NSET - 1;                     // slots ahead
   static constexpr int G = (K + 1) / 4;                   // three-tap (F44: four-tap) groups at tap offsets 0, 4, 8
