@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_SAMPLE = 2568280.0          # 2*MAC of the 184 convolutions per output sample
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 SAMPLE_RATE = 22050
-ROUND_TAG = "r04"                     # only PMC traffic files of this round's code are quoted
+ROUND_TAG = "r05"                     # only PMC traffic files of this round's code are quoted
 
 
 def _cpu_info():
@@ -98,10 +98,19 @@ def cpu_baseline(sd_np, seed, keep=None):
                 dt, n = run(mel, ln, eps, tag if rep == 0 else None)
                 times.append(dt)
             rec[tag] = dict(value=n / min(times), unit="samples/s", shape=f"{B}x{T}", best_s=min(times), all_s=[round(t, 3) for t in times])
+            if tag == "c2" and phys and min(avail, phys) != cores:
+                # SURVEY.md 8(d) names "all physical host cores": the same workload once at that thread count, beside the best one
+                nall = min(avail, phys)
+                torch.set_num_threads(nall)
+                run(mel[:wb], ln[:wb], eps[:wb])
+                dt, n = run(mel, ln, eps)
+                rec["c2_all_cores"] = dict(value=n / dt, unit="samples/s", threads=nall, shape=f"{B}x{T}", s=round(dt, 3), runs=1)
+                torch.set_num_threads(cores)
     return dict(value=rec["c2"]["value"], unit="samples/s", cores=cores, kind="port",
                 sample=f"16x512 frames (the bench workload, whole batch), 1 warm-up + best of 3 = {rec['c2']['best_s']:.2f} s; "
                        f"{cores} of {avail} host threads (best of an 8/16/32/64 probe), torch {torch.__version__} fp32 oneDNN",
                 cpu_model=model, physical_cores=phys, logical_cpus=avail, c1_1x200=rec["c1"], c2_16x512=rec["c2"],
+                c2_16x512_all_physical_cores=rec.get("c2_all_cores"),
                 cores_note=f"SURVEY.md 8(d) asks for all physical cores ({phys}); {cores} threads measured FASTER than more in the probe "
                            "(oneDNN's small convolutions stop scaling), so the best thread count is the one reported",
                 protocol="SURVEY.md 8(d): 1 warm-up + best of 3, C1 and C2", wall_s=round(time.perf_counter() - t_all, 1))
@@ -296,7 +305,18 @@ def main():
             return out
         return o
 
-    def step():
+    marks = []                                     # N>1: (before infer, after infer, after gather) events of every timed step, on the launch stream
+
+    def step(timed=False):
+        if timed and use_dist:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            o = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+            ev[1].record()
+            r = collect(o)
+            ev[2].record()
+            marks.append(ev)
+            return r
         o = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
         return collect(o)
 
@@ -334,7 +354,7 @@ def main():
         t0 = time.perf_counter()
         ev0.record()                     # the HIP kernels are enqueued on torch's current stream
         for _ in range(args.steps):
-            out = step()
+            out = step(timed=True)
         ev1.record()
         torch.cuda.synchronize()
         if use_dist:
@@ -360,10 +380,52 @@ def main():
         tsc = torch.tensor([(time.perf_counter() - ts) / nsc * 1e3], dtype=torch.float64, device=cdev)
         dist.all_reduce(tsc, op=dist.ReduceOp.MAX)
         scatter_ms = float(tsc.item())
+    per_rank = sharded = None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt_own, dt = dt, float(tt.item())
+        # Attribution of the N>1 line: per rank, the mean device time of `infer` and of the waveform gather inside the
+        # timed steps (HIP events on the launch stream; the gather's span includes waiting for the slowest peer) and the rank's own wall time.
+        inf_ms = sum(e[0].elapsed_time(e[1]) for e in marks) / max(1, len(marks))
+        gat_ms = sum(e[1].elapsed_time(e[2]) for e in marks) / max(1, len(marks))
+        mine = torch.tensor([dt_own / args.steps * 1e3, inf_ms, gat_ms, gpu_ms / args.steps], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"step_wall_ms": [float(t[0]) for t in allr], "infer_ms": [float(t[1]) for t in allr], "gather_ms": [float(t[2]) for t in allr],
+                    "step_gpu_ms": [float(t[3]) for t in allr]}
+        # The public entry point itself: parallel.infer_sharded (ONE scatter of (lengths | mel | eps) from rank 0 + infer + ONE gather per call,
+        # shapes passed by the caller so that nothing is broadcast or read back), K calls between the same barriers.  A second figure:
+        # `value` stays the weak-scaling step above (inputs resident on every rank), this one moves the job's inputs from rank 0 every call.
+        full = None
+        if rank == 0:
+            full = [torch.from_numpy(sw.synthetic_mel(1001, Bj, T)).to(dev), torch.full((Bj,), T, dtype=torch.int64, device=dev),
+                    torch.from_numpy(sw.synthetic_eps(1001, Bj, T)).to(dev)]
+        sh_out = None
+        if rank == 0:
+            sh_out = torch.empty((Bj, 1, T * net.dec.hop), dtype=torch.float32, device=dev if cdev.type != "cpu" else torch.device("cpu"))
+        try:
+            with torch.no_grad():
+                def sharded_call():
+                    return parallel.infer_sharded(net, full[0] if full else None, full[1] if full else None, full[2] if full else None,
+                                                  noise_scale=0.667, src=0, shape=(Bj, T), out=sh_out)
+                for _ in range(max(1, min(2, args.warmup))):
+                    o_sh = sharded_call()
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    o_sh = sharded_call()
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            tsh = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
+            sharded = {"ms_per_call": float(tsh.item()) / args.steps * 1e3, "calls": args.steps,
+                       "samples_per_s": Bj * T * net.dec.hop * args.steps / float(tsh.item()),
+                       "what": "parallel.infer_sharded(shape=(B, T), out=...): scatter of the job's inputs from rank 0 + infer + gather per call, max over ranks"}
+            if rank == 0:
+                sharded["equals_timed_step_output"] = bool(torch.equal(o_sh.to(out.device), out))
+        except Exception as e:   # noqa: BLE001
+            sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+        del full
 
     if rank == 0:
         samples_per_step = Bj * T * net.dec.hop
@@ -387,6 +449,18 @@ def main():
             "real_time_factor": value / SAMPLE_RATE / world,
             "samples_per_s_per_gpu": value / world,
         }
+        if per_rank is not None:
+            res["per_rank"] = per_rank
+            res["step_ms_min_over_ranks"] = min(per_rank["step_wall_ms"])
+            res["step_ms_max_over_ranks"] = max(per_rank["step_wall_ms"])
+            res["infer_ms_min_over_ranks"], res["infer_ms_max_over_ranks"] = min(per_rank["infer_ms"]), max(per_rank["infer_ms"])
+            res["gather_ms"] = per_rank["gather_ms"][0]
+            res["per_rank_note"] = ("means over the timed steps; infer_ms / gather_ms = HIP events on each rank's launch stream around net.infer and the "
+                                    "waveform gather (rank 0's gather span includes waiting for the slowest peer), step_wall_ms = the rank's own wall clock "
+                                    "between the barriers; `ms_per_step` is the max over ranks")
+            res["infer_sharded"] = sharded
+        res["scaling_curve"] = ("this line is one point of the weak-scaling curve (the driver derives efficiency from the N = 1, 2, 4, 8 lines)" if world > 1 else
+                                "NOT MEASURED by this line: world size 1 moves no bytes over xGMI; no scaling number is claimed")
         # Roofline.  `achieved` / `frac` (round 4): 2*MAC the matrix pipe really ISSUED in the timed region - counted per launch by
         # the library (the Winograd kernels issue a fixed share of the direct form's multiply-adds) and checked against the hardware's
         # SQ_INSTS_VALU_MFMA_MOPS_F32 count below - over the device time of the region (HIP events on the launch stream; conservative: the region
@@ -402,9 +476,9 @@ def main():
                            "winograd_form_floor_ms": stats["executed_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "direct_form_floor_ms": stats["conv_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group|_acc3|_pair)_kernel (Winograd F(4,4) for k=7/11 at C>=128, F(4,3) otherwise: every ResBlock convolution of the decoder), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, wn_layer_fused(_ks)_kernel (fallbacks: resblock_fused_ct_kernel, conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group|_acc3|_pair)_kernel (every ResBlock convolution of the decoder, all four stages: Winograd F(4,4) for k=7/11, F(4,3) for k=3; SVOC_W4_F44=0: F(4,3) throughout), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, wn_layer_fused(_ks)_kernel (fallbacks: resblock_fused_ct_kernel, conv_wino(_ws)(_group)_kernel F(2,3), conv_group_kernel)",
                            "note": "achieved/frac = executed 2*MAC / time (<= peak). Shares of the direct form's multiply-adds issued per kernel size k=3/7/11: "
-                                   "F(4,3) (default) 1/2, 4/7, 6.5/11; F(4,4) (C>=128 stages, k=7/11) 3.5/7, 5.25/11 (merged accumulate launch: k=3 1.75/3); "
+                                   "F(4,3) (k=3; every k with SVOC_W4_F44=0) 1/2, 4/7, 6.5/11; F(4,4) (default for k=7/11 in every stage) 3.5/7, 5.25/11 (merged accumulate launch: k=3 1.75/3 too); "
                                    "F(2,3) (fall-back) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8; F(2,5) WN in_layers 3/5; everything else 1. "
                                    "achieved_direct_form/frac_direct_form = algorithmic direct-form 2*MAC (SURVEY.md 8d) / time, NOT bounded by the peak; "
                                    "winograd_form_floor_ms = executed FLOPs of one step at 157.3 TFLOP/s",

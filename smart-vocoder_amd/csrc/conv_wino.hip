@@ -483,418 +483,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino_group_kernel(const WinoGroup
   else wino_tile<3, D, WM>(p, tl - t * p.ntn, t - bz * p.gy, bz, lin);
 }
 
-// ------------------------------------------------------------------ wave-specialised variant (4 x 1 tiles)
-// Default for 4 x 1 tiles with dilation 1 / 3 (SVOC_WINO_WS=0: the kernel above).  The workgroups above alternate between MFMA
-// phases and staging / transform / epilogue code, and although three of them share a CU the matrix pipe is busy only ~80 %
-// of the time: their phases correlate.  Here a
-// workgroup has EIGHT waves: waves 0-3 are consumers - one 32-row tile each, nothing but the MFMA stream, the weight
-// stream and the epilogue - and waves 4-7 are producers: producer p stages and transforms channel rows 8p..8p+7 of every
-// chunk (rows are wave-private, so staging -> transform needs no barrier) one stage ahead of the consumers, into the other
-// of two plane buffers.  One workgroup-wide barrier per stage: B_s is reached by the producers after producing stage s and
-// by the consumers after consuming stage s - 1.  Workgroups are persistent (a stage = (tile, chunk); the producers run
-// ahead across tile boundaries), two per CU.  Measured against the kernel above in one run (C = 128, us): k=3 375 / 410,
-// k=7 743 / 750, k=11 1020 / 1031 (d = 3: 430 / 440, 794 / 810, 1125 / 1138); 16 x 512 step -0.1 .. -0.2 ms.  The matrix pipe is
-// ~86 % busy.  Timing with work removed (profiles/r02_winograd_ws_phase_removal.txt): idle producers buy 1-8 %, no epilogue 2-13 %,
-// and the bare consumer streams still reach only 70 / 79 / 89 % of the pipe (k = 3 / 7 / 11): 0.7-1.2 us per stage go at the stage
-// boundaries.  Handing stages over through two LDS counters instead of the barrier (consumers then never wait for their
-// siblings) and serving the per-tile bias from LDS instead of global memory both measured no faster.  Per-workgroup stamps
-// (tools/wino_ws_timeline.py): the two workgroups of a CU finish 17 % apart (821 - 986 us at k = 11) although both have 16 tiles;
-// handing tiles out dynamically (device-wide counter) makes them finish together - at the LATE end (1011 us): the early one was
-// fast at the other's expense, the CU's throughput does not change (kernel 1052 against 1020 us).
-template <int K, int D, bool DBG = false>
-__device__ __forceinline__ void wino_ws_problem(const WinoArgs& p, const int v0, const int vend, const int first, const int stride) {
-  constexpr int WM = 4;
-  using Geo = WinoGeo<K, D, WM>;
-  constexpr int G = Geo::G, ND = Geo::ND, PADT = Geo::PADT, PQV = Geo::PQV, PQE = Geo::PQE, RAW = Geo::RAW, SLOTS = Geo::SLOTS;
-  constexpr int PU = Geo::PU, XOFF = Geo::XOFF, S = Geo::S, EO = Geo::EO, NQ = Geo::NQ, ESH = Geo::ESH;
-  constexpr int PLANE = KC * PQV, EBASE = 4 * PLANE, PLF = Geo::PL_FLOATS;
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  float* const raw = wl;                                   // [KC][RAW], producers only
-  float* const pl = wl + Geo::RAW_FLOATS;                  // two plane sets of PLF floats
-  if (v0 >= vend) return;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = p.L;
-  const int ntiles_all = vend - first;
-  const int nch = p.nchunks;
-  const int my_tiles = (vend - v0 + stride - 1) / stride;
-  const int nstages = my_tiles * nch;
-  auto locate = [&](int v, int& n0_, int& bz_, int& by_) {
-    const int tl = xcd_linear(v - first, ntiles_all, p.xcd);
-    const int t = tl / p.ntn;
-    bz_ = t / p.gy;
-    n0_ = (tl - t * p.ntn) * Geo::W;
-    by_ = t - bz_ * p.gy;
-  };
-
-  if (wave >= 4) {
-    // ================================================================= producer
-    const int pw_ = wave - 4;
-    constexpr int R4 = RAW / 4, NGW = 8 * R4, SPW = (NGW + 63) / 64;
-    constexpr int NQ2 = D == 1 ? Geo::NT : (NQ + 1) / 2, IPR = NQ2 * D, NIW = 8 * IPR, TPW = (NIW + 63) / 64;
-    const long long ldb = (long long)p.x_ld * 4;
-    const float slope = p.pre_slope;
-    unsigned goff[SPW];
-    float* rdst[SPW];
-#pragma unroll
-    for (int u = 0; u < SPW; ++u) {
-      const int it = min(lane + 64 * u, NGW - 1);
-      const int row = 8 * pw_ + it / R4, g4 = it % R4;
-      goff[u] = (unsigned)(row * p.x_ld + 4 * g4) * 4u;
-      rdst[u] = raw + row * RAW + 4 * g4;
-    }
-    const float* tsrc[TPW];
-    int tdst[TPW], tedst[TPW];                             // float offsets inside a plane set
-    unsigned tflags = 0;
-#pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-      const int it = min(lane + 64 * u, NIW - 1);
-      const int row = 8 * pw_ + it / IPR, rem = it % IPR;
-      const int tq2 = rem / D, tph = rem - tq2 * D;
-      tsrc[u] = D == 1 ? raw + row * RAW + 4 * tq2 : raw + row * RAW + (4 * tq2 - PADT) * D + tph - XOFF;
-      tdst[u] = row * PQV + 2 * tq2 * D + tph;
-      const int e1 = (2 * tq2 - ESH) * D + tph;
-      tedst[u] = EBASE + row * PQE + e1;
-      const bool second = D == 1 || 2 * tq2 + 1 < NQ;
-      if (second) tflags |= 1u << (3 * u);
-      if (e1 >= 0 && e1 < Geo::NUE) tflags |= 2u << (3 * u);
-      if (second && e1 + D < Geo::NUE) tflags |= 4u << (3 * u);
-    }
-    float4 v[SPW];
-    int n0 = 0, bz = 0, by = 0;
-    auto issue = [&](const char* xb_, int xs_, bool interior_, int ch) {
-      const char* cb = xb_ + (long long)ch * KC * ldb;
-      if (interior_) {
-        const char* ct = cb + (long long)xs_ * 4;
-#pragma unroll
-        for (int u = 0; u < SPW; ++u) v[u] = *reinterpret_cast<const float4*>(ct + goff[u]);
-      } else {
-        int l_ = lane;
-        asm volatile("" : "+v"(l_));
-#pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-          const int it = min(l_ + 64 * u, NGW - 1);
-          const int row = 8 * pw_ + it / R4, tg = xs_ + 4 * (it % R4);
-          v[u] = *reinterpret_cast<const float4*>(cb + (long long)row * ldb + (long long)((tg >= 0 && tg + 3 < L) ? tg : 0) * 4);
-        }
-      }
-    };
-    // stage 0 request
-    locate(v0, n0, bz, by);
-    {
-      const int xs = n0 + XOFF;
-      issue(reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs), xs, xs >= 0 && xs + RAW <= L, 0);
-    }
-    int ti = 0, ch = 0;                                    // stage s = (tile ti, chunk ch)
-    for (int s_ = 0; s_ < nstages; ++s_) {
-      const int xs_start = n0 + XOFF;
-      const bool interior = xs_start >= 0 && xs_start + RAW <= L;
-      const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
-      // ---- publish own rows (lrelu, zero padding on edge tiles)
-      if (interior) {
-#pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-          if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
-            float4 q = v[u];
-            wino_lrelu4(q, slope);
-            *reinterpret_cast<float4*>(rdst[u]) = q;
-          }
-        }
-      } else {
-        int l_ = lane;
-        asm volatile("" : "+v"(l_));
-#pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-          if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
-            const int it = l_ + 64 * u;
-            const int row = 8 * pw_ + it / R4, tg = xs_start + 4 * (it % R4);
-            float4 q = v[u];
-            if (!(tg >= 0 && tg + 3 < L)) {
-              const float* xr = reinterpret_cast<const float*>(xb + (long long)(ch * KC + row) * ldb);
-              q.x = (tg >= 0 && tg < L) ? xr[tg] : 0.f;
-              q.y = (tg + 1 >= 0 && tg + 1 < L) ? xr[tg + 1] : 0.f;
-              q.z = (tg + 2 >= 0 && tg + 2 < L) ? xr[tg + 2] : 0.f;
-              q.w = (tg + 3 >= 0 && tg + 3 < L) ? xr[tg + 3] : 0.f;
-            }
-            wino_lrelu4(q, slope);
-            *reinterpret_cast<float4*>(rdst[u]) = q;
-          }
-        }
-      }
-      // ---- request the next stage's raw rows (next chunk, or chunk 0 of this workgroup's next tile)
-      int nti = ti, nchn = ch + 1, n0n = n0, bzn = bz, byn = by;
-      if (nchn == nch) { nchn = 0; ++nti; if (nti < my_tiles) locate(v0 + nti * stride, n0n, bzn, byn); }
-      if (s_ + 1 < nstages) {
-        const int xsn = n0n + XOFF;
-        issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= L, nchn);
-      }
-      // ---- transform own rows into plane set s & 1 (LDS operations of one wave execute in order: no barrier needed)
-      float* const pb = pl + (s_ & 1) * PLF;
-#pragma unroll
-      for (int u = 0; u < TPW; ++u) {
-        if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
-          const float* r = tsrc[u];
-          float* o = pb + tdst[u];
-          if constexpr (D == 1) {
-            const float4 fa = *reinterpret_cast<const float4*>(r), fb = *reinterpret_cast<const float4*>(r + 4);
-            const float d0 = fa.y, d1 = fa.z, d2 = fa.w, d3 = fb.x, d4 = fb.y, d5 = fb.z;
-            *reinterpret_cast<float2*>(o) = make_float2(d0 - d2, d2 - d4);
-            *reinterpret_cast<float2*>(o + PLANE) = make_float2(d1 + d2, d3 + d4);
-            *reinterpret_cast<float2*>(o + 2 * PLANE) = make_float2(d2 - d1, d4 - d3);
-            *reinterpret_cast<float2*>(o + 3 * PLANE) = make_float2(d3 - d1, d5 - d3);
-            if constexpr (ND > 0) {
-              *reinterpret_cast<float2*>(o + 4 * PLANE) = make_float2(d1, d3);
-              *reinterpret_cast<float2*>(o + 5 * PLANE) = make_float2(d2, d4);
-            }
-          } else {
-            const float d0 = r[0], d1 = r[D], d2 = r[2 * D], d3 = r[3 * D];
-            o[0] = d0 - d2; o[PLANE] = d1 + d2; o[2 * PLANE] = d2 - d1; o[3 * PLANE] = d3 - d1;
-            float* oe = pb + tedst[u];
-            if constexpr (ND > 0) {
-              if (!Geo::ESHIFT || (tflags & (2u << (3 * u)))) { oe[0] = d1; oe[KC * PQE] = d2; }
-            }
-            if ((NQ & 1) == 0 || (tflags & (1u << (3 * u)))) {
-              const float d4 = r[4 * D], d5 = r[5 * D];
-              o[D] = d2 - d4; o[PLANE + D] = d3 + d4; o[2 * PLANE + D] = d4 - d3; o[3 * PLANE + D] = d5 - d3;
-              if constexpr (ND > 0) {
-                if (!Geo::ESHIFT || (tflags & (4u << (3 * u)))) { oe[D] = d3; oe[KC * PQE + D] = d4; }
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();                                     // B_s: plane set s & 1 complete
-      ti = nti; ch = nchn; n0 = n0n; bz = bzn; by = byn;
-    }
-    return;
-  }
-
-  // =================================================================== consumer: row tile `wave`
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int uu = l31;
-  const unsigned pbase = (unsigned)(size_t)pl;
-  const unsigned baddr0 = pbase + (unsigned)(hi * PQV + uu) * 4u, baddrE0 = pbase + (unsigned)(hi * PQE + uu) * 4u;
-  const unsigned wlane = (unsigned)lane * 16u;
-  f32x16 M[4];
-  float4 a[2][4];
-  auto mfma_chunk = [&](const unsigned baddr, const unsigned baddrE, const char* wa, const char* wnext, auto par) {
-    constexpr int PAR = decltype(par)::value;
-    constexpr int NS = 4 * SLOTS;
-    float fb[2][4], fo[2][4];
-    auto request = [&](auto tc) {
-      constexpr int T = decltype(tc)::value;
-      if constexpr (T < NS) {
-        constexpr int SG = T / 4, KG = T % 4;
-        if constexpr (SG < 4 * G) {
-          constexpr int GG = SG / 4, P = SG % 4;
-          wino_frag<PQV, P * PLANE, KG, (2 * GG + S) * D>(fb[T & 1], baddr);
-        } else {
-          constexpr int DI = SG - 4 * G;
-          constexpr int DQ = (G == 2) ? 1 : (DI == 0 ? 0 : 2);
-          wino_frag<PQE, EBASE, KG, (DQ - 1 + EO) * D>(fb[T & 1], baddrE);
-          wino_frag<PQE, EBASE + KC * PQE, KG, (DQ - 1 + EO) * D>(fo[T & 1], baddrE);
-        }
-      }
-    };
-    auto wait_for = [&](auto tc) {
-      constexpr int T = decltype(tc)::value;
-      constexpr int N = wino_step_reads<K>(T + 1);
-      float(&b)[4] = fb[T & 1];
-      if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-      else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-      else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-      if constexpr (wino_step_direct<K>(T)) {
-        float(&o)[4] = fo[T & 1];
-        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-      }
-    };
-    auto step = [&](auto tc) {
-      constexpr int T = decltype(tc)::value;
-      constexpr int SG = T / 4, KG = T % 4;
-      if constexpr (KG == 0) {
-        if constexpr (SG + 1 < SLOTS) {
-#pragma unroll
-          for (int kg = 0; kg < 4; ++kg) a[(PAR + SG + 1) & 1][kg] = *reinterpret_cast<const float4*>(wa + (SG + 1) * 4096 + kg * 1024 + wlane);
-        } else if (wnext) {
-#pragma unroll
-          for (int kg = 0; kg < 4; ++kg) a[(PAR + SG + 1) & 1][kg] = *reinterpret_cast<const float4*>(wnext + kg * 1024 + wlane);
-        }
-      }
-      wait_for(tc);
-      const float4 av = a[(PAR + SG) & 1][KG];
-      if constexpr (SG < 4 * G) {
-        constexpr int P = SG % 4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) M[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[P], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          M[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fb[T & 1][s], M[0], 0, 0, 0);
-          M[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wino_pick(av, s), fo[T & 1][s], M[3], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      request(std::integral_constant<int, T + 2>{});
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    request(std::integral_constant<int, 0>{});
-    request(std::integral_constant<int, 1>{});
-    wino_static_for<0, NS>(step);
-  };
-  auto wtile = [&](int mt_) -> const char* { return reinterpret_cast<const char*>(p.wp) + (size_t)mt_ * nch * SLOTS * 4096; };
-  const int lpart = 2 * (uu / D) * D + (uu % D);
-  const unsigned ylb = (unsigned)p.y_ld * 4u, rlb = (unsigned)p.res_ld * 4u;
-  unsigned yo4[4], ro4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    yo4[i] = (unsigned)((4 * hi + i) * p.y_ld + lpart) * 4u;
-    ro4[i] = (unsigned)((4 * hi + i) * p.res_ld + lpart) * 4u;
-  }
-  long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0;     // diagnostics (stamped build): consumer wave 0 of each workgroup
-  if constexpr (DBG) cyc_all0 = (long long)__builtin_readcyclecounter();
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    int n0, bz, by;
-    locate(v0 + ti * stride, n0, bz, by);
-    const int mt = by * WM + wave;
-    const bool row_ok = mt < p.mtiles;
-    const int mtc = row_ok ? mt : p.mtiles - 1;
-    const char* const wt = wtile(mtc);
-    if (ti == 0) {
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) a[0][kg] = *reinterpret_cast<const float4*>(wt + kg * 1024 + wlane);
-    }
-    {
-      const float* bias = p.bias + mtc * 32 + 4 * hi;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { M[0][i] = 0.f; M[1][i] = bias[(i & 3) + 8 * (i >> 2)]; M[2][i] = 0.f; M[3][i] = 0.f; }
-    }
-    // slot 0 of the next tile (its row tile may differ when gy > 1)
-    const char* wnext_tile = nullptr;
-    if (ti + 1 < my_tiles) {
-      int n0n, bzn, byn;
-      locate(v0 + (ti + 1) * stride, n0n, bzn, byn);
-      const int mtn = byn * WM + wave;
-      wnext_tile = wtile(mtn < p.mtiles ? mtn : p.mtiles - 1);
-    }
-    auto stage = [&](int ch, auto par) {
-      const int s_ = ti * nch + ch;
-      long long c0 = 0, c1 = 0;
-      if constexpr (DBG) c0 = (long long)__builtin_readcyclecounter();
-      __syncthreads();                                     // B_s: plane set s & 1 is complete, set (s - 1) & 1 may be overwritten
-      if constexpr (DBG) c1 = (long long)__builtin_readcyclecounter();
-      const unsigned off = (unsigned)((s_ & 1) * PLF) * 4u;
-      const char* wa = wt + (size_t)ch * SLOTS * 4096;
-      const char* wnext = ch + 1 < nch ? wa + (size_t)SLOTS * 4096 : wnext_tile;
-      mfma_chunk(baddr0 + off, baddrE0 + off, wa, wnext, par);
-      if constexpr (DBG) { cyc_bar += c1 - c0; cyc_mf += (long long)__builtin_readcyclecounter() - c1; }
-    };
-    if constexpr ((SLOTS & 1) == 0) {
-      for (int ch = 0; ch < nch; ++ch) stage(ch, std::integral_constant<int, 0>{});
-    } else {                                               // odd slot count: the starting register set alternates; nch is even (host)
-      for (int ch = 0; ch < nch; ch += 2) {
-        stage(ch, std::integral_constant<int, 0>{});
-        stage(ch + 1, std::integral_constant<int, 1>{});
-      }
-    }
-    // ---- epilogue
-    long long ce0 = 0;
-    if constexpr (DBG) ce0 = (long long)__builtin_readcyclecounter();
-    const int ne = n0 + lpart;
-    if (row_ok && uu < PU && ne < L) {
-      const bool odd_ok = ne + D < L;
-      unsigned yq4[4], rq4[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { yq4[i] = yo4[i]; rq4[i] = ro4[i]; asm volatile("" : "+v"(yq4[i]), "+v"(rq4[i])); }
-      char* yb4[4];
-      const char* rb4[4];
-      {
-        char* const ybase = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld + n0);
-        const char* const rbase = reinterpret_cast<const char*>(p.res + (long long)bz * p.res_bs + (long long)(mt * 32) * p.res_ld + n0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { yb4[i] = ybase + (size_t)(8 * i) * ylb; rb4[i] = rbase + (size_t)(8 * i) * rlb; }
-      }
-      auto finish = [&](auto pair_c, auto half_c) {
-        constexpr bool PAIR = decltype(pair_c)::value;
-        constexpr int R0 = 8 * decltype(half_c)::value;
-        auto ld2 = [&](const char* q) -> float2 {
-          if constexpr (D == 1 && PAIR) return *reinterpret_cast<const float2*>(q);
-          else if constexpr (PAIR) return make_float2(*reinterpret_cast<const float*>(q), *reinterpret_cast<const float*>(q + 4 * D));
-          else return make_float2(*reinterpret_cast<const float*>(q), 0.f);
-        };
-        float2 vo[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const float t1 = M[1][R0 + r] + M[2][R0 + r], t2 = M[1][R0 + r] - M[2][R0 + r];
-          vo[r] = make_float2(M[0][R0 + r] + t1, M[3][R0 + r] + t2);
-        }
-        if (p.flags & F_RES) {
-          float2 rv[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) rv[r] = ld2(rb4[(R0 + r) >> 2] + rq4[r & 3]);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; }
-        }
-        if (p.flags & F_ACC) {
-          float2 yv[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) yv[r] = ld2(yb4[(R0 + r) >> 2] + yq4[r & 3]);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) { vo[r].x = yv[r].x + vo[r].x; vo[r].y = yv[r].y + vo[r].y; }
-        }
-        if (p.flags & F_DIV) {
-          const float dv = p.div, rc = 1.0f / dv;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float qx = vo[r].x * rc, qy = vo[r].y * rc;
-            vo[r].x = __builtin_fmaf(__builtin_fmaf(-qx, dv, vo[r].x), rc, qx);
-            vo[r].y = __builtin_fmaf(__builtin_fmaf(-qy, dv, vo[r].y), rc, qy);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          char* q = yb4[(R0 + r) >> 2] + yq4[r & 3];
-          if constexpr (D == 1 && PAIR) *reinterpret_cast<float2*>(q) = vo[r];
-          else {
-            *reinterpret_cast<float*>(q) = vo[r].x;
-            if constexpr (PAIR) *reinterpret_cast<float*>(q + 4 * D) = vo[r].y;
-          }
-        }
-      };
-      if (odd_ok) { finish(std::true_type{}, std::integral_constant<int, 0>{}); finish(std::true_type{}, std::integral_constant<int, 1>{}); }
-      else { finish(std::false_type{}, std::integral_constant<int, 0>{}); finish(std::false_type{}, std::integral_constant<int, 1>{}); }
-    }
-    if constexpr (DBG) cyc_epi += (long long)__builtin_readcyclecounter() - ce0;
-  }
-  if constexpr (DBG) if (tid == 0) {      // [workgroup][16]: 0 tiles, 1 total cycles, 2 barrier waits, 3 MFMA streams, 4 epilogues, 5 marker, 6 HW_ID, 7 XCC_ID
-    long long* d = p.dbg + 16 * (long long)(p.dbg_base + v0);
-    d[0] = my_tiles; d[1] = (long long)__builtin_readcyclecounter() - cyc_all0; d[2] = cyc_bar; d[3] = cyc_mf; d[4] = cyc_epi; d[5] = 2;
-    d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-    d[7] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-  }
-}
-
-template <int K, int D, bool DBG>
-__global__ void __launch_bounds__(512, 4) conv_wino_ws_kernel(const WinoArgs p, const int total) {
-  wino_ws_problem<K, D, DBG>(p, blockIdx.x, total, 0, gridDim.x);
-}
-template <int K, int D>
-__device__ __forceinline__ void wino_ws_member(const WinoArgs& p, const int first, const int vend, const int b, const int G_) {
-  if (vend <= first) return;
-  int v0 = b - first % G_;
-  if (v0 < 0) v0 += G_;
-  wino_ws_problem<K, D>(p, v0 + first, vend, first, G_);
-}
-template <int D>
-__global__ void __launch_bounds__(512, 4) conv_wino_ws_group_kernel(const WinoGroup g) {
-  const int b = blockIdx.x, G_ = gridDim.x;
-  wino_ws_member<11, D>(g.a[0], 0, g.end[0], b, G_);
-  __syncthreads();
-  wino_ws_member<7, D>(g.a[1], g.end[0], g.end[1], b, G_);
-  __syncthreads();
-  wino_ws_member<3, D>(g.a[2], g.end[1], g.end[2], b, G_);
-}
-
 // ------------------------------------------------------------------ weight transform + packing
 // wp[m-tile][chunk][slot][k-group][lane][4]: lane l of k-step 4*kg + s holds the slot's weight for
 // row 32*mt + (l & 31), channel 32*chunk + 2*(4*kg + s) + (l >> 5).
@@ -954,9 +542,7 @@ int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, bool f44, const float* w_or_v, const float* scale, hipStream_t st);
 int wino4_launch(const WinoArgs& w, int K, int D, int NC, bool f44, long long total, hipStream_t st);
 int wino4_launch_group(const WinoGroup& g, int D, int NC, int in_perm, int out_perm, bool f44, long long total, hipStream_t st);
-int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, bool f44, long long total, hipStream_t st);
 int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, bool f44, long long total, hipStream_t st);      // conv_wino4_acc.hip
-bool wino4_acc3_enabled();
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
   static const bool on = !(getenv("SVOC_WINO") && atoi(getenv("SVOC_WINO")) == 0);
@@ -1018,8 +604,6 @@ int pack_wino_named(PackedWino& pw, int Cin, int Cout, int K, const TensorTable&
 
 // ------------------------------------------------------------------ launches
 static int wino_wm(const PackedWino& pw) {
-  static const int force = getenv("SVOC_WINO_WM") ? atoi(getenv("SVOC_WINO_WM")) : 0;
-  if (force == 2 || force == 4) return force;
   return pw.mtiles >= 4 && pw.mtiles % 4 == 0 ? 4 : 2;
 }
 static int wino_tile_w(int D, int WM) { return 2 * (((32 * (4 / WM)) / D) * D); }
@@ -1072,38 +656,6 @@ static int wino_launch_group(const WinoGroup& g, long long total, size_t lds, hi
   return SVOC_OK;
 }
 
-// wave-specialised kernels: 4 x 1 tiles, dilation 1 / 3 (two plane sets must fit twice per CU), even chunk counts
-static bool wino_ws_on() {
-  static const bool on = !(getenv("SVOC_WINO_WS") && atoi(getenv("SVOC_WINO_WS")) == 0);
-  return on;
-}
-template <int K, int D>
-static size_t wino_ws_lds() { return (size_t)(WinoGeo<K, D, 4>::RAW_FLOATS + 2 * WinoGeo<K, D, 4>::PL_FLOATS) * 4; }
-template <int K, int D>
-static int wino_ws_launch_one(const WinoArgs& w, long long total, hipStream_t st) {
-  const size_t lds = wino_ws_lds<K, D>();
-  const unsigned grid = (unsigned)std::min<long long>(total, 2LL * device_cu_count());
-  if (w.dbg) {                                             // stamped build (tools/wino_ws_timeline.py)
-    auto kern = conv_wino_ws_kernel<K, D, true>;
-    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
-  } else {
-    auto kern = conv_wino_ws_kernel<K, D, false>;
-    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w, (int)total);
-  }
-  return SVOC_OK;
-}
-template <int D>
-static int wino_ws_launch_group(const WinoGroup& g, long long total, hipStream_t st) {
-  auto kern = conv_wino_ws_group_kernel<D>;
-  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  const size_t lds = std::max(wino_ws_lds<11, D>(), std::max(wino_ws_lds<7, D>(), wino_ws_lds<3, D>()));
-  const unsigned grid = (unsigned)std::min<long long>(total, 2LL * device_cu_count());
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
-  return SVOC_OK;
-}
-
 // share of the direct form's multiply-adds that the F(2,3) grouping issues: two products per output and three-tap group plus
 // one per left-over tap (k=3: 2/3, k=7: 5/7, k=11: 8/11); tile padding is not counted
 static double wino_exec_ratio(int K) { const int G = (K + 1) / 4; return (2.0 * G + (G - 1)) / (double)K; }
@@ -1123,11 +675,13 @@ static bool wino4_args(const PackedWino& pw, const ConvArgs& a, int dil, const W
   // window-major rows: written by a dilated convolution with a plain epilogue, read by an undilated one; the row must hold whole q blocks
   if (a.wperm_out && (dil == 1 || a.wperm_out != dil || (o.flags & (F_RES | F_ACC | F_DIV)) || o.y_ld < 4 * dil * ((a.Ncols + 4 * dil - 1) / (4 * dil)))) return false;
   if (a.wperm_in && (dil != 1 || !(a.wperm_in == 3 || a.wperm_in == 5) || a.x_ld < 4 * a.wperm_in * ((a.Ncols + 4 * a.wperm_in - 1) / (4 * a.wperm_in)))) return false;
+  // both sides of the window-major hand-over move whole float4 groups per lane (conv_wino4_kernels.h: the dilated epilogue's 16-byte store, the
+  // undilated producers' 16-byte q-block loads): base, row stride and batch stride must keep them aligned
+  if (a.wperm_out && ((reinterpret_cast<uintptr_t>(o.y) & 15) || (o.y_ld & 3) || (o.y_bs & 3))) return false;
+  if (a.wperm_in && ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.x_ld & 3) || (a.x_bs & 3))) return false;
   w4 = w;
   w4.out_perm = a.wperm_out;
   w4.wp = pw.wp4.f();
-  static const bool prio = !(getenv("SVOC_W4_PRIO") && atoi(getenv("SVOC_W4_PRIO")) == 0);      // producers at s_setprio 3 (conv_wino4.hip)
-  if (prio) w4.flags |= 0x100u;
   w4.ntn = wino4_ntn(a.Ncols, dil, wino4_nc(pw));
   w4.gy = pw.mtiles / wino4_nc(pw);
   return true;
@@ -1162,15 +716,6 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
     SVOC_HIP(hipGetLastError());
     return SVOC_OK;
   }
-  if (wino_ws_on() && WM == 4 && dil <= 3 && (pw.nchunks & 1) == 0) {
-#define SVOC_WS(KK, DD) if (pw.K == KK && dil == DD) rc = wino_ws_launch_one<KK, DD>(w, total, st);
-    SVOC_WS(3, 1) SVOC_WS(7, 1) SVOC_WS(11, 1) SVOC_WS(3, 3) SVOC_WS(7, 3) SVOC_WS(11, 3)
-#undef SVOC_WS
-    prof_end(st, prof_idx);
-    if (rc != SVOC_OK) return rc;
-    SVOC_HIP(hipGetLastError());
-    return SVOC_OK;
-  }
 #define SVOC_W(KK, DD) if (pw.K == KK && dil == DD) rc = WM == 4 ? wino_launch_one<KK, DD, 4>(w, total, st) : wino_launch_one<KK, DD, 2>(w, total, st);
   SVOC_W(3, 1) SVOC_W(7, 1) SVOC_W(11, 1) SVOC_W(3, 3) SVOC_W(7, 3) SVOC_W(11, 3) SVOC_W(3, 5) SVOC_W(7, 5) SVOC_W(11, 5)
 #undef SVOC_W
@@ -1184,8 +729,7 @@ int launch_conv_wino(const PackedWino& pw, const ConvArgs& a, int B, int dil, hi
 // + accumulate; + accumulate and divide) into one output: ONE launch of conv_wino4_accum_kernel.  1 = not eligible (the caller
 // runs them one by one).
 int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, int B, hipStream_t st, bool query) {
-  static const bool on = !(getenv("SVOC_W4_ACCUM") && atoi(getenv("SVOC_W4_ACCUM")) == 0);
-  if (!on || B <= 0 || !pws[0] || !pws[1] || !pws[2] || pws[0]->K != 3 || pws[1]->K != 7 || pws[2]->K != 11) return 1;
+  if (B <= 0 || !pws[0] || !pws[1] || !pws[2] || pws[0]->K != 3 || pws[1]->K != 7 || pws[2]->K != 11) return 1;
   WinoGroup g4{};
   double flops = 0, exec4 = 0;
   long long total = 0;
@@ -1206,6 +750,10 @@ int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, in
   if (total * 3 / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
   const int in_perm = as[0].wperm_in;
   if (as[1].wperm_in != in_perm || as[2].wperm_in != in_perm) return 1;
+  // one set of accumulators for the three members (conv_wino4_acc.hip): every member a plain residual convolution, accumulated in chain order
+  // (round 3's three read-modify-write members in one launch were removed in round 5: otherwise the caller runs them one by one)
+  if (!((g4.a[0].flags & (F_RES | F_ACC | F_DIV)) == F_RES && (!f44 || pws[0]->wp44.p) &&
+        (g4.a[1].flags & (F_RES | F_ACC)) == (F_RES | F_ACC) && (g4.a[2].flags & (F_RES | F_ACC)) == (F_RES | F_ACC))) return 1;
   if (query) return 0;
   int prof_idx = -1;
   if (prof_enabled()) {
@@ -1213,14 +761,11 @@ int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, in
     snprintf(d, sizeof(d), "wino4A Ci%-4d Co%-4d k3+7+11 accumulate N%-7d B%-3d%s", pws[0]->Cin, pws[0]->Cout, as[0].Ncols, B, f44 ? " F(4,4)" : "");
     prof_idx = prof_begin(st, d, flops);
   }
-  // one set of accumulators for the three members (conv_wino4_acc.hip) when every member is a plain residual convolution
-  const bool merged = wino4_acc3_enabled() && (g4.a[0].flags & (F_RES | F_ACC | F_DIV)) == F_RES && (!f44 || pws[0]->wp44.p) &&
-                      (g4.a[1].flags & (F_RES | F_ACC)) == (F_RES | F_ACC) && (g4.a[2].flags & (F_RES | F_ACC)) == (F_RES | F_ACC);
-  if (merged && f44) g4.a[0].wp = pws[0]->wp44.f();         // one set of accumulators: the k = 3 member in F(4,4) form as well
+  if (f44) g4.a[0].wp = pws[0]->wp44.f();                   // one set of accumulators: the k = 3 member in F(4,4) form as well
   for (int i = 0; i < 3; ++i)
-    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K, i == 0 ? (merged && f44) : f44);
+    exec4 += pws[i]->flops_per_col * (double)B * (double)as[i].Ncols * wino4_exec_ratio(pws[i]->K, f44);
   stats_add_conv(flops, 3, exec4);
-  const int rc = merged ? wino4_launch_acc3(g4.a, wino4_nc(*pws[0]), in_perm, f44, total, st) : wino4_launch_accum(g4, wino4_nc(*pws[0]), in_perm, f44, total, st);
+  const int rc = wino4_launch_acc3(g4.a, wino4_nc(*pws[0]), in_perm, f44, total, st);
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;
   SVOC_HIP(hipGetLastError());
@@ -1273,8 +818,6 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   }
   int rc = SVOC_OK;
   if (f4) rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), in_perm, out_perm, f44, total4, st);
-  else if (wino_ws_on() && WM == 4 && dil <= 3 && n == 3 && pws[0]->K == 11 && pws[1]->K == 7 && pws[2]->K == 3 && (pws[1]->nchunks & 1) == 0)
-    rc = dil == 1 ? wino_ws_launch_group<1>(g, total, st) : wino_ws_launch_group<3>(g, total, st);
   else if (WM == 4) rc = dil == 1 ? wino_launch_group<1, 4>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 4>(g, total, lds, st) : wino_launch_group<5, 4>(g, total, lds, st));
   else rc = dil == 1 ? wino_launch_group<1, 2>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 2>(g, total, lds, st) : wino_launch_group<5, 2>(g, total, lds, st));
   prof_end(st, prof_idx);

@@ -98,11 +98,9 @@ unsigned wino4_grid(long long total) { return (unsigned)std::min<long long>(tota
 // the instantiations, one translation unit per row-tile layout and form (conv_wino4_launch.h)
 template <int NRT, bool F44> int wino4_launch_nrt(const WinoArgs& w, int K, int D, long long total, hipStream_t st);
 template <int NRT, bool F44> int wino4_launch_group_nrt(const WinoGroup& g, int D, int in_perm, int out_perm, long long total, hipStream_t st);
-template <int NRT, bool F44> int wino4_launch_accum_nrt(const WinoGroup& g, int in_perm, long long total, hipStream_t st);
 #define SVOC_W4_EXTERN(NRT, F44)                                                                                          \
   extern template int wino4_launch_nrt<NRT, F44>(const WinoArgs&, int, int, long long, hipStream_t);                      \
-  extern template int wino4_launch_group_nrt<NRT, F44>(const WinoGroup&, int, int, int, long long, hipStream_t);          \
-  extern template int wino4_launch_accum_nrt<NRT, F44>(const WinoGroup&, int, long long, hipStream_t);
+  extern template int wino4_launch_group_nrt<NRT, F44>(const WinoGroup&, int, int, int, long long, hipStream_t);
 SVOC_W4_EXTERN(4, false) SVOC_W4_EXTERN(2, false) SVOC_W4_EXTERN(1, false) SVOC_W4_EXTERN(4, true) SVOC_W4_EXTERN(2, true) SVOC_W4_EXTERN(1, true)
 #undef SVOC_W4_EXTERN
 #define SVOC_W4_BY_LAYOUT(FN, ...)                                                                                        \
@@ -113,11 +111,6 @@ SVOC_W4_EXTERN(4, false) SVOC_W4_EXTERN(2, false) SVOC_W4_EXTERN(1, false) SVOC_
 int wino4_launch(const WinoArgs& w, int K, int D, int NRT, bool f44, long long total, hipStream_t st) {
   if (f44 && K < 7) return 1;
   return SVOC_W4_BY_LAYOUT(wino4_launch_nrt, w, K, D, total, st);
-}
-// members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each); in_perm: 0, or the dilation (3 / 5) of the
-// convolutions that wrote the members' inputs window-major; f44: the k = 7 / 11 members' images are in F(4,4) form
-int wino4_launch_accum(const WinoGroup& g, int NRT, int in_perm, bool f44, long long total, hipStream_t st) {
-  return SVOC_W4_BY_LAYOUT(wino4_launch_accum_nrt, g, in_perm, total, st);
 }
 // in_perm (D = 1): 0, or the dilation of the convolutions that wrote the members' inputs window-major; out_perm (D > 1): nonzero =
 // the members write window-major

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
   if (wave >= 4) {
     // ================================================================= producers
     const int pw_ = wave - 4;
-    if (p3.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);
     float4 v3[Acc3Prod<G3>::NV], v7[Acc3Prod<G7>::NV], v11[Acc3Prod<G11>::NV];
     int w0, bz, by;
     locate(v0, w0, bz, by);
@@ -359,9 +359,4 @@ int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, bool f44, long lo
   return SVOC_W4M(0);
 #undef SVOC_W4M
 }
-bool wino4_acc3_enabled() {
-  static const bool on = !(getenv("SVOC_W4_ACC3") && atoi(getenv("SVOC_W4_ACC3")) == 0);      // SVOC_W4_ACC3=0: three read-modify-write members
-  return on;
-}
-
 }  // namespace svoc

@@ -90,8 +90,8 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     // (tools/mfma_valu_probe.hip), and the older consumer wave wins the arbitration by age, so at equal priority the
     // producer only advances in the gaps of the MFMA stream and the consumers then wait for it at the stage barrier.
     // Measured (profiles/r03_i_f43_producer_priority.txt): barrier waits of the consumers halve, k = 11 tile 120.7k -> 118.6k cycles,
-    // 16 x 512 step 33.2 -> 33.0 ms.  SVOC_W4_PRIO=0 switches it off.
-    if (p.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
+    // 16 x 512 step 33.2 -> 33.0 ms.
+    __builtin_amdgcn_s_setprio(3);
     constexpr int R4 = RAW / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;      // producer p owns channel rows RPW p .. RPW p + RPW - 1
     constexpr int IPR = NE, NIW = RPW * IPR, TPW = (NIW + 63) / 64;        // transform items: one window each
     const long long ldb = (long long)p.x_ld * 4;
@@ -607,22 +607,6 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_group_kernel(const WinoGrou
   wino4_member<7, D, NRT, PERM, F44>(g.a[1], g.end[0], g.end[1], b, G_);
   __syncthreads();
   wino4_member<3, D, NRT, PERM>(g.a[2], g.end[1], g.end[2], b, G_);
-}
-
-// The last convolutions of the three MRF chains accumulate into ONE tensor in chain order, xs = rb_0 + rb_1 + rb_2, x = xs / 3
-// (reference models.py:149-155).  As three launches each pays its own tail and the k = 3 one runs alone; here every workgroup
-// walks the SAME tiles for the three members in chain order (k = 3, 7, 11: no rotation of the assignment), so the tile a wave
-// accumulates into was written by that very wave (same lane, same registers' worth of addresses) one member earlier: program
-// order makes the read-modify-write safe without any inter-workgroup synchronisation, and the summation order of the reference
-// is kept bit for bit.
-template <int NRT, int PERM = 0, bool F44 = false>
-__global__ void __launch_bounds__(512, 2) conv_wino4_accum_kernel(const WinoGroup g) {
-  const int b = blockIdx.x, G_ = gridDim.x, total = g.end[0];
-  wino4_problem<3, 1, NRT, false, PERM>(g.a[0], b, total, 0, G_);
-  __syncthreads();
-  wino4_problem<7, 1, NRT, false, PERM, F44>(g.a[1], b, total, 0, G_);
-  __syncthreads();
-  wino4_problem<11, 1, NRT, false, PERM, F44>(g.a[2], b, total, 0, G_);
 }
 
 }  // namespace svoc

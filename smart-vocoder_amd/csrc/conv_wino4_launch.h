@@ -46,23 +46,6 @@ static int wino4_launch_group_d(const WinoGroup& g, long long total, hipStream_t
   hipLaunchKernelGGL(kern, dim3(wino4_grid(total)), dim3(512), lds, st, g);
   return SVOC_OK;
 }
-template <int NRT, int PERM, bool F44>
-static int wino4_launch_accum_n(const WinoGroup& g, long long total, hipStream_t st) {
-  auto kern = conv_wino4_accum_kernel<NRT, PERM, F44>;
-  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  const size_t l11 = wino4_lds<11, 1, NRT, PERM, F44>(), l7 = wino4_lds<7, 1, NRT, PERM, F44>(), l3 = wino4_lds<3, 1, NRT, PERM>();
-  const size_t lds = std::max(l11, std::max(l7, l3));
-  hipLaunchKernelGGL(kern, dim3(wino4_grid(total)), dim3(512), lds, st, g);
-  return SVOC_OK;
-}
-// members in chain order, k = 3, 7, 11, dilation 1, one tile space (g.end[0] tiles each); in_perm: 0, or the dilation (3 / 5) of the
-// convolutions that wrote the members' inputs window-major
-template <int NRT, bool F44>
-int wino4_launch_accum_nrt(const WinoGroup& g, int in_perm, long long total, hipStream_t st) {
-  if (in_perm == 5) return wino4_launch_accum_n<NRT, 5, F44>(g, total, st);
-  if (in_perm == 3) return wino4_launch_accum_n<NRT, 3, F44>(g, total, st);
-  return wino4_launch_accum_n<NRT, 0, F44>(g, total, st);
-}
 // in_perm (D = 1): 0, or the dilation of the convolutions that wrote the members' inputs window-major; out_perm (D > 1): nonzero =
 // the members write window-major
 template <int NRT, bool F44>
@@ -73,7 +56,6 @@ int wino4_launch_group_nrt(const WinoGroup& g, int D, int in_perm, int out_perm,
 }
 #define SVOC_W4_INSTANTIATE(NRT, F44)                                                                                     \
   template int wino4_launch_nrt<NRT, F44>(const WinoArgs&, int, int, long long, hipStream_t);                             \
-  template int wino4_launch_group_nrt<NRT, F44>(const WinoGroup&, int, int, int, long long, hipStream_t);                 \
-  template int wino4_launch_accum_nrt<NRT, F44>(const WinoGroup&, int, long long, hipStream_t);
+  template int wino4_launch_group_nrt<NRT, F44>(const WinoGroup&, int, int, int, long long, hipStream_t);
 
 }  // namespace svoc

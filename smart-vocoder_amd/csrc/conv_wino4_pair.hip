@@ -100,7 +100,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
   if (wave >= 4) {
     // ================================================================= producers
     const int pw_ = wave - 4;
-    if (g.flags & 0x100u) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);
     constexpr int RPW = KS / 4, RAW1 = G1::RAW, R4 = RAW1 / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
     constexpr int NE1 = G1::NE, NIW1 = RPW * NE1, TPW1 = (NIW1 + 63) / 64, PQ1 = G1::PQ;
     constexpr int NIW2 = RPW * NE2, TPW2 = (NIW2 + 63) / 64, PQ2 = G2::PQ;
@@ -347,8 +347,7 @@ static int pair_launch_d(PairGroup& g, hipStream_t st) {
 }
 
 bool wino4_pair_enabled() {
-  static const bool on = wino4_c32_enabled() && !(getenv("SVOC_W4_PAIR") && atoi(getenv("SVOC_W4_PAIR")) == 0);      // SVOC_W4_PAIR=0: conv by conv
-  return on;
+  return wino4_c32_enabled();
 }
 // tiles a launch would have (the engine's size gate)
 bool wino44_enabled();
@@ -366,11 +365,10 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
   if (!wino4_pair_enabled() || B <= 0 || (L & 3) || (ld & 3) || (bs & 3) || !(D1 == 1 || D1 == 3 || D1 == 5)) return 1;
   if (64LL * ld * 4 >= (1LL << 31)) return 1;               // the producers' staging loads: 32-bit offsets within one batch element
   static const int ks[3] = {11, 7, 3};
-  static const bool c64 = !(getenv("SVOC_W4_PAIR64") && atoi(getenv("SVOC_W4_PAIR64")) == 0);      // SVOC_W4_PAIR64=0: the C = 64 stage conv by conv
   const int C = pw1[0] ? pw1[0]->Cin : 0;
   // C = 64 (64-window tiles: the halo costs more lanes): measured -97 us for the d = 1 pair, -8 us for the d = 3 pair (c2 keeps 57 of 64
   // windows there) - only the first is taken
-  if (!(C == 32 || (C == 64 && c64 && D1 == 1))) return 1;
+  if (!(C == 32 || (C == 64 && D1 == 1))) return 1;
   PairGroup g{};
   double flops = 0, exec = 0;
   for (int i = 0; i < 3; ++i) {
@@ -386,9 +384,10 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
     flops += f;
     exec += f * (pw1[i]->f44 ? 1.75 * G : 1.5 * G + (G - 1)) / (double)ks[i];
   }
+  // tile totals are validated before the launch is counted or profiled: "1 = not eligible" must leave no trace
+  if (wino4_pair_tiles(C, L, B, D1) > 0x7fffffffLL) return 1;           // an upper bound of pair_launch_d's total (the k = 11 member has the narrowest tiles)
   g.L = L; g.B = B; g.xcd = xcd_mapping_enabled(); g.slope = slope;
-  static const bool prio = !(getenv("SVOC_W4_PRIO") && atoi(getenv("SVOC_W4_PRIO")) == 0);
-  g.flags = prio ? 0x100u : 0u;
+  g.flags = 0u;
   stats_add_conv(flops, 6, exec);
   int prof_idx = -1;
   if (prof_enabled()) {

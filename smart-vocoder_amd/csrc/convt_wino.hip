@@ -604,17 +604,15 @@ int launch_convt_wino(const PackedCtWino& pw, const float* x, long long x_bs, in
   a.x = x; a.x_bs = x_bs; a.x_ld = x_ld; a.Lin = Lin; a.pre_slope = pre_slope;
   a.wp = pw.wp.f(); a.bias = pw.bias.f(); a.nchunks = pw.nchunks; a.mtiles = pw.mtiles;
   a.y = y; a.y_bs = y_bs; a.y_ld = y_ld; a.Lout = Lin * pw.S;
-  static const bool tail_on = !(getenv("SVOC_CT_TAIL") && atoi(getenv("SVOC_CT_TAIL")) == 0);
-  const bool tail = tail_on && (Lin & 3) == 0 && pw.Cin <= 1024;     // the column q = Lin by convt_tail_kernel, the windows cover 0 .. Lin - 1
+  const bool tail = (Lin & 3) == 0 && pw.Cin <= 1024;     // the column q = Lin by convt_tail_kernel, the windows cover 0 .. Lin - 1
   const int nw = (Lin + (tail ? 0 : 1) + 3) / 4;          // windows over the columns q = 0 .. Lin
   // 256-row blocks (eight consumers) where they leave two workgroups per CU, else 128-row blocks, or 64 rows x twice the windows
-  static const bool nrt8_on = !(getenv("SVOC_CT_ROWS256") && atoi(getenv("SVOC_CT_ROWS256")) == 0);
   // fewest workgroups the launch is worth it for: half the CUs (measured per launch, direct -> F(4,2) in us: 256 tiles 156 -> 74 and
   // 91 -> 58, 128 tiles 78 -> 71, 100 tiles 42 -> 51 and 28 -> 35, 32 tiles 58 -> 77); SVOC_CT_MIN_TILES overrides
   static const long long min_cfg = getenv("SVOC_CT_MIN_TILES") ? atoll(getenv("SVOC_CT_MIN_TILES")) : -1;
   const long long min_tiles = min_cfg >= 0 ? min_cfg : device_cu_count() / 2;
   int nrt = pw.mtiles % 4 == 0 ? 4 : 2;
-  if (nrt8_on && pw.mtiles % 8 == 0 && (long long)((nw + 31) / 32) * (pw.mtiles / 8) * variant_batch(B) >= 2LL * device_cu_count()) nrt = 8;
+  if (pw.mtiles % 8 == 0 && (long long)((nw + 31) / 32) * (pw.mtiles / 8) * variant_batch(B) >= 2LL * device_cu_count()) nrt = 8;
   const int nwt = nrt == 2 ? 64 : 32;
   a.ntn = (nw + nwt - 1) / nwt;
   a.gy = pw.mtiles / nrt; a.B = B;

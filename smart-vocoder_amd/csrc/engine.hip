@@ -417,7 +417,7 @@ struct Generator {
 
   int create(const svoc_generator_config& c, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
     cfg = c;
-    use_streams = !(getenv("SVOC_STREAMS") && atoi(getenv("SVOC_STREAMS")) == 0) && c.n_kernels > 1;
+    use_streams = c.n_kernels > 1;                          // one ResBlock chain per stage: everything on the caller's stream
     if (use_streams) {
       chain_st.assign(c.n_kernels, nullptr);
       chain_done.assign(c.n_kernels, nullptr);
@@ -484,9 +484,7 @@ struct Generator {
     static const bool fuse = !(getenv("SVOC_FUSE") && atoi(getenv("SVOC_FUSE")) == 0);
     const int nk = cfg.n_kernels;
     if (!on || nk < 2 || nk > 3) return false;
-    // C = 32: the fused ResBlock kernel (conv-by-conv execution is HBM-bound there).  C = 64: measured faster conv by
-    // conv in Winograd form (grouped launches, 8.4 ms per step) than fused in direct form (9.9 ms); SVOC_FUSE64=1 = fused
-    static const bool fuse64 = getenv("SVOC_FUSE64") && atoi(getenv("SVOC_FUSE64")) != 0;
+    // C = 64: measured faster conv by conv in Winograd form (grouped launches) than fused in direct form (8.4 against 9.9 ms per step, round 2)
     // C = 32 (round 4): conv by conv in F(4,3) form with one row tile per workgroup (SVOC_W4_C32=0: the fused kernel)
     bool c32_wino = C == 32 && nk == 3;
     for (int j = 0; j < nk && c32_wino; ++j) {
@@ -494,7 +492,7 @@ struct Generator {
       for (int it = 0; it < rb.ND && c32_wino; ++it)
         c32_wino = rb.kind == 1 && rb.w1[it] && rb.w1[it]->wp4.p && rb.w2[it] && rb.w2[it]->wp4.p;
     }
-    if (fuse && ((C == 32 && !c32_wino) || (C == 64 && fuse64))) return false;
+    if (fuse && C == 32 && !c32_wino) return false;        // C = 32 without the F(4,3) images: the fused direct-form ResBlock kernel on the stream plan
     const ResBlock& r0 = *rbs[stage * nk];
     for (int j = 0; j < nk; ++j) {
       const ResBlock& rb = *rbs[stage * nk + j];
@@ -525,6 +523,8 @@ struct Generator {
       auto launch3 = [&](bool wino, int dil) -> int {
         int r = 1;
         if (wino) r = launch_conv_wino_group(pws, as, nk, B, dil, st);
+        // only the grouped F(4,3) kernels understand window-major rows: the query above promised them
+        if (r == 1 && (as[0].wperm_in || as[0].wperm_out)) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "MRF: the grouped launch refused window-major rows it had accepted");
         if (r == 1) r = launch_conv_group(pcs, as, nk, B, st);
         if (r < 0) return r;
         if (r == 1) for (int q = 0; q < nk; ++q) SVOC_TRY(launch_conv(*pcs[q], as[q], B, st));
@@ -599,11 +599,10 @@ struct Generator {
         }
       }
       // A dilated c1 writes its rows window-major (one 16-byte store per lane and row instead of four scattered dwords) and the c2
-      // behind it reads through the same map - when both launches are the grouped F(4,3) kernels (SVOC_W4_PERM=0: natural order)
+      // behind it reads through the same map - when both launches are the grouped F(4,3) kernels
       {
-        static const bool perm_on = !(getenv("SVOC_W4_PERM") && atoi(getenv("SVOC_W4_PERM")) == 0);
         const int dil = pcs[0]->dil;
-        if (perm_on && dil > 1 && all_w && all_w2 && (!last || nk == 3)) {
+        if (dil > 1 && all_w && all_w2 && (!last || nk == 3)) {
           ConvArgs t1[3], t2[3];
           for (int q = 0; q < nk; ++q) { t1[q] = as[q]; t1[q].wperm_out = dil; t2[q] = (last && nk == 3) ? aas[q] : as2[q]; t2[q].wperm_in = dil; }
           const bool ok = launch_conv_wino_group(pws, t1, nk, B, dil, st, true) == 0 &&

@@ -14,10 +14,7 @@
 namespace svoc {
 
 // diagnostics: kernels that support phase stamps write them here when set (svoc_debug_set_stamp_buffer)
-int xcd_mapping_enabled() {
-  static const int on = !(getenv("SVOC_XCD") && atoi(getenv("SVOC_XCD")) == 0);
-  return on;
-}
+int xcd_mapping_enabled() { return 1; }                     // XCD-aware tile order (xcd_linear); the natural order was an A/B switch until round 5
 
 static std::atomic<int> g_variant_batch{getenv("SVOC_VARIANT_BATCH") ? atoi(getenv("SVOC_VARIANT_BATCH")) : 0};
 int variant_batch(int B) { const int v = g_variant_batch.load(std::memory_order_relaxed); return v > 0 ? v : B; }

@@ -220,9 +220,8 @@ __global__ void __launch_bounds__(256) dds_ln_v2_kernel(const float* __restrict_
 }
 // eligibility of the vectorised kernels: 16-byte aligned rows with room for whole float4 groups, at most 256 channels
 static bool ln_v2_ok(const void* src, long long s_bs, int s_ld, const void* dst, long long d_bs, int d_ld, int C, int T) {
-  static const bool on = !(getenv("SVOC_LN_V2") && atoi(getenv("SVOC_LN_V2")) == 0);
   const int T4 = (T + 3) & ~3;
-  return on && C <= 256 && s_ld >= T4 && d_ld >= T4 && (s_ld & 3) == 0 && (d_ld & 3) == 0 && (s_bs & 3) == 0 && (d_bs & 3) == 0 &&
+  return C <= 256 && s_ld >= T4 && d_ld >= T4 && (s_ld & 3) == 0 && (d_ld & 3) == 0 && (s_bs & 3) == 0 && (d_bs & 3) == 0 &&
          (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
 }
 

@@ -19,6 +19,8 @@ namespace svoc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ __forceinline__ float fz_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+
 struct FusedArgs {
   const float* x; long long x_bs; int x_ld; int L;
   const float* wp1; const float* bias1; int ksg1; int dil1; int pad1;
@@ -31,232 +33,14 @@ struct FusedArgs {
   long long* dbg;            // optional [nblocks][8] cycle stamps (svoc_debug_set_stamp_buffer)
 };
 
-__device__ __forceinline__ float fz_pick4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
-
-// acc[nr] += W[rows of m-tile mt][K] * B, B fragments read from an LDS tile `tile` ([channels][row_len]) at column
-// offset col0 + tap*dil; ACT applies leaky-relu to the fragments as they are read.
-template <int NR, bool ACT>
-__device__ __forceinline__ void fused_gemm(f32x16 (&acc)[NR], const float4* __restrict__ wp4, long long abase, int ksg_total,
-                                           const float* tile, int row_len, int col0, int ktaps, int dil, int nchunks,
-                                           int hi, float slope) {
-  // ping-pong fragment registers; the next group's requests are issued after the first k-step's MFMAs
-  float4 a0 = wp4[abase], a1;
-  int ksg = 0;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const float* bp = tile + (ch * KC + hi) * row_len + col0;
-    float b0[4][NR], b1[4][NR];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int nr = 0; nr < NR; ++nr) {
-        const float v = bp[(2 * s) * row_len + nr * 32];
-        b0[s][nr] = ACT ? fmaxf(v, v * slope) : v;            // lrelu for slope in (0,1)
-      }
-    const int ngroups = ktaps * (KC / 8);
-    int g = 0;
-    auto run_group = [&](float4& ac, float(&bc)[4][NR], float4& an, float(&bn)[4][NR], bool last_group) {
-#pragma unroll
-      for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x, bc[0][nr], acc[nr], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ++ksg;
-      an = wp4[abase + (long long)(ksg < ksg_total ? ksg : 0) * 64];
-      const float* bpn = (g == KC / 8 - 1) ? bp + dil - (KC - 8) * row_len : bp + 8 * row_len;
-      if (!last_group) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int nr = 0; nr < NR; ++nr) bn[s][nr] = bpn[(2 * s) * row_len + nr * 32];
-      }
-      bp = bpn;
-      g = (g + 1) & (KC / 8 - 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 1; s < 4; ++s) {
-        const float av = fz_pick4(ac, s);
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) acc[nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[s][nr], acc[nr], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (ACT && !last_group) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int nr = 0; nr < NR; ++nr) bn[s][nr] = fmaxf(bn[s][nr], bn[s][nr] * slope);
-      }
-    };
-    for (int gi = 0; gi < ngroups; gi += 2) {
-      run_group(a0, b0, a1, b1, false);
-      run_group(a1, b1, a0, b0, gi + 2 >= ngroups);
-    }
-  }
-}
-
-template <int WM, int WN, int NR>
-__global__ void __launch_bounds__(256, 2) resblock_fused_kernel(const FusedArgs p) {
-  constexpr int SU = 13;                                   // one batch of staging loads per thread
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const XT = lds;                                   // lrelu(x) tile  [C][xrow]
-  float* const YT = lds;                                   // lrelu(c1(.)) tile [C][yrow], ALIASES the x tile (see below)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int tl = xcd_linear(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z, p.xcd);
-  const int b = tl / (int)gridDim.x;
-  const int t0 = (tl - b * (int)gridDim.x) * p.n2;         // first output sample of this tile
-  const int h2 = p.pad2;
-  long long ts[6] = {0, 0, 0, 0, 0, 0};
-  if (p.dbg) ts[0] = __builtin_readcyclecounter();
-
-  // ---- stage the x tile: all C channels, columns [t0 + xoff0, +xrow); zero outside [0, L)
-  {
-    const int R4 = p.xrow >> 2;
-    const int total = p.C * R4;
-    const int xs_start = t0 + p.xoff0;
-    const float* xb = p.x + (long long)b * p.x_bs;
-    int wc = tid / R4, wg = tid - wc * R4;
-    const int dc = 256 / R4, dg = 256 - dc * R4;
-    for (int base = tid; base < total; base += 256 * SU) {
-      float4 v[SU];
-      const int wc_s = wc, wg_s = wg;
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int c = min(wc, p.C - 1);
-        int t = xs_start + 4 * wg;
-        t = (t >= 0 && t < p.L) ? t : 0;
-        v[u] = *reinterpret_cast<const float4*>(xb + (long long)c * p.x_ld + t);
-        wc += dc; wg += dg;
-        if (wg >= R4) { wg -= R4; ++wc; }
-      }
-      int wc2 = wc_s, wg2 = wg_s;
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        if (base + u * 256 < total) {
-          const int t = xs_start + 4 * wg2;
-          float4 q = v[u];
-          q.x = (t >= 0 && t < p.L) ? q.x : 0.f;
-          q.y = (t + 1 >= 0 && t + 1 < p.L) ? q.y : 0.f;
-          q.z = (t + 2 >= 0 && t + 2 < p.L) ? q.z : 0.f;
-          q.w = (t + 3 >= 0 && t + 3 < p.L) ? q.w : 0.f;
-          // the tile holds lrelu(x): c1 re-reads every element once per tap, activating at staging costs k times less
-          // vector ALU work beside the MFMAs; the residual recovers x from it (see below)
-          q.x = fmaxf(q.x, q.x * p.slope);
-          q.y = fmaxf(q.y, q.y * p.slope);
-          q.z = fmaxf(q.z, q.z * p.slope);
-          q.w = fmaxf(q.w, q.w * p.slope);
-          *reinterpret_cast<float4*>(XT + wc2 * p.xrow + 4 * wg2) = q;
-        }
-        wc2 += dc; wg2 += dg;
-        if (wg2 >= R4) { wg2 -= R4; ++wc2; }
-      }
-    }
-  }
-  const int mt = wm;                                       // this wave's 32-row tile (WM tiles cover C)
-  f32x16 acc[NR];
-  // ---- phase A: c1 on columns m in [0, NA) <-> global time t0 - h2 + m
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias1[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
-  __syncthreads();
-  if (p.dbg) ts[1] = __builtin_readcyclecounter();
-  {
-    const int col0 = wn * NR * 32 + l31 - h2 - p.pad1 - p.xoff0;
-    fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp1), (long long)mt * p.ksg1 * 64 + lane, p.ksg1, XT, p.xrow, col0,
-                         p.ktaps, p.dil1, p.nchunks, hi, p.slope);
-  }
-  // The x tile is now only needed for the residual: every wave pulls its own residual values into registers, then
-  // (after a barrier) the same LDS region is overwritten with lrelu(c1(.)) as c2's B operand.  Halving the LDS
-  // footprint doubles the number of resident workgroups.
-  if (p.dbg) ts[2] = __builtin_readcyclecounter();
-  const int ncol0 = wn * NR * 32;
-  const float inv_slope = 1.0f / p.slope;
-  float resv[NR][16];
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr) {
-    const int n = ncol0 + nr * 32 + l31;
-    const int cidx = min(n - p.xoff0, p.xrow - 1);
-    const float* rbase = XT + (mt * 32 + 4 * hi) * p.xrow + cidx;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // x from lrelu(x): negative values were scaled by the slope (0.1: 1/slope = 10 exactly in fp32; the round trip
-      // x*0.1*10 differs from x by at most one ulp, 6e-8 relative, on negative samples only)
-      const float v = rbase[((r & 3) + 8 * (r >> 2)) * p.xrow];
-      resv[nr][r] = fminf(v, v * inv_slope);      // inv_slope > 1: min picks v*inv_slope for v < 0, v otherwise
-    }
-  }
-  __syncthreads();
-  // lrelu, zero outside [0, L) (c2 zero-pads ITS input)
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr) {
-    const int m = wn * NR * 32 + nr * 32 + l31;
-    const int tA = t0 - h2 + m;
-    const bool ok = tA >= 0 && tA < p.L;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float v = acc[nr][r];
-      v = fmaxf(v, v * p.slope);
-      YT[row * p.yrow + m] = ok ? v : 0.f;
-    }
-  }
-  // ---- phase B: c2 on the interior columns n in [0, n2) <-> global time t0 + n
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nr][i] = p.bias2[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi];
-  __syncthreads();
-  if (p.dbg) ts[3] = __builtin_readcyclecounter();
-  if (ncol0 >= p.n2 || t0 + ncol0 >= p.L) return;
-  fused_gemm<NR, false>(acc, reinterpret_cast<const float4*>(p.wp2), (long long)mt * p.ksg2 * 64 + lane, p.ksg2, YT, p.yrow,
-                        ncol0 + l31, p.ktaps, 1, p.nchunks, hi, 1.0f);
-  if (p.dbg) ts[4] = __builtin_readcyclecounter();
-  // ---- epilogue: + residual (x recovered from the LDS tile above), sink flags, store
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr) {
-    const int n = ncol0 + nr * 32 + l31;
-    const int t = t0 + n;
-    if (n >= p.n2 || t >= p.L) continue;
-    float* ybase = p.y + (long long)b * p.y_bs + (long long)(mt * 32 + 4 * hi) * p.y_ld + t;
-    float yo[16];
-    if (p.flags & F_ACC) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) yo[r] = ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld];
-    }
-    float vo[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = acc[nr][r] + resv[nr][r];
-      if (p.flags & F_ACC) v = yo[r] + v;
-      vo[r] = v;
-    }
-    if (p.flags & F_DIV) {          // one uniform branch: see conv_mfma.hip (an in-loop `if` becomes 16 unconditional divisions)
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < 16; ++r) vo[r] = vo[r] / p.div;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ybase[(long long)((r & 3) + 8 * (r >> 2)) * p.y_ld] = vo[r];
-  }
-  if (p.dbg && threadIdx.x == 0) {
-    ts[5] = __builtin_readcyclecounter();
-    long long* d = p.dbg + 8 * (blockIdx.x + (long long)gridDim.x * blockIdx.z);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = ts[i];
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Generation 2: the same algorithm with every piece of geometry known at compile time (C, k, c1 dilation).
-// Round-1 PMC counters (profiles/r01_e_pmc_instruction_mix.txt) show the generic kernel issuing 2.5 (C=64) / 4.0 (C=32)
+// Every piece of geometry is known at compile time (C, k, c1 dilation); a generic run-time-geometry kernel (round 1) was removed in
+// round 5 - other shapes run as two convolutions.  Round-1 PMC counters (profiles/r01_e_pmc_instruction_mix.txt) showed that generic kernel issuing 2.5 (C=64) / 4.0 (C=32)
 // vector-ALU instructions per MFMA, and on gfx950 every vector instruction takes matrix-pipe time (fp32 MFMA runs at
 // the vector rate on the same lanes).  With compile-time row strides the LDS fragment reads, the residual pull and the
 // activation exchange use immediate offsets; the staging walks an exact slot count, interior tiles (all but two per
 // row) skip the zero-padding clamps and selects, the weight stream is addressed as a uniform base + 32-bit lane offset,
-// and the output rows as uniform row bases + one per-lane offset.  Summation order is unchanged: results are
-// bit-identical to the generic kernel above (tools/rb_bench.py checks it).
+// and the output rows as uniform row bases + one per-lane offset.
 template <int C, int K, int D, int NRT = 2>
 struct RbGeo {
   static constexpr int WM = C / 32;                       // waves along the rows (one 32-row tile each)
@@ -612,8 +396,6 @@ static bool launch_v2(const FusedArgs& a, const PackedConv& c1, const PackedConv
 
 // Eligibility + launch.  Returns 1 if the fused kernel does not apply (caller runs the two convolutions).
 bool resblock_fused_ct_supported(int C, int k, int dil) {
-  const char* ev = getenv("SVOC_FUSE_V");
-  if (ev && atoi(ev) == 1) return false;
   return (C == 32 || C == 64) && (k == 3 || k == 7 || k == 11) && (dil == 1 || dil == 3 || dil == 5);
 }
 
@@ -627,6 +409,9 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
   if ((x_ld & 3) || (x_bs & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return 1;
   if (flags & ~(unsigned)(F_ACC | F_DIV)) return 1;
   const int k = c1.ktaps;
+  // other kernel sizes / dilations run as two convolutions (a generic run-time-geometry copy of this kernel existed until round 5)
+  if (!resblock_fused_ct_supported(C, k, c1.dil)) return 1;
+  if ((long long)4 * 32 * y_ld + L >= (1LL << 30)) return 1;           // the kernel's 32-bit lane offsets
   const int NA = (C == 32) ? 256 : 128;
   FusedArgs a;
   a.x = x; a.x_bs = x_bs; a.x_ld = x_ld; a.L = L;
@@ -655,17 +440,9 @@ int launch_resblock_fused(const PackedConv& c1, const PackedConv& c2, const floa
     prof_idx = prof_begin(st, d, (c1.flops_per_col + c2.flops_per_col) * (double)B * (double)L);
   }
   int rc2 = SVOC_OK;
-  if (launch_v2(a, c1, c2, B, L, st, &rc2)) {
-    if (rc2 != SVOC_OK) { prof_end(st, prof_idx); return rc2; }       // launched by the compile-time-specialised kernel
-  } else if (C == 32) {
-    auto kern = resblock_fused_kernel<1, 4, 2>;
-    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
-  } else {
-    auto kern = resblock_fused_kernel<2, 2, 2>;
-    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
-  }
+  const bool launched = launch_v2(a, c1, c2, B, L, st, &rc2);         // resblock_fused_ct_supported() held above
+  if (!launched) rc2 = SVOC_ERR_UNSUPPORTED;
+  if (rc2 != SVOC_OK) { prof_end(st, prof_idx); return rc2; }
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;

@@ -921,14 +921,12 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
   a.arow = NA + 1;
   size_t lds = (size_t)H * std::max(a.xrow, a.arow) * sizeof(float);
   // short inputs: 2*npairs waves per workgroup, K split in two halves (wn_layer_fused_ks_kernel)
-  static const bool ksplit_on = !(getenv("SVOC_WN_KSPLIT") && atoi(getenv("SVOC_WN_KSPLIT")) == 0);
-  const bool ksplit = ksplit_on && NR == 1 && (a.nchunks % 2) == 0 && 2 * npairs * 64 <= 768;
+  const bool ksplit = NR == 1 && (a.nchunks % 2) == 0 && 2 * npairs * 64 <= 768;
   if (ksplit) lds += (size_t)2 * npairs * 16 * 64 * sizeof(float);
   if (lds > 160 * 1024) return 1;
   dim3 grid((T + NA - 1) / NA, 1, B);
   const double flops = (in_l.flops_per_col + rs_l.flops_per_col) * (double)B * (double)T;
-  static const bool ct_on = !(getenv("SVOC_WN_CT") && atoi(getenv("SVOC_WN_CT")) == 0);
-  const bool ct = ct_on && ksplit && H == 192 && in_l.ktaps == 5 && in_l.dil == 1 && a.xrow == 40 && a.arow == 33 && a.nchunks == 6 &&
+  const bool ct = ksplit && H == 192 && in_l.ktaps == 5 && in_l.dil == 1 && a.xrow == 40 && a.arow == 33 && a.nchunks == 6 &&
                   (long long)in_l.mtiles * in_l.ksg_total * 1024 < (1LL << 31);
   const bool f25 = ksplit && ct && wpf != nullptr && wn_f25_enabled() && rs_l.ksg_total == 24;
   // F(2,5): 6 products per two outputs instead of 10 for the in_layer

@@ -314,29 +314,45 @@ class SynthesizerTrn(_HipModule):
 
         As in the reference, speaker conditioning is off (g=None, models.py:332) and sid/length_scale/noise_scale_w
         are ignored.  `eps` (extension, keyword only in spirit) injects the N(0,1) draw the reference takes with
-        randn_like (models.py:336); by default it is drawn with torch.randn on the device.
+        randn_like (models.py:336); by default it is drawn exactly as there - ``torch.randn_like`` of the [B, 192, T] fp32
+        ``m_p`` on the device - so after ``torch.manual_seed(s)`` the call consumes the generator stream the reference's
+        call would (tests/test_gpu_parity.py::test_default_noise_is_the_reference_draw).
+
+        Blocking behaviour: the call only enqueues on the current stream, except that the first call at a new (B, T) sizes every
+        workspace for it first (``svoc_synth_reserve``: a no-op unless one has to grow; then one device synchronisation +
+        reallocation, BEFORE anything of this call is enqueued, never in the middle of it).  Call ``reserve(batch, frames)``
+        once with the largest shape to keep every later ``infer`` free of allocations and synchronisations.
         """
         x = N.f32(x)
         if x.dim() != 3 or x.shape[1] != 80:
             raise ValueError(f"expected mel [B, 80, T], got {tuple(x.shape)}")
         B, _, T = x.shape
         ln = x_lengths.to(device=x.device, dtype=torch.int64).contiguous()
-        if eps is None:
-            eps = torch.randn(B, self.inter_channels, T, dtype=torch.float32, device=x.device)
-        eps = N.f32(eps)
-        if tuple(eps.shape) != (B, self.inter_channels, T):
-            raise ValueError("eps must be [B, inter_channels, T]")
         Td = T if max_len is None else max(0, min(T, int(max_len) if max_len >= 0 else T + int(max_len)))
         dev = x.device
         IC = self.inter_channels
+        z, z_p, m_p, logs_p = (torch.empty(B, IC, T, dtype=torch.float32, device=dev) for _ in range(4))
+        if eps is None:
+            eps = torch.randn_like(m_p)                      # the reference's draw (models.py:336)
+        eps = N.f32(eps)
+        if tuple(eps.shape) != (B, self.inter_channels, T):
+            raise ValueError("eps must be [B, inter_channels, T]")
         o = torch.empty(B, 1, Td * self.dec.hop, dtype=torch.float32, device=dev)
         x_mask = torch.empty(B, 1, T, dtype=torch.float32, device=dev)
-        z, z_p, m_p, logs_p = (torch.empty(B, IC, T, dtype=torch.float32, device=dev) for _ in range(4))
         if Td == 0:
             raise ValueError("max_len leaves no frames to decode")
         _same_device(x, eps)
         with torch.cuda.device(dev):
-            N.check(N.lib().svoc_synth_infer(self._native(), N.stream_ptr(dev), N.ptr(x), N.ptr(ln), N.ptr(eps),
+            h = self._native()
+            seen = self._nh.__dict__.setdefault("reserved_shapes", set())   # (on the Handle object: a rebuilt handle starts from nothing)
+            if (B, T) not in seen:
+                # first sight of this shape: size every workspace for it now, ahead of the first launch of this call
+                # (a no-op unless some workspace has to grow; then: one device synchronisation + reallocation)
+                N.check(N.lib().svoc_synth_reserve(h, B, T))
+                if len(seen) >= 4096:
+                    seen.clear()
+                seen.add((B, T))
+            N.check(N.lib().svoc_synth_infer(h, N.stream_ptr(dev), N.ptr(x), N.ptr(ln), N.ptr(eps),
                                              float(noise_scale), Td, N.ptr(o), N.ptr(x_mask), N.ptr(z), N.ptr(z_p),
                                              N.ptr(m_p), N.ptr(logs_p), B, T))
         return o, x_mask, (z, z_p, m_p, logs_p)
@@ -345,7 +361,9 @@ class SynthesizerTrn(_HipModule):
         """Extension: size the library's workspaces for batches up to [batch, 80, frames] now, so that later ``infer``
         calls neither allocate nor synchronise (svoc_synth_reserve)."""
         with torch.cuda.device(self._dev()):
-            N.check(N.lib().svoc_synth_reserve(self._native(), int(batch), int(frames)))
+            h = self._native()
+            N.check(N.lib().svoc_synth_reserve(h, int(batch), int(frames)))
+            self._nh.__dict__.setdefault("reserved_shapes", set()).add((int(batch), int(frames)))
         return self
 
     # receptive half-width of the whole path in mel frames: encoder WN 16*2 + flow 4*8*2 + decoder (conv_pre 3,

@@ -55,8 +55,13 @@ def scatter_batch(tensors, shapes_tail, dtypes, B, src=0, device=None, group=Non
     """Scatter dim-0 chunks of each tensor from `src` in ONE collective: the source packs (lengths | mel | eps ...) of every rank
     into one byte buffer [world, chunk_bytes] - one strided device copy per tensor, no zero filling, no per-rank loop when B
     divides evenly - and scatters its rows (views, no further copies).  `tensors` is the list of full tensors on `src` (ignored
-    elsewhere); shapes_tail/dtypes describe them on every rank.  Returns the local chunks on `device` (views of the receive
-    buffer)."""
+    elsewhere); shapes_tail/dtypes describe them on every rank.  Returns the local chunks on `device`.
+
+    ALIASING: when the collective runs on `device` itself (RCCL) the returned tensors are VIEWS OF ONE shared uint8 receive
+    buffer (mel, lengths and eps share a storage; `.untyped_storage()` spans all of them).  They are meant to be read -
+    `infer` only reads its inputs; clone a chunk before writing to it in place or before handing it to code that assumes
+    it owns the storage.  With an uneven split the spare slot of the smaller chunks is sent uninitialised and is NOT part of
+    the returned views."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bounds = shard_bounds(B, world)
     nloc = bounds[rank][1] - bounds[rank][0]
@@ -134,7 +139,7 @@ def _now(dev):
 
 
 def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0, group=None, bucket=False, bitwise=False,
-                  halo_frames=None, timings=None):
+                  halo_frames=None, timings=None, shape=None, host_lengths=None, out=None):
     """Run net.infer on this rank's shard of a batch living on `src`; `src` gets the full [B,1,L] waveform back.
     mel/lengths/eps need to be valid on `src` only (shapes are broadcast from there).
 
@@ -150,20 +155,41 @@ def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0
       gathered result is bit-identical to a single process running the whole batch under the same setting (SURVEY.md 8e);
       with bucket=True the trimmed frame count differs per shard, so only bucket=False is bit-exact.
     timings: optional dict, filled with host-side milliseconds {"scatter_ms", "infer_ms", "gather_ms"} (device
-      synchronised at each boundary - diagnostics, costs a sync per phase)."""
+      synchronised at each boundary - diagnostics, costs a sync per phase).
+    shape: (B, T) of the job's batch, passed by EVERY rank - the call then makes no metadata broadcast and no host read-back:
+      it is ONE scatter + infer + ONE gather, all enqueued (n_mel / inter_channels are the model's).  Without it the
+      shapes are broadcast from `src` (one small collective + a host synchronisation per call).
+    host_lengths: bucket=True only - the job's lengths as a HOST sequence / tensor on every rank: the sort and every
+      shard's frame count are then computed on the host, without the lengths broadcast and its device read-back.
+    out: `src` only, optional [B, 1, L] receive buffer for the gather (see gather_waveforms; ignored with bucket=True)."""
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     dev = next(net.parameters()).device
     wire = _wire_device(dev, group)
     tdev = dev if timings is not None else None
     t0 = _now(tdev) if timings is not None else 0.0
-    meta = torch.zeros(4, dtype=torch.int64, device=wire)
-    if rank == src:
-        meta[0], meta[1], meta[2], meta[3] = mel.shape[0], mel.shape[2], eps.shape[1], mel.shape[1]
-    dist.broadcast(meta, src=src, group=group)
-    B, T, IC, n_mel = (int(v) for v in meta.tolist())
+    if shape is not None:
+        B, T = int(shape[0]), int(shape[1])
+        IC, n_mel = int(net.inter_channels), 80
+        if rank == src and (tuple(mel.shape) != (B, n_mel, T) or tuple(eps.shape) != (B, IC, T)):
+            raise ValueError(f"shape={tuple(shape)} does not describe mel {tuple(mel.shape)} / eps {tuple(eps.shape)}")
+    else:
+        meta = torch.zeros(4, dtype=torch.int64, device=wire)
+        if rank == src:
+            meta[0], meta[1], meta[2], meta[3] = mel.shape[0], mel.shape[2], eps.shape[1], mel.shape[1]
+        dist.broadcast(meta, src=src, group=group)
+        B, T, IC, n_mel = (int(v) for v in meta.tolist())
     inv = None
-    if bucket:
+    if bucket and host_lengths is not None:
+        hl = torch.as_tensor(host_lengths, dtype=torch.int64, device="cpu").reshape(-1)
+        if hl.numel() != B:
+            raise ValueError("host_lengths must hold the job's B lengths")
+        order, inv = sort_by_length(hl)
+        ln_all = hl[order]
+        if rank == src:
+            od = order.to(mel.device)
+            mel, lengths, eps = mel[od], lengths.to(mel.device)[od], eps[od]
+    elif bucket:
         # every rank needs the sorted lengths to size its own shard; only src has them
         ln_all = torch.zeros(B, dtype=torch.int64, device=wire)
         order = None
@@ -204,7 +230,7 @@ def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0
     else:
         o = torch.empty(0, 1, Td * hop, device=dev)
     t2 = _now(tdev) if timings is not None else 0.0
-    out = gather_waveforms(o, B, dst=src, group=group)
+    out = gather_waveforms(o, B, dst=src, group=group, out=None if bucket else out)
     if out is not None and inv is not None:
         out = out[inv.to(out.device)]
     if timings is not None:

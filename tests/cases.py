@@ -35,6 +35,43 @@ INFER_CASES = {
 }
 
 
+# Full-size runs of the REFERENCE itself (tests/golden/make_golden.py): the bench workload C2 (16 x 512, seed 1001 - exactly
+# bench.py's tensors) and one long utterance (1 x 4096).  Stored: every `stride`-th waveform sample, float64 sum / sum of
+# squares of the waveform per mel frame (256 samples), per-utterance float64 sum / sum of squares of z, z_p, m_p, logs_p, and
+# z of `z_rows` at every `z_stride`-th frame.  These shapes reach the throughput kernels (grouped / pair / accumulate Winograd
+# launches, F(4,2) upsamplers, fused F(2,5) WN layers) that the small full-path cases above never select.
+REF_LARGE_CASES = {
+    "c2_16x512": dict(B=16, T=512, seed=1001, noise_scale=0.667, stride=64, z_rows=(0, 15), z_stride=4),
+    "long_1x4096": dict(B=1, T=4096, seed=1005, noise_scale=0.667, stride=64, z_rows=(0,), z_stride=16),
+}
+
+
+def large_inputs(case):
+    c = REF_LARGE_CASES[case]
+    mel = sw.synthetic_mel(c["seed"], c["B"], c["T"])
+    eps = sw.synthetic_eps(c["seed"], c["B"], c["T"])
+    ln = np.full((c["B"],), c["T"], dtype=np.int64)
+    return mel, ln, eps
+
+
+def large_digest(c, o, z, z_p, m_p, logs_p, rows=None):
+    """The quantities a REF_LARGE fixture holds, computed from full outputs (numpy, float32 in; sums in float64).
+    `rows`: the utterances `o` ... hold (default: all of the case's batch)."""
+    o = np.asarray(o)[:, 0, :]
+    d = {"o_sub": np.ascontiguousarray(o[:, ::c["stride"]]).astype(np.float32)}
+    o64 = o.astype(np.float64).reshape(o.shape[0], -1, 256)
+    d["o_frame_sum"] = o64.sum(-1)
+    d["o_frame_sumsq"] = (o64 * o64).sum(-1)
+    for nm, a in (("z", z), ("z_p", z_p), ("m_p", m_p), ("logs_p", logs_p)):
+        a64 = np.asarray(a).astype(np.float64)
+        d[nm + "_sum"] = a64.sum((1, 2))
+        d[nm + "_sumsq"] = (a64 * a64).sum((1, 2))
+    rows = list(range(o.shape[0])) if rows is None else list(rows)
+    zr = [rows.index(r) for r in c["z_rows"] if r in rows]
+    d["z_rows"] = np.ascontiguousarray(np.asarray(z)[zr][:, :, ::c["z_stride"]]).astype(np.float32)
+    return d
+
+
 def infer_inputs(case):
     c = INFER_CASES[case]
     mel = sw.synthetic_mel(c["seed"], c["B"], c["T"])

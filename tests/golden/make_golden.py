@@ -79,6 +79,21 @@ for name, c in cases.INFER_CASES.items():
     save("infer_" + name, o=o.numpy(), mask=mask.numpy(), z=z.numpy(), z_p=z_p.numpy(), m_p=m_p.numpy(),
          logs_p=logs_p.numpy())
 
+# full-size runs of the reference (the shapes that select the throughput kernels): digests only, see cases.REF_LARGE_CASES
+for name, c in cases.REF_LARGE_CASES.items():
+    if ONLY and not any(f in "ref_" + name for f in ONLY):
+        continue
+    mel, ln, eps = cases.large_inputs(name)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: T(eps).to(t.dtype)
+    try:
+        o, mask, (z, z_p, m_p, logs_p) = net.infer(T(mel), T(ln), noise_scale=c["noise_scale"])
+    finally:
+        torch.randn_like = orig
+    assert bool(mask.all())
+    print(name, "o rms", float(o.pow(2).mean().sqrt()), "max", float(o.abs().max()), "z rms", float(z.pow(2).mean().sqrt()))
+    save("ref_" + name, **cases.large_digest(c, o.numpy(), z.numpy(), z_p.numpy(), m_p.numpy(), logs_p.numpy()))
+
 # decoder stage activations of the C1 case (stage rms sanity for DESIGN.md; not stored)
 
 # ---------------------------------------------------------------- module-level

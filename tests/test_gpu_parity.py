@@ -643,6 +643,61 @@ def test_c2_full_size_vs_oracle(M, net):
     assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)
 
 
+def test_default_noise_is_the_reference_draw(M, net):
+    """Without `eps=` the reference draws `torch.randn_like(m_p)` (models.py:336: one N(0,1) draw of a [B, 192, T] fp32
+    tensor on the model's device).  Our `infer` must consume the generator the same way: after the same seed, the default
+    path equals the injected-eps path given that very draw, bit for bit, and leaves the generator in the same state."""
+    mel, ln, _ = cases.infer_inputs("ragged")
+    mel, ln = T(mel).cuda(), T(ln).cuda()
+    B, _, Tn = mel.shape
+    torch.manual_seed(4242)
+    o1, _, (z1, zp1, mp1, _) = net.infer(mel, ln, noise_scale=0.667)
+    after_default = torch.cuda.get_rng_state()
+    torch.manual_seed(4242)
+    eps = torch.randn_like(torch.empty(B, 192, Tn, dtype=torch.float32, device="cuda"))
+    after_draw = torch.cuda.get_rng_state()
+    o2, _, (z2, zp2, mp2, _) = net.infer(mel, ln, noise_scale=0.667, eps=eps)
+    assert torch.equal(after_default, after_draw)
+    assert torch.equal(zp1, zp2) and torch.equal(z1, z2) and torch.equal(o1, o2)
+    lp = net.infer(mel, ln, noise_scale=0.667, eps=eps)[2][3]
+    rec = ((zp1 - mp1) / (torch.exp(lp) * 0.667))                      # the draw, recovered as SURVEY.md 8c describes
+    m = (torch.arange(Tn, device="cuda")[None, :] < ln[:, None])[:, None, :].expand_as(rec)
+    assert (rec - eps)[m].abs().max().item() <= 1e-4
+    torch.manual_seed(4243)
+    assert not torch.equal(net.infer(mel, ln, noise_scale=0.667)[0], o1)
+
+
+@pytest.mark.parametrize("name", list(cases.REF_LARGE_CASES))
+def test_full_size_vs_reference_fixture(M, net, name):
+    """The throughput kernels against numbers the REFERENCE produced: `tests/golden/make_golden.py` ran
+    /root/reference's SynthesizerTrn.infer (models.py:331-339) on the bench batch itself (16 x 512, seed 1001) and on a
+    1 x 4096 utterance; the fixtures hold every 64th waveform sample, float64 sums / energies of every 256-sample frame (so
+    every output sample is covered), per-utterance sums of the latents and z of two utterances.  At these sizes `infer` runs
+    the grouped / pair / merged-accumulate Winograd F(4,3)/F(4,4) launches, the F(4,2) upsamplers and the fused F(2,5) WN
+    layers - none of which the small reference fixtures select."""
+    c = cases.REF_LARGE_CASES[name]
+    mel, ln, eps = cases.large_inputs(name)
+    M.native.stats_reset()
+    o, mask, (z, z_p, m_p, logs_p) = net.infer(T(mel).cuda(), T(ln).cuda(), noise_scale=c["noise_scale"], eps=T(eps).cuda())
+    st = M.native.stats_get()
+    assert st["executed_flops"] < 0.6 * st["conv_flops"], "the Winograd throughput kernels did not run at this size"
+    assert bool(mask.all())
+    d = cases.large_digest(c, o.cpu().numpy(), z.cpu().numpy(), z_p.cpu().numpy(), m_p.cpu().numpy(), logs_p.cpu().numpy())
+    g = cases.golden("ref_" + name)
+    check(name + " waveform subsample", d["o_sub"], g["o_sub"])
+    err = (d["o_sub"].astype(np.float64) - g["o_sub"])
+    rms, ref = float(np.sqrt((err ** 2).mean())), float(np.sqrt((g["o_sub"].astype(np.float64) ** 2).mean()))
+    fs = float(np.abs(d["o_frame_sum"] - g["o_frame_sum"]).max())
+    fe = float((np.abs(d["o_frame_sumsq"] - g["o_frame_sumsq"]) / (g["o_frame_sumsq"] + 1e-3)).max())
+    print(f"{name} vs REFERENCE: subsample rms err {rms:.3e} (rel {rms / ref:.2e}), frame sums max {fs:.2e}, frame energies rel {fe:.2e}")
+    assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)
+    assert fs <= 1e-3 and fe <= 1e-4, (fs, fe)
+    check(name + " z rows", d["z_rows"], g["z_rows"], 5e-5, 1e-4)
+    for nm in ("z", "z_p", "m_p", "logs_p"):
+        assert np.abs(d[nm + "_sum"] - g[nm + "_sum"]).max() <= 5e-2, nm
+        assert (np.abs(d[nm + "_sumsq"] - g[nm + "_sumsq"]) / g[nm + "_sumsq"]).max() <= 2e-5, nm
+
+
 def test_variant_batch_pins_kernel_choice(M, net):
     """svoc_set_variant_batch(n): kernel variants are chosen as if the batch held n utterances, so a shard of a job
     reproduces the whole job's bits ("8-GPU output == 1-GPU output bitwise").  16 x 200 frames: alone, a

@@ -1,36 +1,23 @@
-"""The alternate kernel paths that still ship are selected by environment variables the library reads once per process, so
-each variant runs a slice of the parity suite in a subprocess.  Every `getenv` in csrc/ that changes a kernel choice is
-listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run checks the two lists against each other):
+"""The fall-back kernel paths a SHAPE can reach are selected, at the shapes of the parity suite, by environment variables the library
+reads once per process, so each variant runs a slice of the parity suite in a subprocess.  Every `getenv` in csrc/ that changes a kernel
+choice is listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run checks the two lists against each other).  Round 5
+removed the switches (and the code) that only an environment variable could reach - A/B arms whose verdict is recorded in DESIGN.md:
+SVOC_W4_{ACCUM,ACC3,PERM,PRIO,PAIR,PAIR64}, SVOC_FUSE_V, SVOC_FUSE64, SVOC_WINO_WS, SVOC_WINO_WM, SVOC_WN_CT, SVOC_WN_KSPLIT, SVOC_LN_V2,
+SVOC_XCD, SVOC_CT_ROWS256, SVOC_CT_TAIL, SVOC_STREAMS (kernels those arms shared with a shape-reachable path are covered by shape:
+tests/test_gpu_parity.py::test_fallback_shapes).
 
-  SVOC_FUSE=0 SVOC_FUSE_WN=0     unfused fallbacks: two convolutions per ResBlock iteration / WN layer
-  SVOC_FUSE_V=1                  generic fused-ResBlock kernel instead of the compile-time-specialised one
-  SVOC_FUSE64=1                  C=64 stage on the fused direct-form ResBlock kernel instead of Winograd conv by conv
-  SVOC_STREAMS=0                 single-stream MRF
-  SVOC_GROUP=0                   MRF chains on separate streams for every stage (no grouped launches)
-  SVOC_WINO=0                    direct-form grouped kernel (conv_group_kernel) instead of Winograd F(2,3)
-  SVOC_WINO_F4=0                 Winograd F(2,3) kernels (wave-specialised, two workgroups per CU) instead of F(4,3)
-  SVOC_WINO_F4=0 SVOC_WINO_WS=0  four-wave F(2,3) Winograd kernels
-  SVOC_W4_PRIO=0                 F(4,3) producers at the consumers' priority
+  SVOC_FUSE=0 SVOC_FUSE_WN=0     unfused fallbacks: two convolutions per ResBlock iteration / WN layer (any shape the fused kernels refuse)
+  SVOC_GROUP=0                   MRF chains on separate streams for every stage (chains that disagree on the dilation order; short inputs)
+  SVOC_WINO=0                    direct-form kernels instead of Winograd (kernel sizes other than 3 / 7 / 11, dilations other than 1 / 3 / 5)
+  SVOC_WINO_F4=0                 Winograd F(2,3) kernels instead of F(4,3) / F(4,4) (odd row-block counts, unaligned rows, L % 4 != 0)
   SVOC_W4_F44=0                  k = 7 / 11 in F(4,3) form (six-product groups + left-over taps) instead of F(4,4)
-  SVOC_W4_ACC3=0                 the accumulate launch as three read-modify-write members instead of one set of accumulators
-  SVOC_W4_PAIR64=0               C = 64 stage: the undilated ResBlock iteration conv by conv as well (the pair kernel at C = 32 only)
-  SVOC_W4_PAIR=0                 C = 32 stage: c1 and c2 of a ResBlock iteration as two grouped launches instead of one (conv_wino4_pair.hip)
-  SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv
-  SVOC_W4_PERM=0                 dilated F(4,3) convolutions store their rows in natural order (four scattered dwords per lane)
+  SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv (short inputs)
   SVOC_WN_SMALL_F25=0            short inputs: WN layers as two K-split convolutions instead of one launch per layer (wn_small.hip)
-  SVOC_WN_F25=0                  WN in_layers in direct form (K-split layer kernel) instead of Winograd F(2,5)
-  SVOC_W4_ACCUM=0                the chains' last convolutions as three launches instead of one accumulate launch
-  SVOC_WINO_WM=2                 2x2 wave layout (64-row tiles) for the Winograd kernels at C >= 128
-  SVOC_WN_CT=0                   generic (runtime-geometry) MFMA loops in the K-split WN layer kernel
-  SVOC_WN_KSPLIT=0               6-wave WN layer kernel (one wave per row pair) instead of the 12-wave K-split one
+  SVOC_WN_F25=0                  WN in_layers in direct form (K-split layer kernel) instead of Winograd F(2,5) (H != 192, k != 5)
   SVOC_KSPLIT=0 SVOC_WN_SMALL=0 SVOC_MRF_SMALL=0    short inputs on the throughput kernels (no K-split convolutions, fused WN
                                  layers, grouped MRF launches)
-  SVOC_GRAPH=0                   short inputs as direct launches (no captured hipGraph plans)
-  SVOC_XCD=0                     natural workgroup -> tile order instead of the XCD-aware one
-  SVOC_LN_V2=0                   round-1 LayerNorm / DDSConv tile kernel
-  SVOC_CT_WINO=0                 upsamplers on the direct polyphase kernel instead of the Winograd F(4,2) one (convt_wino.hip)
-  SVOC_CT_TAIL=0                 F(4,2) upsamplers: the column q = L inside the window tiles (no separate tail launch)
-  SVOC_CT_ROWS256=0              F(4,2) upsamplers: 128-row blocks (four consumer waves) where 256-row blocks would be used
+  SVOC_GRAPH=0                   short inputs as direct launches (no captured hipGraph plans: a caller that is itself capturing)
+  SVOC_CT_WINO=0                 upsamplers on the direct polyphase kernel instead of the Winograd F(4,2) one (other k / stride; short inputs)
 """
 import os
 import subprocess
@@ -48,38 +35,20 @@ pytestmark = pytest.mark.gpu
 DEC = ("test_conv1d_winograd or test_resblock1 or test_generator or test_infer_vs_reference_golden or test_infer_long_form_tiling")
 WNS = "test_wn or test_coupling or test_infer_vs_reference_golden or test_full_size_properties"
 SMALL = "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_generator or test_wn or test_resblock1"
-OFFG = "test_dds or test_layer_norm or test_convflow"
 UPS = "test_conv_transpose or test_generator or test_infer_vs_reference_golden or test_c2_full_size_vs_oracle"
 
 VARIANTS = {
     "unfused": ({"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"}, DEC + " or " + WNS),
-    "generic_fused_resblock": ({"SVOC_FUSE_V": "1"}, DEC),
-    "fused_c64": ({"SVOC_FUSE64": "1"}, DEC),
-    "single_stream": ({"SVOC_STREAMS": "0"}, DEC),
     "ungrouped": ({"SVOC_GROUP": "0"}, DEC),
     "no_winograd": ({"SVOC_WINO": "0"}, DEC),
     "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
-    "winograd_f23_4wave": ({"SVOC_WINO_F4": "0", "SVOC_WINO_WS": "0"}, DEC),
-    "winograd_f43_equal_priority": ({"SVOC_W4_PRIO": "0"}, DEC),
     "winograd_f43_for_k7_k11": ({"SVOC_W4_F44": "0"}, DEC),
-    "mrf_accumulate_one_by_one": ({"SVOC_W4_ACCUM": "0"}, DEC),
-    "mrf_accumulate_three_members": ({"SVOC_W4_ACC3": "0"}, DEC),
-    "c32_conv_by_conv": ({"SVOC_W4_PAIR": "0"}, DEC),
-    "c64_conv_by_conv": ({"SVOC_W4_PAIR64": "0"}, DEC),
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
-    "winograd_f43_natural_rows": ({"SVOC_W4_PERM": "0"}, DEC),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),
     "wn_short_inputs_two_convolutions": ({"SVOC_WN_SMALL_F25": "0"}, SMALL + " or test_coupling or test_flow"),
-    "winograd_2x2": ({"SVOC_WINO_F4": "0", "SVOC_WINO_WM": "2"}, DEC),
-    "wn_no_ksplit": ({"SVOC_WN_KSPLIT": "0"}, WNS),
-    "wn_generic_loops": ({"SVOC_WN_CT": "0"}, WNS),
     "no_small_shape_kernels": ({"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"}, SMALL),
     "no_graph": ({"SVOC_GRAPH": "0"}, SMALL),
-    "natural_tile_order": ({"SVOC_XCD": "0"}, DEC),
-    "layernorm_v1": ({"SVOC_LN_V2": "0"}, OFFG),
     "upsamplers_direct": ({"SVOC_CT_WINO": "0"}, UPS),
-    "upsamplers_f42_no_tail_launch": ({"SVOC_CT_TAIL": "0"}, UPS),
-    "upsamplers_f42_128_row_blocks": ({"SVOC_CT_ROWS256": "0"}, UPS),
 }
 
 

@@ -52,6 +52,40 @@ def test_infer(name):
     close(o, g["o"], 1e-5)
 
 
+def digest_close(d, g, sub_tol, frame_tol, what):
+    """A REF_LARGE digest `d` (cases.large_digest) against the reference's `g`, restricted to the rows `d` holds."""
+    err = np.abs(d["o_sub"] - g["o_sub"])
+    assert err.max() <= sub_tol, (what, "waveform subsample", float(err.max()))
+    # 256-sample frame sums: every sample of the waveform enters one of them
+    assert np.abs(d["o_frame_sum"] - g["o_frame_sum"]).max() <= frame_tol, (what, "frame sums", float(np.abs(d["o_frame_sum"] - g["o_frame_sum"]).max()))
+    rel = np.abs(d["o_frame_sumsq"] - g["o_frame_sumsq"]) / (g["o_frame_sumsq"] + 1e-3)
+    assert rel.max() <= 1e-4, (what, "frame energies", float(rel.max()))
+
+
+@pytest.mark.parametrize("name,rows", [("c2_16x512", (0, 15)), ("long_1x4096", (0,))])
+def test_oracle_vs_reference_at_full_size(name, rows):
+    """The oracle against the REFERENCE's own outputs at the sizes the throughput kernels run at (make_golden.py ran the
+    reference on the bench batch, 16 x 512 seed 1001, and on a 1 x 4096 utterance; digests in tests/golden/ref_*.npz).
+    Utterances are independent (reference models.py:331-339 has no cross-batch op), so the CPU suite runs rows 0 and 15 of
+    C2 only and compares them with the matching rows of the digest."""
+    c = cases.REF_LARGE_CASES[name]
+    mel, ln, eps = cases.large_inputs(name)
+    rows = list(rows)
+    sd = sdT(cases.full_model_weights())
+    with torch.no_grad():
+        o, mask, (z, z_p, m_p, logs_p) = O.infer(sd, T(mel[rows]), T(ln[rows]), T(eps[rows]), c["noise_scale"])
+    d = cases.large_digest(c, o.numpy(), z.numpy(), z_p.numpy(), m_p.numpy(), logs_p.numpy(), rows=rows)
+    g = cases.golden("ref_" + name)
+    gz = g["z_rows"]
+    g = {k: (v[rows] if k != "z_rows" else v) for k, v in g.items()}
+    digest_close(d, g, 1e-5, 2e-4, name)
+    zi = [list(c["z_rows"]).index(r) for r in rows if r in c["z_rows"]]
+    assert np.abs(d["z_rows"] - gz[zi]).max() <= 4e-6
+    for nm in ("z", "z_p", "m_p", "logs_p"):
+        assert np.abs(d[nm + "_sum"] - g[nm + "_sum"]).max() <= 2e-2, nm        # sums over 98 304+ elements of O(1) values
+        assert (np.abs(d[nm + "_sumsq"] - g[nm + "_sumsq"]) / g[nm + "_sumsq"]).max() <= 1e-5, nm
+
+
 @pytest.mark.parametrize("name", list(cases.RESBLOCK1_CASES))
 def test_resblock1(name):
     c = cases.RESBLOCK1_CASES[name]

@@ -20,6 +20,7 @@ class _FakeNet(torch.nn.Module):
     """Stands in for SynthesizerTrn on CPU: 'waveform' = a deterministic function of (mel, eps, lengths)."""
 
     RECEPTIVE_FRAMES = 2
+    inter_channels = 192
 
     class _Dec:
         hop = 4
@@ -80,6 +81,33 @@ def _worker(rank, world, port, B, T, q):
     ok = ok and N.set_variant_batch(0) == 0          # restored after the call
     if rank == 0:
         ok = ok and torch.equal(o2, ref)
+    # shapes passed by the caller: no metadata broadcast, no host read-back; gather into the caller's buffer
+    calls = {"n": 0}
+    orig_bc = dist.broadcast
+
+    def counting_broadcast(*a, **k):
+        calls["n"] += 1
+        return orig_bc(*a, **k)
+
+    dist.broadcast = counting_broadcast
+    try:
+        outb = torch.full((B, 1, T * 4), float("nan")) if rank == 0 else None
+        o3 = parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                                    noise_scale=0.5, src=0, shape=(B, T), out=outb)
+        o4 = parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                                    noise_scale=0.5, src=0, bucket=True, shape=(B, T), host_lengths=ln.tolist())
+    finally:
+        dist.broadcast = orig_bc
+    ok = ok and calls["n"] == 0
+    if rank == 0:
+        ok = ok and torch.equal(o3, ref) and torch.equal(o4, ob)
+        if B % world == 0:
+            ok = ok and o3.data_ptr() == outb.data_ptr()
+        try:
+            parallel.infer_sharded(net, mel, ln, eps, src=0, shape=(B + 1, T))
+            ok = False
+        except ValueError:
+            pass
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -97,6 +125,45 @@ def test_scatter_gather_world2(B):
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+@pytest.mark.parametrize("B,world", [(5, 3), (2, 3), (9, 8), (7, 7), (1, 4)])
+def test_scatter_uneven_splits_and_small_batches_mocked(B, world, monkeypatch):
+    """uneven splits and B < world of the packed scatter, and what the returned chunks alias.  torch.distributed is
+    replaced by a recorder: the source rank's call captures the rows it would send, every other rank's call receives its row."""
+    from smart_vocoder_amd import parallel
+    T = 6
+    g = torch.Generator().manual_seed(B * 31 + world)
+    mel = torch.randn(B, 80, T, generator=g); eps = torch.randn(B, 192, T, generator=g)
+    ln = torch.randint(1, T + 1, (B,), generator=g)
+    state = {"rank": 0, "rows": None}
+
+    def fake_scatter(recv, rows, src=0, group=None):
+        if state["rank"] == src:
+            assert rows is not None and len(rows) == world and all(r.numel() == recv.numel() for r in rows)
+            state["rows"] = [r.clone() for r in rows]
+        else:
+            assert rows is None
+        recv.copy_(state["rows"][state["rank"]])
+
+    monkeypatch.setattr(parallel.dist, "get_world_size", lambda group=None: world)
+    monkeypatch.setattr(parallel.dist, "get_rank", lambda group=None: state["rank"])
+    monkeypatch.setattr(parallel.dist, "get_backend", lambda group=None: "gloo")
+    monkeypatch.setattr(parallel.dist, "scatter", fake_scatter)
+    bounds = parallel.shard_bounds(B, world)
+    for r in range(world):
+        state["rank"] = r
+        m, l, e = parallel.scatter_batch([mel, ln, eps] if r == 0 else None, [(80, T), (), (192, T)],
+                                         [torch.float32, torch.int64, torch.float32], B, src=0, device=torch.device("cpu"))
+        a, b = bounds[r]
+        assert m.shape[0] == l.shape[0] == e.shape[0] == b - a
+        assert torch.equal(m, mel[a:b]) and torch.equal(l, ln[a:b]) and torch.equal(e, eps[a:b])
+        if b > a:
+            # documented aliasing: the three chunks are views of one receive buffer
+            assert m.untyped_storage().data_ptr() == l.untyped_storage().data_ptr() == e.untyped_storage().data_ptr()
+            keep = e.clone()
+            m.add_(1.0)                                  # writing one chunk in place must not reach its neighbours' regions
+            assert torch.equal(e, keep) and torch.equal(l, ln[a:b])
 
 
 def test_shard_bounds_and_sort():

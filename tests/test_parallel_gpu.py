@@ -103,6 +103,12 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["collective"] == "gather" and j["config"]["global_batch"] == 8
     assert j["value"] > 0 and j["scaling"] == "weak"
+    # attribution of an N>1 line: per-rank spans and the public entry point timed beside the step
+    pr = j["per_rank"]
+    assert all(len(pr[k]) == 2 and min(pr[k]) > 0 for k in ("step_wall_ms", "infer_ms", "gather_ms", "step_gpu_ms")), pr
+    assert j["step_ms_min_over_ranks"] <= j["step_ms_max_over_ranks"] <= j["ms_per_step"] * 1.001
+    sh = j["infer_sharded"]
+    assert "error" not in sh and sh["ms_per_call"] > 0 and sh["equals_timed_step_output"] is True, sh
 
 
 def test_bench_single_gpu_line_schema():
@@ -199,3 +205,5 @@ def test_bench_one_rank_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["config"]["collective"] == "gather" and j["config"]["scatter_ms"] is not None, j["config"]
+    assert len(j["per_rank"]["infer_ms"]) == 1 and j["gather_ms"] > 0 and j["infer_sharded"]["equals_timed_step_output"] is True, j
+    assert j["scaling_curve"].startswith("NOT MEASURED")
