@@ -567,6 +567,18 @@ __global__ void __launch_bounds__(768) wn_layer_f25_kernel(const WnArgs p) {
   long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int i) { if (p.dbg) ts[i] = (long long)__builtin_readcyclecounter(); };
   stamp(0);
+  // phase A's weight stream: descriptor, ring of four 16-byte sets, three requests ahead.  The first three go out here, ahead of the x tile
+  // (round 5: they used to wait behind the planes' barrier, and the stream then started with an L2 round trip)
+  constexpr int NST = WNF_KS * 6;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpf), 0, 0x7fffffff, 0x00020000);
+  const int w0 = __builtin_amdgcn_readfirstlane((pi * 2 + kh) * NST * 1024);
+  const unsigned wlane = (unsigned)lane * 16u;
+  float4 a[4];
+  auto wload = [&](float4& d, int soff) {
+    const wn_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wlane, soff, 0);
+    d = *reinterpret_cast<const float4*>(&t);
+  };
+  wload(a[0], w0); wload(a[1], w0 + 1024); wload(a[2], w0 + 2048);
   // ---- stage the x tile: all H channels, columns [t0 - 4, t0 + 36), zero outside [0, T)
   {
     constexpr int R4 = WNF_XROW / 4, total = H * R4, SU = 3;       // 1920 groups of four floats: 2.5 per thread
@@ -633,18 +645,9 @@ __global__ void __launch_bounds__(768) wn_layer_f25_kernel(const WnArgs p) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) M[rt][q] = (wn_f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    constexpr int NST = WNF_KS * 6;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpf), 0, 0x7fffffff, 0x00020000);
-    const int w0 = __builtin_amdgcn_readfirstlane((pi * 2 + kh) * NST * 1024);
-    const unsigned wlane = (unsigned)lane * 16u;
     const unsigned baddr0 = (unsigned)(size_t)PLN + (unsigned)(((kh * 96 + k4) * WNF_NQ + col) * 4);
     const unsigned baddr1 = baddr0 + 3u * WNF_PLANE * 4u;
-    float4 a[4];
     float fb[2];
-    auto wload = [&](float4& d, int soff) {
-      const wn_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)wlane, soff, 0);
-      d = *reinterpret_cast<const float4*>(&t);
-    };
     auto rdb = [&](auto ic) {
       constexpr int I = decltype(ic)::value;
       if constexpr (I < NST) {
@@ -676,7 +679,6 @@ __global__ void __launch_bounds__(768) wn_layer_f25_kernel(const WnArgs p) {
       rdb(std::integral_constant<int, I + 2>{});
       __builtin_amdgcn_sched_barrier(0);
     };
-    rqw(std::integral_constant<int, 0>{}); rqw(std::integral_constant<int, 1>{}); rqw(std::integral_constant<int, 2>{});
     rdb(std::integral_constant<int, 0>{}); rdb(std::integral_constant<int, 1>{});
     wino_static_for<0, NST>(step);
   }
@@ -695,6 +697,24 @@ __global__ void __launch_bounds__(768) wn_layer_f25_kernel(const WnArgs p) {
       const float y1 = __builtin_fmaf(2.f, d34, d12) + M[rt][5][i];
       if (mine) { own[h][i][0] = y0; own[h][i][1] = y1; }
       else { red_mine[(h * 8 + 2 * i) * 64] = y0; red_mine[(h * 8 + 2 * i + 1) * 64] = y1; }
+    }
+  }
+  // The epilogue's read operands - kh = 0: the residual rows of x (on the last layer: the rows of `out`), kh = 1: the rows of `out` - are requested
+  // here, their latency under the exchange barriers, the gate and phase B (round 5: the epilogue used to start with these sixteen loads).
+  const int te = t0 + l31, tec = min(te, p.T - 1);
+  const int row0 = pi * 32 + 4 * hi;
+  float pre[16];
+  {
+    const bool want_x = !LAST && !kh, want_o = (LAST ? !kh : kh) && !p.first;
+    const float* src = want_x ? p.x + (long long)b * p.x_bs + (long long)row0 * p.x_ld + tec
+                              : p.out + (long long)b * p.out_bs + (long long)row0 * p.out_ld + tec;
+    const long long sld = want_x ? p.x_ld : p.out_ld;
+    if (want_x || want_o) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pre[r] = src[(long long)((r & 3) + 8 * (r >> 2)) * sld];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pre[r] = 0.f;
     }
   }
   stamp(7);
@@ -762,39 +782,23 @@ __global__ void __launch_bounds__(768) wn_layer_f25_kernel(const WnArgs p) {
     }
   };
   // ---- epilogue (modules.py:168-175)
-  const int t = t0 + l31;
-  if (t >= p.T) { dump(); return; }
+  if (te >= p.T) { dump(); return; }
   const float* mb = p.mask + (long long)b * p.mask_bs;
-  const float mk = mb[t];
-  const int row0 = pi * 32 + 4 * hi;
-  float* ob = p.out + (long long)b * p.out_bs + (long long)row0 * p.out_ld + t;
+  const float mk = mb[te];
+  float* ob = p.out + (long long)b * p.out_bs + (long long)row0 * p.out_ld + te;
   if (!LAST) {
     if (!kh) {         // x = (x + rs[:H]) * mask
-      const float* xr = p.x + (long long)b * p.x_bs + (long long)row0 * p.x_ld + t;
-      float* xw = p.xo + (long long)b * p.xo_bs + (long long)row0 * p.xo_ld + t;
-      float rv[16];
+      float* xw = p.xo + (long long)b * p.xo_bs + (long long)row0 * p.xo_ld + te;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rv[r] = xr[(long long)((r & 3) + 8 * (r >> 2)) * p.x_ld];
+      for (int r = 0; r < 16; ++r) xw[(long long)((r & 3) + 8 * (r >> 2)) * p.xo_ld] = (pre[r] + fin[r]) * mk;
+    } else {           // out += rs[H:]   (first layer: pre = 0)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xw[(long long)((r & 3) + 8 * (r >> 2)) * p.xo_ld] = (rv[r] + fin[r]) * mk;
-    } else {           // out += rs[H:]
-      float ov[16];
-      if (!p.first) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = p.first ? fin[r] : ov[r] + fin[r];
+      for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = p.first ? fin[r] : pre[r] + fin[r];
     }
   } else if (!kh) {    // last layer: out = (out + rs) * mask
-    float ov[16];
-    if (!p.first) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ov[r] = ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld];
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float v = p.first ? fin[r] : ov[r] + fin[r];
+      const float v = p.first ? fin[r] : pre[r] + fin[r];
       ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = v * mk;
     }
   }
@@ -913,7 +917,11 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
       // one row pair per workgroup, K split over its four waves: 42 + 84 workgroups with 240 / 24-MFMA chains at 1 x 200).
     if (wn_layer_prefers_unfused(B, T)) return 1;
   }
-  const int NR = ((long long)variant_batch(B) * ((T + 63) / 64) >= 2LL * ncu) ? 2 : 1;
+  // 64-column tiles (the six-wave direct-form kernel) once they still give every CU two workgroups - except where the Winograd F(2,5) layer
+  // kernel applies: it exists for 32-column tiles only and issues 3/5 of the in_layer's multiply-adds (round 5: long inputs such as 8 x 4096
+  // took the direct-form kernel here until then)
+  const bool f25_shape = wpf != nullptr && wn_f25_enabled() && H == 192 && in_l.ktaps == 5 && in_l.dil == 1 && rs_l.ksg_total == 24;
+  const int NR = (!f25_shape && (long long)variant_batch(B) * ((T + 63) / 64) >= 2LL * ncu) ? 2 : 1;
   const int NA = NR * 32;
   const int minoff = -in_l.pad, maxoff = (in_l.ktaps - 1) * in_l.dil - in_l.pad;
   a.xoff0 = minoff & ~3;

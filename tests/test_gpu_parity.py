@@ -795,6 +795,31 @@ def test_generator_mixed_dilation_orders_vs_oracle(M):
     check("generator mixed dilations", y, ref, 5e-5, 1e-4)
 
 
+@pytest.mark.parametrize("what", ["one_chain", "two_chains", "k5_resblocks"])
+def test_fallback_shapes(M, what):
+    """Paths that a SHAPE reaches and that, until round 5, were also behind environment switches (now removed with the A/B arms that only a
+    switch could reach): a Generator with ONE ResBlock chain per stage (everything on the caller's stream: no fork / join, no grouped launches;
+    was SVOC_STREAMS=0), one with TWO chains at a length where the grouped launches apply (the chains' last convolutions accumulate one by one:
+    the merged accumulate launch needs k = 3 / 7 / 11; was SVOC_W4_ACCUM=0), and ResBlocks with k = 5 at C = 64 / 32 (no Winograd form, and since
+    the generic fused kernel was deleted each iteration runs as two direct-form convolutions).  Against the oracle."""
+    cfg = {"one_chain": dict(rks=[7], rds=[[1, 3, 5]], B=3, T=300),
+           "two_chains": dict(rks=[3, 7], rds=[[1, 3, 5], [1, 3, 5]], B=8, T=1600),
+           "k5_resblocks": dict(rks=[5, 3], rds=[[1, 2, 4], [1, 3, 5]], B=2, T=160)}[what]
+    c = dict(initial_channel=32, resblock="1", rks=cfg["rks"], rds=cfg["rds"], ur=[4, 2, 2], uic=256, uks=[8, 4, 4], gin=0)
+    sd = sw.fill_state_dict(cases.generator_shapes(c), 7750 + len(what), 1.0)
+    m = load(M.models.Generator(c["initial_channel"], c["resblock"], c["rks"], c["rds"], c["ur"], c["uic"], c["uks"], gin_channels=0), sd)
+    x = T(cases.rnd(7751, "x", (cfg["B"], 32, cfg["T"]), 1.0))
+    M.native.stats_reset()
+    y = m(x.cuda())
+    st = M.native.stats_get()
+    with torch.no_grad():
+        ref = O.generator(sdT(sd), x, prefix="", resblock="1", resblock_kernel_sizes=c["rks"], resblock_dilation_sizes=c["rds"],
+                          upsample_rates=c["ur"], upsample_kernel_sizes=c["uks"])
+    check("generator " + what, y, ref, 5e-5, 1e-4)
+    if what == "two_chains":
+        assert st["executed_flops"] < 0.8 * st["conv_flops"], "the grouped Winograd launches did not run"
+
+
 def test_generator_winograd_upsamplers_vs_oracle(M):
     """Stride-8 and stride-2 upsamplers inside the decoder at a shape that passes the F(4,2) kernel's gate, with an input length
     that is NOT a multiple of four (row stride != length; the window tiles then carry the column q = L themselves) at the first

@@ -22,7 +22,7 @@ python $R/tools/pmc_traffic.py /tmp/pr /tmp/pw $NK 2 > $O/${TAG}_pmc_hbm_traffic
 
 
 ( cd $R && for k in 3 7 11; do python tools/wino4_timeline.py 128 $k 1; done; python tools/wino4_timeline.py 128 11 3; python tools/wino4_timeline.py 256 11 1; for k in 7 11; do WL=65536 python tools/wino4_timeline.py 64 $k 1; done; for k in 3 7 11; do WL=131072 python tools/wino4_timeline.py 32 $k 1; done; WL=131072 python tools/wino4_timeline.py 32 11 3 ) > $O/${TAG}_winograd_workgroup_stamps.txt 2>/dev/null
-( cd $R && for sh in "512 256 16 8 512" "256 128 16 8 4096" "128 64 4 2 32768" "64 32 4 2 65536"; do python tools/ct_timeline.py $sh; done; SVOC_CT_ROWS256=0 python tools/ct_timeline.py 512 256 16 8 512; SVOC_CT_ROWS256=0 python tools/ct_timeline.py 256 128 16 8 4096 ) > $O/${TAG}_upsampler_f42_workgroup_stamps.txt 2>/dev/null
+( cd $R && for sh in "512 256 16 8 512" "256 128 16 8 4096" "128 64 4 2 32768" "64 32 4 2 65536"; do python tools/ct_timeline.py $sh; done;  ) > $O/${TAG}_upsampler_f42_workgroup_stamps.txt 2>/dev/null
 ( cd $R && for v in 1 0; do SVOC_CT_WINO=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc 2>/dev/null | tail -1; done ) > $O/${TAG}_bench_upsamplers_f42_vs_direct.txt
 ( cd $R && python tools/wn_timeline.py 16 512 ) > $O/${TAG}_wn_layer_phase_stamps.txt 2>/dev/null
 ( cd $R && python tools/wino_bench.py 128 32768; python tools/wino_bench.py 64 65536; python tools/wino_bench.py 256 4096; python tools/wino_bench.py 32 131072 ) > $O/${TAG}_winograd_per_conv.txt 2>/dev/null
@@ -32,7 +32,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pi2 --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pmc --no-other-configs > /dev/null 2>&1
 python $R/tools/pmc_inst_mix.py /tmp/pi1 /tmp/pi2 > $O/${TAG}_pmc_instruction_mix.txt 2>&1
 ls -la $O
-( cd $R && SVOC_STREAMS=0 python tools/profile_infer.py 16 512 3 ) > $O/${TAG}_per_layer_event_profile_single_stream.txt 2>&1
+
 ( cd $R && python tools/profile_infer.py 1 200 5 ) > $O/${TAG}_per_layer_event_profile_1x200.txt 2>&1
 ( cd $R && BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 5 --warmup 2 ) > $O/${TAG}_bench_2ranks_gloo_one_gpu.json 2> $O/${TAG}_bench_2ranks_gloo_one_gpu.err
 ls -la $O
