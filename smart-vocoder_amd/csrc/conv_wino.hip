@@ -624,6 +624,8 @@ static bool wino_args(const PackedWino& pw, const ConvArgs& a, int B, int D, int
   const int W = wino_tile_w(D, WM);
   w.ntn = (a.Ncols + W - 1) / W; w.gy = (pw.mtiles + WM - 1) / WM; w.xcd = xcd_mapping_enabled();
   w.dbg = debug_stamp_buffer(); w.dbg_base = 0;
+  static const unsigned abl_env = getenv("SVOC_DBG_ABL") ? (unsigned)atoi(getenv("SVOC_DBG_ABL")) : 0u;      // diagnostics (tools/wino4_timeline.py): results are WRONG with it
+  w.abl = w.dbg ? abl_env : 0u;
   w.out_perm = 0;
   (void)B;
   return true;

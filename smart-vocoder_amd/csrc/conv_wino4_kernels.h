@@ -57,6 +57,10 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L;
+  // Stamped build only: work REMOVED for the power / clock ablations of round 5 (results are wrong; the stamps give the effective clock):
+  //   1 producers: no global loads behind the first    2 producers: no publish / transform behind stage 2 (barriers only)
+  //   4 consumers: no epilogue    8 consumers: every weight request re-reads the image's first 4 KB (no L2 -> CU weight traffic)
+  const unsigned abl = DBG ? p.abl : 0u;
   const int ntiles_all = vend - first;
   const int nch = p.nchunks;                               // 32-channel chunks
   const int nst = nch * HALVES / CPS;                      // stages per tile
@@ -196,6 +200,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       const int xs_start = xs0;
       const bool interior = xs_start >= 0 && xs_start + RAW <= L;
       const char* const xb = reinterpret_cast<const char*>(p.x + (long long)bz * p.x_bs);
+      if (!(DBG && (abl & 2u) && s_ > 2)) {
       // ---- publish own rows (lrelu, zero padding on edge tiles)
       if constexpr (PERM > 0) {
         if (interior) {
@@ -260,18 +265,21 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
           }
         }
       }
+      }
       // ---- request the next stage's raw rows (next chunk, or chunk 0 of this workgroup's next tile)
       int nti = ti, nchn = ch + 1, w0n = w0, bzn = bz, byn = by, xsn = xs0, ph0n = ph0, leadn = lead0;
       if (nchn == nst) { nchn = 0; ++nti; if (nti < my_tiles) { locate(v0 + nti * stride, w0n, bzn, byn); origin(w0n, xsn, ph0n, leadn); } }
-      if (s_ + 1 < nstages) issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= L, nchn);
+      if (s_ + 1 < nstages && !(abl & 1u)) issue(reinterpret_cast<const char*>(p.x + (long long)bzn * p.x_bs), xsn, xsn >= 0 && xsn + RAW <= L, nchn);
       // ---- transform own rows into plane set s & 1 (LDS operations of one wave execute in order: no barrier needed)
       float* const pb = pl + (NPS == 2 ? (s_ & 1) : pset) * PLF;
       if constexpr (NPS == 3) pset = pset == 2 ? 0 : pset + 1;
+      if (!(DBG && (abl & 2u) && s_ > 2)) {
 #pragma unroll
       for (int u = 0; u < TPW; ++u) {
         if (64 * (u + 1) <= NIW || lane < NIW - 64 * u) {
           w4_transform_window<Geo>(pb + tdst[u], D == 1 ? raw + tsrc[u] : raw + tsrc[u] + toff[u]);
         }
+      }
       }
       long long pb0 = 0;
       if constexpr (DBG) pb0 = (long long)__builtin_readcyclecounter();
@@ -299,6 +307,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   const unsigned wlane = (unsigned)lane * 16u;
   f32x16 M[NACC];
   float4 a[NSET][KGS];
+  const int wstep = (DBG && (abl & 8u)) ? 0 : 4096;        // ablation 8: the slot stride of the weight requests (0: the same 4 KB over and over, from the L1)
   // MFMA stream of one 32-channel chunk (chunk CC of the stage: plane rows 32 CC ..) or of half HF of a chunk (KS = 16): NSTEP steps of four MFMAs, fragment
   // reads two steps ahead in two register sets, the next weight slot's four float4 requested at the first step of each slot
   // Weights stream through buffer loads: descriptor base = packed image, SGPR offset = (row tile, chunk, slot), VGPR offset =
@@ -330,8 +339,13 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       constexpr int T = decltype(tc)::value;
       constexpr int WS = Geo::wslot(T), KG = Geo::kgi(T);
       if constexpr (Geo::slot_first(T)) {                 // request slot WS + PD (of this stage, else of the stage / tile that follows)
-        if constexpr (WS + PD < WSLOTS) wload4(a[(PAR + WS + PD) % NSET], wa + (WS + PD) * 4096, hf);
-        else if (wnext >= 0) wload4(a[(PAR + WS + PD) % NSET], wnext + (WS + PD - WSLOTS) * 4096, std::integral_constant<int, NHF>{});
+        if constexpr (DBG) {                                // ablation 8, branch-free (a branch per slot stretched the stream from 68 to 85 cycles per MFMA): every request re-reads slot 0
+          if constexpr (WS + PD < WSLOTS) wload4(a[(PAR + WS + PD) % NSET], wa + (WS + PD) * wstep, hf);
+          else if (wnext >= 0) wload4(a[(PAR + WS + PD) % NSET], wnext + (WS + PD - WSLOTS) * wstep, std::integral_constant<int, NHF>{});
+        } else {
+          if constexpr (WS + PD < WSLOTS) wload4(a[(PAR + WS + PD) % NSET], wa + (WS + PD) * 4096, hf);
+          else if (wnext >= 0) wload4(a[(PAR + WS + PD) % NSET], wnext + (WS + PD - WSLOTS) * 4096, std::integral_constant<int, NHF>{});
+        }
       }
       {
         float(&b)[4] = fb[T & 1];
@@ -350,7 +364,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     request(std::integral_constant<int, 1>{});
     wino_static_for<0, NSTEP>(step);
   };
-  auto wtile = [&](int mt_) -> int { return __builtin_amdgcn_readfirstlane(mt_ * nch * WSLOTS * 4096); };
+  auto wtile = [&](int mt_) -> int { return (DBG && (abl & 8u)) ? 0 : __builtin_amdgcn_readfirstlane(mt_ * nch * WSLOTS * 4096); };
   // byte offsets of this lane's first output (then + D, + 2D, + 3D) in rows 4 hi + i of a 32-row block.  D = 1: relative to the
   // tile's first column (fixed); D > 1: absolute column of window w0 + uu, recomputed per tile
   const unsigned ylb = (unsigned)p.y_ld * 4u, rlb = (unsigned)p.res_ld * 4u;
@@ -477,7 +491,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     // ---- output transform + epilogue: the lane owns y[row][ne + r D], r = 0..3, for its 16 accumulator rows, four at a time
     long long ce0 = 0;
     if constexpr (DBG) ce0 = (long long)__builtin_readcyclecounter();
-    if (lane_ok) {
+    if (lane_ok && !(DBG && (abl & 4u))) {
       auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
         constexpr int Q = decltype(q_c)::value;
 #pragma unroll

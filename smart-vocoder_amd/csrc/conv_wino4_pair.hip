@@ -29,11 +29,13 @@ struct PairMember {
   float* y; long long y_bs; int y_ld;                       // output
   const float* wp1; const float* bias1;                     // c1: F(4,3) (F44: k = 7 / 11 F(4,4)) image, bias
   const float* wp2; const float* bias2;                     // c2
+  unsigned eflags; float div;                               // accumulate form: F_ACC (y += ...) and F_DIV (... / div) of this member's epilogue
 };
 struct PairGroup { PairMember m[3]; int end[3]; int L; int B; int xcd; unsigned flags; float slope; };   // members k = 11, 7, 3; end[i] = first tile id behind member i
 // NRT = 1: C = 32 (1 x 4 consumers, 128 windows per tile); NRT = 2: C = 64 (2 x 2 consumers, 64 windows per tile, two 32-channel chunks)
 
-template <int K, int D1, int NRT, bool F44_ = false>
+// NW2CAP > 0: keep at most that many c2 windows per tile (the accumulate form gives the three members ONE tile space: the k = 11 member's count)
+template <int K, int D1, int NRT, bool F44_ = false, int NW2CAP = 0>
 struct PairGeo {
   static constexpr int KD = K == 3 ? 2 : 1;                 // 8 (C = 32) / 16 (C = 64) channels per stage for every member: four stages per phase
   static constexpr bool F44 = F44_ && K >= 7;               // k = 3 stays F(4,3)
@@ -44,7 +46,8 @@ struct PairGeo {
   static_assert(G1::KS == 8 * NRT && G2::KS == 8 * NRT && ROWS / KS == 4, "four stages per phase");
   static constexpr int NWC1 = (NWT / D1) * D1;              // c1 windows per tile: whole q blocks
   static constexpr int COLS1 = 4 * NWC1;                    // columns of the intermediate tile
-  static constexpr int NW2 = (COLS1 - 4 * D1 + 4 - G2::LEAD - SPAN) / 4 - G2::G + 2;   // c2 windows kept per tile
+  static constexpr int NW2OWN = (COLS1 - 4 * D1 + 4 - G2::LEAD - SPAN) / 4 - G2::G + 2;   // c2 windows this member could keep per tile
+  static constexpr int NW2 = (NW2CAP > 0 && NW2CAP < NW2OWN) ? NW2CAP : NW2OWN;          // c2 windows kept per tile
   static constexpr int NE2 = NW2 + G2::G - 1;               // c2 plane entries needed
   static constexpr int W2 = 4 * NW2;                        // tile step in output columns
   static constexpr int MIDS = COLS1;                        // row stride of the intermediate tile
@@ -327,6 +330,313 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_pair_kernel(const PairGroup
   pair_member<3, D1, NRT, F44>(g.m[2], g, g.end[1], g.end[2], b, G_);
 }
 
+// ------------------------------------------------------------------------------------------------ the accumulate form (round 5)
+// The LAST step of the C = 32 MRF stage (reference models.py:149-155: xs = sum of the three chains' ResBlocks, x = xs / 3): c1 (dilation D1) -> c2
+// of the three chains AND the sum over the chains in ONE launch.  TILE-major: a workgroup runs the k = 11, k = 7 and k = 3 pairs of one tile back to
+// back - the members share ONE tile space (the k = 11 member's c2 windows per tile, PairGeo's NW2CAP) and one output tensor: the k = 11 member writes
+// y = c2 + x_11, the k = 7 member adds its c2 + x_7 to what that very lane stored a few microseconds earlier (program order; the tile is still in the
+// L2), the k = 3 member adds, divides and stores.  Against the window-major c1 launch + the merged accumulate launch (conv_wino4_acc.hip): c1's three
+// stores and c2's three global staging passes are gone - HBM sees three inputs and one output (member-major, the first version: the read-modify-write
+// went through HBM, 1217 against 1239 us).  F(4,4) images for k = 7 / 11, F(4,3) for k = 3 (each member keeps its own form: no shared accumulators).
+template <class T> struct PairTag { using type = T; };
+template <int K, int D1, bool F44>
+struct PairAccT {
+  using PG = PairGeo<K, D1, 1, F44, PairGeo<11, D1, 1, F44>::NW2OWN>;
+  using G1 = typename PG::G1;
+  using G2 = typename PG::G2;
+  static constexpr int KS = PG::KS, RPW = KS / 4, RAW1 = G1::RAW, R4 = RAW1 / 4, NGW = RPW * R4, SPW = (NGW + 63) / 64;
+  static constexpr int NE1 = G1::NE, NIW1 = RPW * NE1, TPW1 = (NIW1 + 63) / 64, PQ1 = G1::PQ;
+  static constexpr int NE2 = PG::NE2, NIW2 = RPW * NE2, TPW2 = (NIW2 + 63) / 64, PQ2 = G2::PQ;
+};
+// tile (batch element bz, first c2 output column n2) as member K sees it: origin m0 of its c1 / intermediate tile, offset of c2's raw origin in it,
+// c1's first raw column xs1 (a multiple of four) and the raw index lead1 of window 0's first sample
+template <class T>
+__device__ __forceinline__ void pairacc_origin(const int n2, int& m0, int& off2, int& xs1, int& lead1) {
+  constexpr int D1 = T::G1::DIL;
+  const int xs2 = n2 + T::G2::XOFF;
+  const int b0 = (xs2 + 4 * D1 * 4) / (4 * D1) - 4;
+  m0 = 4 * D1 * b0;
+  off2 = xs2 - m0;
+  const int f0 = m0 - T::G1::PADT * D1;
+  xs1 = f0 & ~3;
+  lead1 = f0 - xs1;
+}
+template <class T>
+__device__ __forceinline__ void pairacc_issue(float4 (&v)[T::SPW], const PairMember& pm, const int L, const int bz, const int xs, const int ch, const int lane, const int pw_) {
+  const long long ldb = (long long)pm.x_ld * 4;
+  const float* const xb = pm.x + (long long)bz * pm.x_bs;
+  const int so = ch * T::KS * (int)ldb;
+  const bool interior = xs >= 0 && xs + T::RAW1 <= L;
+  int l_ = lane;
+  asm volatile("" : "+v"(l_));                              // keeps the per-lane address arithmetic inside the call (conv_wino4_acc.hip)
+#pragma unroll
+  for (int u = 0; u < T::SPW; ++u) {
+    const int it = min(l_ + 64 * u, T::NGW - 1);
+    const int row = T::RPW * pw_ + it / T::R4, tg = xs + 4 * (it % T::R4);
+    v[u] = w4_load16(xb, (unsigned)(row * pm.x_ld + ((interior || (tg >= 0 && tg + 3 < L)) ? tg : 0)) * 4u, so);
+  }
+}
+// one member of one tile, producer side: c1's four stages from global (v holds stage 0's rows on entry), then - behind the consumers' hand-over
+// barrier - c2's four stages from the intermediate tile; next(): requests whatever follows this member's c1 (the next member's, or the next tile's, first rows)
+template <class T, class Next>
+__device__ __forceinline__ void pairacc_produce(const PairMember& pm, const PairGroup& g, float4 (&v)[T::SPW], float* const mid, float* const pl, const int PLFMAX,
+                                                const int bz, const int n2, int& s_, const int lane, const int pw_, Next&& next) {
+  using G1 = typename T::G1;
+  using G2 = typename T::G2;
+  constexpr int D1 = G1::DIL, RPW = T::RPW, RAW1 = T::RAW1, R4 = T::R4, NGW = T::NGW, SPW = T::SPW, NE1 = T::NE1, NIW1 = T::NIW1, TPW1 = T::TPW1, PQ1 = T::PQ1;
+  constexpr int NE2 = T::NE2, NIW2 = T::NIW2, TPW2 = T::TPW2, PQ2 = T::PQ2, MIDS = T::PG::MIDS, KS = T::KS;
+  float* const raw = mid;
+  const int L = g.L;
+  const float slope = g.slope;
+  int m0, off2, xs1, lead1;
+  pairacc_origin<T>(n2, m0, off2, xs1, lead1);
+  const bool interior = xs1 >= 0 && xs1 + RAW1 <= L;
+  int l_ = lane;
+  asm volatile("" : "+v"(l_));
+  float* rdst[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {
+    const int it = min(l_ + 64 * u, NGW - 1);
+    rdst[u] = raw + (RPW * pw_ + it / R4) * RAW1 + 4 * (it % R4);
+  }
+  int t1off[TPW1], t1dst[TPW1];
+#pragma unroll
+  for (int u = 0; u < TPW1; ++u) {
+    const int it = min(l_ + 64 * u, NIW1 - 1);
+    const int row = RPW * pw_ + it / NE1, e = it % NE1;
+    const int qe = e / D1, pe = e - qe * D1;
+    t1off[u] = row * RAW1 + 4 * D1 * qe + pe;
+    t1dst[u] = row * PQ1 + e;
+    asm volatile("" : "+v"(t1off[u]), "+v"(t1dst[u]));
+  }
+  // ---------------- phase A: c1's four stages (8 channels each) from global
+  for (int ch = 0; ch < 4; ++ch) {
+#pragma unroll
+    for (int u = 0; u < SPW; ++u) {
+      if (64 * (u + 1) <= NGW || lane < NGW - 64 * u) {
+        float4 q = v[u];
+        if (!interior) {                                     // L is a multiple of four: a 16-byte group is inside the row or padding
+          const int tg = xs1 + 4 * ((l_ + 64 * u) % R4);
+          if (tg < 0 || tg + 3 >= L) q = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        wino_lrelu4(q, slope);
+        *reinterpret_cast<float4*>(rdst[u]) = q;
+      }
+    }
+    if (ch + 1 < 4) pairacc_issue<T>(v, pm, L, bz, xs1, ch + 1, lane, pw_);
+    float* const pb = pl + s_ * PLFMAX;
+#pragma unroll
+    for (int u = 0; u < TPW1; ++u) {
+      if (64 * (u + 1) <= NIW1 || lane < NIW1 - 64 * u) {
+        const float* r = raw + t1off[u] + lead1;
+        w4_transform_window<G1>(pb + t1dst[u], D1 == 1 ? r - G1::LEAD : r);
+      }
+    }
+    __syncthreads();                                         // B_s: plane set complete
+    s_ ^= 1;
+  }
+  __syncthreads();                                           // X: the consumers have written the rows of c2's first stage into the intermediate tile
+  next();
+  // ---------------- phase B: c2's four stages from the intermediate tile
+  int t2src[TPW2], t2dst[TPW2];
+#pragma unroll
+  for (int u = 0; u < TPW2; ++u) {
+    const int it = min(l_ + 64 * u, NIW2 - 1);
+    const int row = RPW * pw_ + it / NE2, e = it % NE2;
+    t2src[u] = row * MIDS + 4 * e;
+    t2dst[u] = row * PQ2 + e;
+    asm volatile("" : "+v"(t2src[u]), "+v"(t2dst[u]));
+  }
+  for (int ch = 0; ch < 4; ++ch) {
+    float* const pb = pl + s_ * PLFMAX;
+    const float* const mrow = mid + ch * KS * MIDS + off2;
+#pragma unroll
+    for (int u = 0; u < TPW2; ++u) {
+      if (64 * (u + 1) <= NIW2 || lane < NIW2 - 64 * u) w4_transform_window<G2>(pb + t2dst[u], mrow + t2src[u]);
+    }
+    __syncthreads();
+    s_ ^= 1;
+  }
+}
+// one member of one tile, consumer side
+template <class T>
+__device__ __forceinline__ void pairacc_consume(const PairMember& pm, const PairGroup& g, float* const mid, const unsigned plbase, const int PLFMAX, const int bz,
+                                                const int n2, int& s_, const int lane, const int wave) {
+  using PG = typename T::PG;
+  using G1 = typename T::G1;
+  using G2 = typename T::G2;
+  constexpr int D1 = G1::DIL, NACC = G1::NACC, NWC1 = PG::NWC1, NW2 = PG::NW2, MIDS = PG::MIDS;
+  const int L = g.L;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int uu = wave * 32 + l31;                           // this lane's window of the tile (1 x 4 consumers)
+  const unsigned wlane = (unsigned)lane * 16u;
+  int m0, off2, xs1, lead1;
+  pairacc_origin<T>(n2, m0, off2, xs1, lead1);
+  f32x16 M[NACC];
+  WinoArgs p1{}, p2{};
+  p1.wp = pm.wp1; p1.nchunks = 1;
+  p2.wp = pm.wp2; p2.nchunks = 1;
+  const float slope = g.slope;
+  auto init_bias = [&](const float* bias) {                 // the bias starts in M1 (part of all four outputs)
+    const float* bq = bias + 4 * hi;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) M[q][i] = q == 1 ? bq[(i & 3) + 8 * (i >> 2)] : 0.f;
+  };
+  auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
+    constexpr int Q = decltype(q_c)::value;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<G1, NACC>(M, 4 * Q + r);
+  };
+  // ---------------- phase A: c1 into the accumulators, lrelu(c1) -> the intermediate tile (zero outside [0, L))
+  init_bias(pm.bias1);
+  acc3_consume<G1, NACC, 2>(p1, M, plbase, PLFMAX, 0, s_, wlane, (unsigned)(hi * G1::PQ + uu) * 4u);
+  {
+    const bool act = uu < NWC1;
+    const int bq = uu / D1, ph = uu - bq * D1;
+    const int c0 = 4 * D1 * bq + ph;
+    const int n0 = m0 + c0;
+    auto quarter = [&](auto q_c) {
+      constexpr int Q = decltype(q_c)::value;
+      if (!act) return;
+      float4 vo[4];
+      ytrans(q_c, vo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wino_lrelu4(vo[r], slope);
+        float* d = mid + (8 * Q + 4 * hi + r) * MIDS + c0;
+        if constexpr (D1 == 1) {
+          if (n0 < 0 || n0 >= L) vo[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(d) = vo[r];
+        } else {
+          d[0] = (n0 >= 0 && n0 < L) ? vo[r].x : 0.f;
+          d[D1] = (n0 + D1 >= 0 && n0 + D1 < L) ? vo[r].y : 0.f;
+          d[2 * D1] = (n0 + 2 * D1 >= 0 && n0 + 2 * D1 < L) ? vo[r].z : 0.f;
+          d[3 * D1] = (n0 + 3 * D1 >= 0 && n0 + 3 * D1 < L) ? vo[r].w : 0.f;
+        }
+      }
+    };
+    quarter(std::integral_constant<int, 0>{});
+    __syncthreads();                                         // X: rows 0 .. 7 (c2's first stage) are in the intermediate tile (conv_wino4_pair.hip's hand-over)
+    quarter(std::integral_constant<int, 1>{});
+    quarter(std::integral_constant<int, 2>{});
+    quarter(std::integral_constant<int, 3>{});
+  }
+  // ---------------- phase B: c2, then + x (+ what the previous member stored) (/ div) and store
+  init_bias(pm.bias2);
+  acc3_consume<G2, NACC, 2>(p2, M, plbase, PLFMAX, 0, s_, wlane, (unsigned)(hi * G2::PQ + uu) * 4u);
+  const int ne = n2 + 4 * uu;
+  if (uu < NW2 && ne < L) {
+    char* const ybase = reinterpret_cast<char*>(pm.y + (long long)bz * pm.y_bs + (long long)(4 * hi) * pm.y_ld + ne);
+    const char* const rbase = reinterpret_cast<const char*>(pm.x + (long long)bz * pm.x_bs + (long long)(4 * hi) * pm.x_ld + ne);
+    const size_t ylb = (size_t)pm.y_ld * 4, rlb = (size_t)pm.x_ld * 4;
+    const bool eacc = (pm.eflags & F_ACC) != 0, ediv = (pm.eflags & F_DIV) != 0;
+    const float dv = pm.div, rc = 1.0f / dv;
+    auto dv1 = [&](float x) { const float q = x * rc; return __builtin_fmaf(__builtin_fmaf(-q, dv, x), rc, q); };      // x / div (conv_wino4_kernels.h)
+    auto quarter = [&](auto q_c) {
+      constexpr int Q = decltype(q_c)::value;
+      float4 rv[4], vo[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * Q + r) * rlb);
+      if (eacc) {                                            // what this lane stored one member earlier
+        float4 yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[r] = *reinterpret_cast<const float4*>(ybase + (size_t)(8 * Q + r) * ylb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rv[r].x += yv[r].x; rv[r].y += yv[r].y; rv[r].z += yv[r].z; rv[r].w += yv[r].w; }
+      }
+      ytrans(q_c, vo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w;
+        if (ediv) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
+        *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q + r) * ylb) = vo[r];
+      }
+    };
+    quarter(std::integral_constant<int, 0>{});
+    quarter(std::integral_constant<int, 1>{});
+    quarter(std::integral_constant<int, 2>{});
+    quarter(std::integral_constant<int, 3>{});
+  }
+}
+
+template <int D1, bool F44>
+__global__ void __launch_bounds__(512, 2) conv_wino4_pairacc_kernel(const PairGroup g) {
+  using T11 = PairAccT<11, D1, F44>;
+  using T7 = PairAccT<7, D1, F44>;
+  using T3 = PairAccT<3, D1, F44>;
+  constexpr int W2 = T11::PG::W2;
+  static_assert(T7::PG::W2 == W2 && T3::PG::W2 == W2, "one tile space");
+  constexpr int MIDF = T11::PG::MID_FLOATS;
+  static_assert(T7::PG::MID_FLOATS == MIDF && T3::PG::MID_FLOATS == MIDF, "one intermediate tile");
+  constexpr int PLFMAX = T11::PG::cmax(T11::PG::PLFMAX, T11::PG::cmax(T7::PG::PLFMAX, T3::PG::PLFMAX));
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  float* const mid = wl;
+  float* const pl = wl + MIDF;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = g.end[0], stride = gridDim.x, v0 = blockIdx.x;
+  if (v0 >= total) return;
+  const int my_tiles = (total - v0 + stride - 1) / stride;
+  const int L = g.L;
+  const int ntn = (L + W2 - 1) / W2;
+  auto locate = [&](int v, int& bz_, int& n2_) {
+    const int tl = xcd_linear(v, total, g.xcd);
+    bz_ = tl / ntn;
+    n2_ = (tl - bz_ * ntn) * W2;
+  };
+  int s_ = 0;
+  if (wave >= 4) {
+    const int pw_ = wave - 4;
+    __builtin_amdgcn_s_setprio(3);
+    float4 v11[T11::SPW], v7[T7::SPW], v3[T3::SPW];
+    int bz, n2;
+    locate(v0, bz, n2);
+    auto first_rows = [&](auto tc, auto& v, const PairMember& pm, int bz_, int n2_) {
+      using T = typename decltype(tc)::type;
+      int m0, off2, xs1, lead1;
+      pairacc_origin<T>(n2_, m0, off2, xs1, lead1);
+      pairacc_issue<T>(v, pm, L, bz_, xs1, 0, lane, pw_);
+    };
+    first_rows(PairTag<T11>{}, v11, g.m[0], bz, n2);
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      int bzn = bz, n2n = n2;
+      const bool more = ti + 1 < my_tiles;
+      if (more) locate(v0 + (ti + 1) * stride, bzn, n2n);
+      pairacc_produce<T11>(g.m[0], g, v11, mid, pl, PLFMAX, bz, n2, s_, lane, pw_, [&]() { first_rows(PairTag<T7>{}, v7, g.m[1], bz, n2); });
+      pairacc_produce<T7>(g.m[1], g, v7, mid, pl, PLFMAX, bz, n2, s_, lane, pw_, [&]() { first_rows(PairTag<T3>{}, v3, g.m[2], bz, n2); });
+      pairacc_produce<T3>(g.m[2], g, v3, mid, pl, PLFMAX, bz, n2, s_, lane, pw_, [&]() { if (more) first_rows(PairTag<T11>{}, v11, g.m[0], bzn, n2n); });
+      bz = bzn; n2 = n2n;
+    }
+    return;
+  }
+  const unsigned plbase = (unsigned)(size_t)pl;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int bz, n2;
+    locate(v0 + ti * stride, bz, n2);
+    pairacc_consume<T11>(g.m[0], g, mid, plbase, PLFMAX, bz, n2, s_, lane, wave);
+    pairacc_consume<T7>(g.m[1], g, mid, plbase, PLFMAX, bz, n2, s_, lane, wave);
+    pairacc_consume<T3>(g.m[2], g, mid, plbase, PLFMAX, bz, n2, s_, lane, wave);
+  }
+}
+template <int D1, bool F44>
+static int pairacc_launch_d(PairGroup& g, hipStream_t st) {
+  using T11 = PairAccT<11, D1, F44>;
+  constexpr int PLFMAX = T11::PG::cmax(T11::PG::PLFMAX, T11::PG::cmax(PairAccT<7, D1, F44>::PG::PLFMAX, PairAccT<3, D1, F44>::PG::PLFMAX));
+  constexpr int lds = (T11::PG::MID_FLOATS + 2 * PLFMAX) * 4;
+  static_assert(lds <= 160 * 1024, "tile does not fit");
+  const long long total = (long long)((g.L + T11::PG::W2 - 1) / T11::PG::W2) * g.B;
+  if (total > 0x7fffffffLL) return 1;
+  g.end[0] = g.end[1] = g.end[2] = (int)total;
+  auto kern = conv_wino4_pairacc_kernel<D1, F44>;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, st, g);
+  return SVOC_OK;
+}
+
 template <int D1, int NRT, bool F44>
 static int pair_launch_d(PairGroup& g, hipStream_t st) {
   using P11 = PairGeo<11, D1, NRT, F44>;
@@ -353,22 +663,23 @@ bool wino4_pair_enabled() {
 bool wino44_enabled();
 long long wino4_pair_tiles(int C, int L, int B, int D1) {
   const int w = wino44_enabled()
-                    ? (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1, true>::W2 : (D1 == 3 ? PairGeo<11, 3, 1, true>::W2 : PairGeo<11, 5, 1, true>::W2))
-                               : (D1 == 1 ? PairGeo<11, 1, 2, true>::W2 : (D1 == 3 ? PairGeo<11, 3, 2, true>::W2 : PairGeo<11, 5, 2, true>::W2)))
-                    : (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1>::W2 : (D1 == 3 ? PairGeo<11, 3, 1>::W2 : PairGeo<11, 5, 1>::W2))
-                               : (D1 == 1 ? PairGeo<11, 1, 2>::W2 : (D1 == 3 ? PairGeo<11, 3, 2>::W2 : PairGeo<11, 5, 2>::W2)));
+                    ? (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1, true>::W2 : (D1 == 3 ? PairGeo<11, 3, 1, true>::W2 : PairGeo<11, 5, 1, true>::W2)) : PairGeo<11, 1, 2, true>::W2)
+                    : (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1>::W2 : (D1 == 3 ? PairGeo<11, 3, 1>::W2 : PairGeo<11, 5, 1>::W2)) : PairGeo<11, 1, 2>::W2);
   return 3LL * B * ((L + w - 1) / w);
 }
 // The three chains' c1 (dilation D1) -> c2 pairs of one MRF step at C = 32 / 64; members k = 11, 7, 3.  1 = not eligible.
+// accum: the accumulate form (C = 32, F(4,4) images): every y[i] is the SAME tensor, written by the k = 11 member, read-modified-written by the k = 7
+// and k = 3 members, the last one dividing by `div` (the number of chains)
 int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2, const float* const* x, float* const* y, long long bs, int ld,
-                      int B, int L, int D1, float slope, hipStream_t st) {
+                      int B, int L, int D1, float slope, hipStream_t st, int accum, float div) {
   if (!wino4_pair_enabled() || B <= 0 || (L & 3) || (ld & 3) || (bs & 3) || !(D1 == 1 || D1 == 3 || D1 == 5)) return 1;
+  if (accum && (!wino44_enabled() || y[0] != y[1] || y[1] != y[2] || !(div > 0.f))) return 1;
   if (64LL * ld * 4 >= (1LL << 31)) return 1;               // the producers' staging loads: 32-bit offsets within one batch element
   static const int ks[3] = {11, 7, 3};
   const int C = pw1[0] ? pw1[0]->Cin : 0;
   // C = 64 (64-window tiles: the halo costs more lanes): measured -97 us for the d = 1 pair, -8 us for the d = 3 pair (c2 keeps 57 of 64
   // windows there) - only the first is taken
-  if (!(C == 32 || (C == 64 && D1 == 1))) return 1;
+  if (!(C == 32 || (C == 64 && D1 == 1 && !accum))) return 1;
   PairGroup g{};
   double flops = 0, exec = 0;
   for (int i = 0; i < 3; ++i) {
@@ -379,6 +690,9 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
     g.m[i].y = y[i]; g.m[i].y_bs = bs; g.m[i].y_ld = ld;
     g.m[i].wp1 = pw1[i]->wp4.f(); g.m[i].bias1 = pw1[i]->bias.f();
     g.m[i].wp2 = pw2[i]->wp4.f(); g.m[i].bias2 = pw2[i]->bias.f();
+    g.m[i].eflags = accum ? (i == 0 ? 0u : (i == 1 ? (unsigned)F_ACC : (unsigned)(F_ACC | F_DIV))) : 0u;
+    g.m[i].div = div;
+    if (accum && x[i] == y[i]) return 1;                    // never in place: neighbouring tiles read the input's halo
     const double f = (pw1[i]->flops_per_col + pw2[i]->flops_per_col) * (double)B * (double)L;
     const int G = (ks[i] + 1) / 4;
     flops += f;
@@ -392,12 +706,13 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
-    snprintf(d, sizeof(d), "wino4P Ci%-4d Co%-4d k11/7/3 c1(d%d)+c2 N%-7d B%-3d%s", C, C, D1, L, B, wino44_enabled() ? " F(4,4)" : "");
+    snprintf(d, sizeof(d), "wino4P Ci%-4d Co%-4d k11/7/3 c1(d%d)+c2%s N%-7d B%-3d%s", C, C, D1, accum ? " accumulate" : "", L, B, wino44_enabled() ? " F(4,4)" : "");
     prof_idx = prof_begin(st, d, flops);
   }
 #define SVOC_W4P(F) (C == 32 ? (D1 == 1 ? pair_launch_d<1, 1, F>(g, st) : (D1 == 3 ? pair_launch_d<3, 1, F>(g, st) : pair_launch_d<5, 1, F>(g, st))) \
-                             : (D1 == 1 ? pair_launch_d<1, 2, F>(g, st) : (D1 == 3 ? pair_launch_d<3, 2, F>(g, st) : pair_launch_d<5, 2, F>(g, st))))
-  const int rc = wino44_enabled() ? SVOC_W4P(true) : SVOC_W4P(false);
+                             : pair_launch_d<1, 2, F>(g, st))
+  const int rc = accum ? (D1 == 1 ? pairacc_launch_d<1, true>(g, st) : (D1 == 3 ? pairacc_launch_d<3, true>(g, st) : pairacc_launch_d<5, true>(g, st)))
+                       : (wino44_enabled() ? SVOC_W4P(true) : SVOC_W4P(false));
 #undef SVOC_W4P
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;

@@ -551,6 +551,23 @@ struct Generator {
           continue;
         }
       }
+      // C = 32, the LAST step (round 5): c1 -> c2 of the three chains AND the sum over the chains in ONE launch - the pair kernel's accumulate form
+      // (xs = (rb_11 + rb_7 + rb_3) / 3 built in place by the workgroup that owns the tile; replaces the window-major c1 launch + the merged accumulate launch)
+      if (C == 32 && nk == 3 && last && wino4_pair_enabled() &&
+          wino4_pair_tiles(C, L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= 2LL * device_cu_count()) {
+        const PackedWino* p1[3]; const PackedWino* p2[3];
+        const float* xi[3]; float* yo[3];
+        for (int q = 0; q < nk; ++q) {
+          const int j = order[q];
+          p1[q] = rbs[stage * nk + j]->w1[it].get();
+          p2[q] = rbs[stage * nk + j]->w2[it].get();
+          xi[q] = cur[j];
+          yo[q] = XS;
+        }
+        const int rp = launch_wino4_pair(p1, p2, xi, yo, bs, ld, B, L, rbs[stage * nk]->c1[it]->dil, 0.1f, st, 1, (float)nk);
+        if (rp < 0) return rp;
+        if (rp == 0) continue;
+      }
       bool all_w = true, all_w2 = true;
       const PackedConv* pcs2[3];
       const PackedWino* pws2[3];

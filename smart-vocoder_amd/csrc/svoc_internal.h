@@ -197,7 +197,7 @@ bool wino4_c32_enabled();
 bool wino4_pair_enabled();
 long long wino4_pair_tiles(int C, int L, int B, int D1);
 int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2, const float* const* x, float* const* y, long long bs, int ld,
-                      int B, int L, int D1, float slope, hipStream_t st);
+                      int B, int L, int D1, float slope, hipStream_t st, int accum = 0, float div = 1.0f);
 
 // convt_wino.hip: Winograd F(4,2) form of the polyphase transposed convolution (upsamplers k = 2 s: s = 8 or 2)
 struct PackedCtWino {

@@ -19,6 +19,7 @@ struct WinoArgs {
   int ntn; int gy; int xcd;                                         // column tiles per row, row blocks, XCD-aware order
   long long* dbg; int dbg_base;                                     // optional [workgroups][16] stamps (svoc_debug_set_stamp_buffer)
   int out_perm;                                                     // F(4,3), dilation > 1: write rows window-major (conv_wino4.hip)
+  unsigned abl;                                                     // stamped build only (SVOC_DBG_ABL): work removed for power / clock ablations (conv_wino4_kernels.h)
 };
 struct WinoGroup { WinoArgs a[3]; int end[3]; int k[3]; };
 

@@ -29,7 +29,8 @@ __device__ __forceinline__ long long wall100() { return (long long)__builtin_amd
 
 // PROD: 0 = four waves (one consumer per SIMD); otherwise four more waves beside them, as the kernels' producers:
 //   bit 0: packed-fp32 VALU work + LDS stores at about the producers' duty (32 VALU + 8 ds_write_b64 per ~2000 cycles),
-//   bit 1: HBM streaming: one 16-byte load per lane per ~700 cycles from a 4 GB buffer (~3 TB/s over the chip), consumed by a VALU add
+//   bit 1: HBM reads: one 16-byte load per lane per ~800 cycles, every wave walking its own contiguous 4 MB of a 4 GB buffer (~2.5 TB/s over the chip),
+//   bit 2: HBM reads + writes (what was read is written to the other half of the chunk)
 template <int MODE, int PROD = 0>
 __global__ void __launch_bounds__(PROD ? 512 : 256) probe(long long* out, const float* __restrict__ wimg, int iters, const float4* __restrict__ big = nullptr,
                                                        long long big_n = 0) {
@@ -50,9 +51,14 @@ __global__ void __launch_bounds__(PROD ? 512 : 256) probe(long long* out, const 
       for (int j = 0; j < 8; ++j) v[j] = (f32x2){0.5f + j + tid * 1e-6f, 0.25f + j};
       const f32x2 ka = {1.0001f, 0.9999f}, kb = {1e-7f, -1e-7f};
       float* pw = sm + 16384 + (wave - 4) * 1024 + lane * 2;
-      long long gi = ((long long)blockIdx.x * 4 + (wave - 4)) * 64 + lane;
-      const long long gstride = 256LL * 4 * 64;
-      float4 ld[4] = {};
+      // HBM streaming: every producer wave walks its own contiguous chunk of the buffer (sequential 1 KB wave-loads: no TLB thrash), eight loads
+      // in flight; bit 2 of PROD: it also WRITES 1 KB per iteration to the second half of its chunk
+      const long long chunk = big_n / (256LL * 4);                       // float4 per wave
+      const float4* gsrc = big + ((long long)blockIdx.x * 4 + (wave - 4)) * chunk;
+      float4* gdst = const_cast<float4*>(gsrc) + chunk / 2;
+      const long long span = (PROD & 4) ? chunk / 2 : chunk;
+      long long gi = lane;
+      float4 ld[8] = {};
       long long n = 0;
       while (*flag == 0) {
         if constexpr (PROD & 1) {
@@ -64,12 +70,13 @@ __global__ void __launch_bounds__(PROD ? 512 : 256) probe(long long* out, const 
             *reinterpret_cast<f32x2*>(pw + 128 * r + 512) = v[r + 4];
           }
         }
-        if constexpr (PROD & 2) {
-          ld[n & 3] = big[gi];
-          gi += gstride; if (gi >= big_n) gi -= big_n;
-          const float4 q = ld[(n + 1) & 3];                 // consumed three iterations later
-          v[0].x += q.x + q.y + q.z + q.w;
-          __builtin_amdgcn_s_sleep(PROD & 1 ? 6 : 9);
+        if constexpr (PROD & 6) {
+          ld[n & 7] = gsrc[gi];
+          const float4 q = ld[(n + 1) & 7];                 // consumed seven iterations later
+          if constexpr (PROD & 4) gdst[gi] = q;
+          else v[0].x += q.x + q.y + q.z + q.w;
+          gi += 64; if (gi >= span) gi = lane;
+          __builtin_amdgcn_s_sleep(PROD & 1 ? 8 : 11);
         } else {
           __builtin_amdgcn_s_sleep(28);
         }
@@ -192,7 +199,7 @@ static void run(const char* name, long long* out, const float* wimg, int iters) 
   printf("%-76s %6.1f cycles / MFMA   clock %.3f GHz (workgroups %.3f .. %.3f)   %6.1f TFLOP/s   %.1f ms", name, per, ghz, cmin, cmax,
          256.0 * 4 * 64.0 * iters * 4096.0 / secs / 1e12, secs * 1e3);
   if (PROD) printf("   producers: %.0f iterations per wave%s", pit / 256.0, (PROD & 2) ? "" : "");
-  if (PROD & 2) printf(", %.2f TB/s streamed", pit * 4 * 1024.0 / secs / 1e12);
+  if (PROD & 6) printf(", %.2f TB/s read%s", pit * 4 * 1024.0 / secs / 1e12, (PROD & 4) ? " + as much written" : "");
   printf("\n");
 }
 
@@ -204,6 +211,12 @@ int main() {
   for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (float)((int)(s >> 9) - (1 << 22)) * (1.0f / (1 << 22)); }
   (void)hipMemcpy(wimg, hw.data(), 2 << 20, hipMemcpyHostToDevice);
   const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 60000;      // 60000 x 64 MFMAs x 64 cycles = 246 M cycles ~ 100 ms
+  const int only = getenv("ONLY") ? atoi(getenv("ONLY")) : -1;
+  if (only == 6) {
+    g_big_n = (64LL << 20) / 16; (void)hipMalloc(&g_big, 64LL << 20);
+    run<4, 1>("6 = 4 + four producer waves: packed VALU + LDS stores", out, wimg, iters);
+    return 0;
+  }
   printf("one wave per SIMD on 256 CUs, %d x 64 dependent-by-four v_mfma_f32_32x32x2_f32 per wave\n", iters);
   run<0>("0 constant operands (registers)", out, wimg, iters);
   run<1>("1 changing operands, registers only", out, wimg, iters);
@@ -216,9 +229,10 @@ int main() {
   if (hipMalloc(&g_big, 4LL << 30) == hipSuccess) {
     (void)hipMemset(g_big, 0, 4LL << 30);
     run<4, 1>("6 = 4 + four producer waves: packed VALU + LDS stores", out, wimg, iters);
-    run<4, 2>("7 = 4 + four producer waves: HBM streaming", out, wimg, iters);
-    run<4, 3>("8 = 4 + four producer waves: VALU + LDS stores + HBM streaming", out, wimg, iters);
-    run<1, 2>("9 = 1 (registers only) + four producer waves: HBM streaming", out, wimg, iters);
+    run<4, 2>("7 = 4 + four producer waves: HBM reads", out, wimg, iters);
+    run<4, 4>("8 = 4 + four producer waves: HBM reads + writes", out, wimg, iters);
+    run<4, 5>("9 = 4 + four producer waves: VALU + LDS stores + HBM reads + writes", out, wimg, iters);
+    run<1, 4>("10 = 1 (registers only) + four producer waves: HBM reads + writes", out, wimg, iters);
     run<4>("4 again", out, wimg, iters);
   }
   return 0;

@@ -31,7 +31,7 @@ def bench(name, fn, nbytes, n=20, flops=0):
     extra = f"  {flops / ms * 1e-9:6.1f} TFLOP/s (MFMA-bound op)" if flops else ""
     print(f"{name:58s} {ms * 1e3:9.1f} us  {nbytes / ms * 1e-6:8.1f} GB/s ({nbytes / ms * 1e-6 / 8000 * 100:4.1f} % of 8 TB/s){extra}", flush=True)
 
-print(f"# B={B} T={T}; SVOC_LN_V2={os.environ.get('SVOC_LN_V2', '1')} (0 = the scalar round-1 kernels)")
+print(f"# B={B} T={T}")
 C = 192
 x = torch.randn(B, C, T, generator=g).to(dev); mask = torch.ones(B, 1, T, device=dev)
 ct = B * C * T * 4
