@@ -39,6 +39,7 @@ struct WNStack {
   std::vector<std::unique_ptr<DevBuf>> rs16;              // res_skip layers 0 .. NL-2 as 16x16x4 A operands (wn_small.hip: short inputs)
   std::unique_ptr<PackedConv> cond;
   DevBuf ws;
+  DevBuf stack_ws;                                          // wn_stack.hip: halo buffer + per-tile layer counters + error word
 
   int create(int hidden, int k, int dr, int nl, int gin_, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
     if (hidden <= 0 || k <= 0 || (k % 2) == 0 || nl <= 0 || dr <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "WN: bad hyper-parameters");
@@ -64,6 +65,15 @@ struct WNStack {
       PackSpec cp{}; cp.Cin = gin; cp.Cout = 2 * H * NL; cp.K = 1;
       cond.reset(new PackedConv());
       SVOC_TRY(pack_conv_named(*cond, cp, tab, prefix + "cond_layer", st));
+    }
+    if (wn_stack_applies(H, K, DR, NL, 1, 32 * device_cu_count())) {      // (a shape that passes: the scratch is sized by the CU count only)
+      const PackedConv* il[16]; const PackedConv* rl[16]; const float* wf[16];
+      bool all = NL <= 16;
+      for (int i = 0; i < NL && all; ++i) { il[i] = in_l[i].get(); rl[i] = rs_l[i].get(); wf[i] = in_f25[i]->f(); all = wf[i] != nullptr; }
+      if (all) {
+        SVOC_TRY(stack_ws.ensure(wn_stack_scratch_bytes()));
+        SVOC_TRY(wn_stack_prepare(stack_ws.f(), il, rl, wf, NL, st));
+      }
     }
     return SVOC_OK;
   }
@@ -119,6 +129,17 @@ struct WNStack {
         a.mask = mask; a.mask_bs = mask_bs;
         set_out(a.out[0], out, out_bs, out_ld, H, (NL == 1 ? 0u : (unsigned)F_ACC) | F_OUTMASK);
         return launch_conv(*rs_l[NL - 1], a, B, st);
+      }
+    }
+    // The whole stack in ONE persistent launch (wn_stack.hip) while every 32-column tile has a CU of its own and nothing conditions the layers
+    if (!g && stack_ws.p && wn_stack_applies(H, K, DR, NL, B, T)) {
+      const PackedConv* il[16]; const PackedConv* rl[16]; const float* wf[16];
+      bool all = true;
+      for (int i = 0; i < NL; ++i) { il[i] = in_l[i].get(); rl[i] = rs_l[i].get(); wf[i] = in_f25[i]->f(); all = all && wf[i] != nullptr; }
+      if (all) {
+        const int r = launch_wn_stack_f25(il, rl, wf, NL, H, src, src_bs, src_ld, out, out_bs, out_ld, mask, mask_bs, stack_ws.f(), B, T, st);
+        if (r < 0) return r;
+        if (r == 0) return SVOC_OK;
       }
     }
     for (int i = 0; i < NL; ++i) {

@@ -228,6 +228,13 @@ int launch_wn_layer_fused(const PackedConv& in_l, const PackedConv& rs_l, int H,
                           int B, int T, hipStream_t st, const float* wpf = nullptr);
 // F(2,5) image of an in_layer (H = 192, k = 5, dilation 1; wn_layer_f25_kernel), left empty when the form does not apply
 bool wn_f25_enabled();
+// wn_stack.hip: a whole WN stack in one persistent launch (neighbour-to-neighbour edge exchange between the layers)
+size_t wn_stack_scratch_bytes();
+bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T);
+int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, int H, const float* x, long long x_bs,
+                        int x_ld, float* out, long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st);
+int wn_stack_prepare(float* scratch, const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, hipStream_t st);
+int wn_stack_error(const float* scratch, hipStream_t st);
 bool wn_layer_prefers_unfused(int B, int T);              // short inputs: fewer 32-column tiles than half the CUs (wn_fused.hip's size gate)
 // wn_small.hip: short inputs, one launch per layer: res_skip of the previous layer + F(2,5) in_layer + gate; 1 = does not apply
 bool wn_small_enabled();

@@ -378,6 +378,49 @@ def test_wn_edge_shapes(M):
             check(f"wn H{H} k{k} dr{dr} T{Tn} B{B}", y, ref.numpy())
 
 
+@pytest.mark.parametrize("n_layers,B,Tn", [(16, 8, 520), (8, 5, 1000), (3, 16, 512), (2, 255, 32)])
+def test_wn_stack_one_persistent_launch(M, n_layers, B, Tn, tmp_path):
+    """A whole WN stack in ONE persistent launch (csrc/wn_stack.hip; reference modules.py:148-176): taken while every 32-column tile has a CU of its
+    own (128 .. 256 tiles here), the tiles exchanging two-column edges between the layers.  Ragged lengths (an utterance that ends inside a tile, one
+    of a single frame), a last tile of 8 columns (T = 520), 255 one-tile utterances (no neighbours at all).  Against the oracle, and BIT FOR BIT against
+    the one-launch-per-layer path (a second process with SVOC_WN_STACK=0: the arithmetic per layer is the same instruction stream)."""
+    import subprocess, sys, os
+    rng = np.random.default_rng(n_layers * 1000 + B)
+    sd = sw.fill_state_dict(cases.wn_shapes(192, 5, n_layers, 0), 8700 + n_layers)
+    m = load(M.modules.WN(192, 5, 1, n_layers, gin_channels=0), sd)
+    x = T(cases.rnd(8800 + B, "x", (B, 192, Tn), 1.0))
+    lens = [Tn, 1] + [int(rng.integers(1, Tn + 1)) for _ in range(B - 2)]
+    mask = T(cases.lengths_mask(lens, Tn))
+    M.native.stats_reset()
+    y = m((x * mask).cuda(), mask.cuda())
+    st = M.native.stats_get()
+    assert st["conv_launches"] == 1, st                       # ONE GEMM-family launch for the 2 * n_layers convolutions
+    assert st["convolutions"] == 2 * n_layers
+    with torch.no_grad():
+        ref = O.wn(sdT(sd), "", x * mask, mask, None, hidden=192, kernel_size=5, dilation_rate=1, n_layers=n_layers)
+    check(f"wn stack n{n_layers} B{B} T{Tn}", y, ref.numpy())
+    y2 = m((x * mask).cuda(), mask.cuda())
+    assert torch.equal(y, y2)                                  # the neighbour hand-shake leaves no run-to-run difference
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {cases.ROOT!r}); sys.path.insert(0, {os.path.join(cases.ROOT, 'tests')!r})
+import cases
+from cases import sw
+from smart_vocoder_amd import modules, _native
+m = modules.WN(192, 5, 1, {n_layers}, gin_channels=0)
+m.load_state_dict({{k: torch.from_numpy(v) for k, v in sw.fill_state_dict(cases.wn_shapes(192, 5, {n_layers}, 0), {8700 + n_layers}).items()}})
+m = m.cuda().eval()
+x = torch.from_numpy(cases.rnd({8800 + B}, "x", ({B}, 192, {Tn}), 1.0)); mask = torch.from_numpy(cases.lengths_mask({lens!r}, {Tn}))
+_native.stats_reset()
+y = m((x * mask).cuda(), mask.cuda())
+assert _native.stats_get()["conv_launches"] == {n_layers}, _native.stats_get()
+np.save({str(tmp_path / 'y.npy')!r}, y.cpu().numpy())
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVOC_WN_STACK="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert np.array_equal(np.load(str(tmp_path / "y.npy")), y.cpu().numpy()), "persistent stack differs from the per-layer launches"
+
+
 @pytest.mark.parametrize("name", list(cases.POSTERIOR_CASES))
 def test_posterior_encoder(M, name):
     c = cases.POSTERIOR_CASES[name]

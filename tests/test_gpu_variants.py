@@ -13,6 +13,7 @@ tests/test_gpu_parity.py::test_fallback_shapes).
   SVOC_W4_F44=0                  k = 7 / 11 in F(4,3) form (six-product groups + left-over taps) instead of F(4,4)
   SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv (short inputs)
   SVOC_WN_SMALL_F25=0            short inputs: WN layers as two K-split convolutions instead of one launch per layer (wn_small.hip)
+  SVOC_WN_STACK=0                WN stacks one launch per layer instead of one persistent launch per stack (more 32-column tiles than CUs; conditioning input)
   SVOC_WN_F25=0                  WN in_layers in direct form (K-split layer kernel) instead of Winograd F(2,5) (H != 192, k != 5)
   SVOC_KSPLIT=0 SVOC_WN_SMALL=0 SVOC_MRF_SMALL=0    short inputs on the throughput kernels (no K-split convolutions, fused WN
                                  layers, grouped MRF launches)
@@ -45,6 +46,7 @@ VARIANTS = {
     "winograd_f43_for_k7_k11": ({"SVOC_W4_F44": "0"}, DEC),
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),
+    "wn_one_launch_per_layer": ({"SVOC_WN_STACK": "0"}, WNS + " or test_c2_full_size_vs_oracle"),
     "wn_short_inputs_two_convolutions": ({"SVOC_WN_SMALL_F25": "0"}, SMALL + " or test_coupling or test_flow"),
     "no_small_shape_kernels": ({"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"}, SMALL),
     "no_graph": ({"SVOC_GRAPH": "0"}, SMALL),
