@@ -24,7 +24,7 @@ python $R/tools/pmc_traffic.py /tmp/pr /tmp/pw $NK 2 > $O/${TAG}_pmc_hbm_traffic
 ( cd $R && for k in 3 7 11; do python tools/wino4_timeline.py 128 $k 1; done; python tools/wino4_timeline.py 128 11 3; python tools/wino4_timeline.py 256 11 1; for k in 7 11; do WL=65536 python tools/wino4_timeline.py 64 $k 1; done; for k in 3 7 11; do WL=131072 python tools/wino4_timeline.py 32 $k 1; done; WL=131072 python tools/wino4_timeline.py 32 11 3 ) > $O/${TAG}_winograd_workgroup_stamps.txt 2>/dev/null
 ( cd $R && for sh in "512 256 16 8 512" "256 128 16 8 4096" "128 64 4 2 32768" "64 32 4 2 65536"; do python tools/ct_timeline.py $sh; done;  ) > $O/${TAG}_upsampler_f42_workgroup_stamps.txt 2>/dev/null
 ( cd $R && for v in 1 0; do SVOC_CT_WINO=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc 2>/dev/null | tail -1; done ) > $O/${TAG}_bench_upsamplers_f42_vs_direct.txt
-( cd $R && python tools/wn_timeline.py 16 512 ) > $O/${TAG}_wn_layer_phase_stamps.txt 2>/dev/null
+( cd $R && python tools/wn_timeline.py 16 512 | head -1; echo "(above: the persistent stack launch, csrc/wn_stack.hip, default; below: one launch per layer, SVOC_WN_STACK=0, whose kernel carries the phase stamps)"; SVOC_WN_STACK=0 python tools/wn_timeline.py 16 512 ) > $O/${TAG}_wn_layer_phase_stamps.txt 2>/dev/null
 ( cd $R && python tools/wino_bench.py 128 32768; python tools/wino_bench.py 64 65536; python tools/wino_bench.py 256 4096; python tools/wino_bench.py 32 131072 ) > $O/${TAG}_winograd_per_conv.txt 2>/dev/null
 ( cd $R && BENCH_BACKEND=nccl BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29573 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-other-configs ) > $O/${TAG}_bench_1rank_rccl.json 2> $O/${TAG}_bench_1rank_rccl.err
 # instruction mix of the DEFAULT plan (separate counter passes, nothing traced beside them)
@@ -35,4 +35,11 @@ ls -la $O
 
 ( cd $R && python tools/profile_infer.py 1 200 5 ) > $O/${TAG}_per_layer_event_profile_1x200.txt 2>&1
 ( cd $R && BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 5 --warmup 2 ) > $O/${TAG}_bench_2ranks_gloo_one_gpu.json 2> $O/${TAG}_bench_2ranks_gloo_one_gpu.err
+ls -la $O
+# round 5: clock / power study (steady state: every workload looped back to back for seconds, board power from rocm-smi)
+( cd $R && timeout 300 tools/clock_power_probe ) > $O/${TAG}_clock_power_probe.txt 2>&1
+( cd $R && timeout 400 python tools/power_ablate.py ) > $O/${TAG}_power_ablation_steady_state.txt 2>&1
+( cd $R && timeout 300 python tools/power_watch.py ) > $O/${TAG}_power_watch.txt 2>&1
+( cd $R && timeout 300 python tools/power_wn.py ) > $O/${TAG}_power_wn_stack.txt 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt200 --output-format csv -- python $R/tools/small_shape_run.py 1 200 20 > /dev/null 2>&1; python $R/tools/timeline.py /tmp/kt200 400 > $O/${TAG}_kernel_timeline_1x200_graph.txt 2>&1 )
 ls -la $O

@@ -21,4 +21,4 @@ print(f"Ci={ci} Co={co} k={k} s={s} L={L} B={B}: {len(D)} workgroups x {tiles.me
 print(f"   producer wave 0 per tile: total {np.mean(D[:, 8] / tiles):.0f} cycles, of which waiting at stage barriers {np.mean(D[:, 9] / tiles):.0f}, "
       f"for the global loads {np.mean(D[:, 12] / tiles):.0f}, staging (leaky relu -> raw tile) {np.mean(D[:, 13] / tiles):.0f}, next loads + transform {np.mean(D[:, 14] / tiles):.0f}")
 wall = (D[:, 11] - D[:, 10]) / 100.0
-print(f"   wall time per workgroup: median {np.median(wall):.1f} us, span first start .. last end {(D[:, 11].max() - D[:, 10].min()) / 100.0:.1f} us; effective shader clock {np.median(D[:, 1] / wall):.0f} MHz")
+print(f"   wall time per workgroup: median {np.median(wall):.1f} us, span first start .. last end {(D[:, 11].max() - D[:, 10].min()) / 100.0:.1f} us; effective shader clock {np.median(D[:, 1] / wall):.0f} MHz (ONE launch behind an idle gap: the clock ramp, not the sustained clock - see tools/power_ablate.py)")

@@ -22,7 +22,7 @@ print(f"WN(192, k5, 16 layers) B={B} T={T}: {e0.elapsed_time(e1) / 160 * 1e3:.1f
 buf = torch.zeros(1 << 14, 8, dtype=torch.long, device="cuda"); torch.cuda.synchronize()
 N.check(lib.svoc_debug_set_stamp_buffer(N.ptr(buf))); m(x, mask); torch.cuda.synchronize(); N.check(lib.svoc_debug_set_stamp_buffer(None))
 D = buf.cpu().numpy(); D = D[D[:, 6] != 0]          # stamps of the LAST layer that wrote each slot
-if not len(D): print("(short input: the unfused K-split path ran, no stamps)"); sys.exit(0)
+if not len(D): print("(no stamps: the persistent stack launch (SVOC_WN_STACK=0 for the per-layer kernel) or the short-input path ran)"); sys.exit(0)
 if (D[:, 6] < 0).all():      # wn_layer_f25_kernel (round 4): Winograd F(2,5) in_layer
     D[:, 6] = -D[:, 6]
     names = ["staging (loads -> LDS, barrier)", "input transform -> planes, barrier", "phase A (in_layer, F(2,5): 576 MFMAs 16x16x4 per wave)",
