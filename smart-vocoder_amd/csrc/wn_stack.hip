@@ -5,12 +5,17 @@
 // last two columns of its new x to a halo buffer (device-coherent stores), raises a per-tile counter (release), and before layer i + 1 waits for
 // the counters of its two neighbours (acquire) and fetches their edges.  Neighbour-to-neighbour only - no grid-wide barrier.  Every workgroup of
 // the launch must be resident at once (they wait for each other): the launcher takes the stack only while there are no more tiles than CUs (one
-// 768-thread, 154 KB workgroup per CU), and the waits are bounded - a workgroup that gives up (~1 s) raises an error word in the scratch area
-// (wn_stack_error) and goes on, so a scheduling accident produces a wrong result, never a hung GPU.
+// 768-thread, 154 KB workgroup per CU).  When the GPU is shared, part of the launch is resident at first: workgroups are dispatched in tile order, the
+// lowest resident tile's left neighbour has finished, and a window of more than n_layers resident tiles always lets its low end run to completion and
+// free its CUs - progress needs n_layers + 1 CUs, not all of them.  The waits are bounded all the same (30 s of wall time): a workgroup that gives up
+// raises an error word in the scratch area (wn_stack_error) and goes on - a wrong result, never a hung GPU.
 // Memory ordering (gfx950, one L2 per XCD): edges and counters are device-scope relaxed atomics (sc1: they bypass the non-coherent caches in both
 // directions); the writer waits for its edge stores' acknowledgements (s_waitcnt vmcnt(0) - a workgroup-scope release fence) ahead of the workgroup
 // barrier behind which thread 0 raises the counter; the reader's edge loads are issued behind the barrier that follows the successful poll.  No
-// L2 write-back or invalidate is involved, so the weight images stay cached.
+// L2 write-back or invalidate is involved, so the weight images stay cached.  Every (layer, tile, edge) has a halo slot of its OWN, written once per
+// launch: a first version reused two slots by layer parity (a tile can be at most one layer ahead of its neighbour) and returned wrong edges when two
+// processes shared the GPU (tools/r05_two_ranks_one_gpu.sh: the timed step and infer_sharded of a two-rank bench on one device differed; with one slot
+// per layer they agree bit for bit, agent-scope release / acquire fences around the parity slots did not help and cost 6 ms per step).
 // Per layer it is wn_layer_f25_kernel's arithmetic, instruction for instruction (F(2,5) in_layer on v_mfma_f32_16x16x4_f32 with the K halves on
 // two waves, gate from exp2 / rcp, res_skip as the VALU-free 32x32x2 stream): results are bit-identical to the per-layer launches.
 // H = 192, k = 5, dilation 1, no conditioning input (the path's five WN stacks: models.py:35-47, modules.py:324-343).
@@ -35,7 +40,7 @@ struct WnStackArgs {
   const float* mask; long long mask_bs;
   const WnStackLayer* layers;                           // [NL], in device memory (a by-value array indexed by the layer would be copied to scratch)
   int ksg2; int NL; int T;
-  float* halo;                                          // [2 (layer parity)][tiles][2 (left edge, right edge)][H][2]
+  float* halo;                                          // [WNS_MAXL (layer)][tiles][2 (left edge, right edge)][H][2]: a slot is written ONCE per launch
   int* done;                                            // [tiles]: layers completed (zeroed ahead of the launch)
   int* err;                                             // raised when a bounded wait gave up
   long long* dbg;
@@ -128,10 +133,17 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
     if (li > 0) {
       if ((tid == 0 && has_left) || (tid == 64 && has_right)) {
         const int* f = p.done + (tid == 0 ? gt - 1 : gt + 1);
-        int spins = 0;
+        // Bounded by WALL time (the 100 MHz counter), generously: when another process shares the GPU only part of this launch is resident at
+        // first, and a workgroup then waits for CUs that the other process' kernels still hold (the low end of the resident window always runs to
+        // completion and frees its CUs, so the launch makes progress with as few as n_layers + 1 resident workgroups - but slowly).  A first version
+        // counted 2^20 polls (~50 ms) and produced wrong results with two ranks on one GPU.
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < li) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1 << 20)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // ~1 s: give up, never hang
+          if (__builtin_amdgcn_s_memrealtime() - t_start > 3000000000ull) {      // 30 s: give up, never hang
+            __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
         }
       }
       __syncthreads();
@@ -141,7 +153,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
         const bool have = side == 0 ? has_left : has_right;
         if (have) {
           const int src_tile = side == 0 ? gt - 1 : gt + 1;
-          const float* hp = p.halo + ((((long long)((li - 1) & 1) * ntiles + src_tile) * 2 + (side == 0 ? 1 : 0)) * H + r) * 2 + c;
+          const float* hp = p.halo + ((((long long)(li - 1) * ntiles + src_tile) * 2 + (side == 0 ? 1 : 0)) * H + r) * 2 + c;
           XT[r * WNF_XROW + (side == 0 ? 2 : 36) + c] = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
@@ -281,7 +293,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       if (!kh) {         // x = (x + rs[:H]) * mask: into the resident tile; the tile's first and last two columns also to the halo buffer
         float* xc = XT + row0_ * WNF_XROW + 4 + l31_;
         const bool edge = l31_ < 2 || l31_ >= 30;
-        float* hp = p.halo + ((((long long)(li & 1) * ntiles + gt) * 2 + (l31_ < 2 ? 0 : 1)) * H + row0_) * 2 + (l31_ & 1);
+        float* hp = p.halo + ((((long long)li * ntiles + gt) * 2 + (l31_ < 2 ? 0 : 1)) * H + row0_) * 2 + (l31_ & 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
@@ -323,7 +335,7 @@ bool wn_stack_enabled() {
   return on;
 }
 // scratch: halo buffer | per-tile layer counters | error word | (64-byte aligned) the layers' pointer table
-static size_t wn_stack_table_offset() { return (((size_t)2 * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 1) * sizeof(float) + 63) / 64 * 64; }
+static size_t wn_stack_table_offset() { return (((size_t)WNS_MAXL * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 1) * sizeof(float) + 63) / 64 * 64; }
 size_t wn_stack_scratch_bytes() { return wn_stack_table_offset() + WNS_MAXL * sizeof(WnStackLayer); }
 // The stack applies while every tile has a CU of its own (the workgroups wait for their neighbours) and the per-layer kernel would be the F(2,5) one.
 bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T) {
@@ -348,7 +360,7 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   a.ksg2 = rs_l[0]->ksg_total; a.NL = NL; a.T = T;
   const int ntx = (T + 31) / 32, ncu = device_cu_count();
   a.halo = scratch;
-  a.done = reinterpret_cast<int*>(scratch + (size_t)2 * ncu * 2 * WNF_H * 2);
+  a.done = reinterpret_cast<int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2);
   a.err = a.done + ncu;
   a.dbg = nullptr;
   SVOC_HIP(hipMemsetAsync(a.done, 0, (size_t)ncu * sizeof(int), st));      // (the error word behind the counters is sticky: zeroed when the scratch is allocated)
@@ -386,7 +398,7 @@ int wn_stack_error(const float* scratch, hipStream_t st) {
   if (!scratch) return 0;
   const int ncu = device_cu_count();
   int e = 0;
-  const int* err = reinterpret_cast<const int*>(scratch + (size_t)2 * ncu * 2 * WNF_H * 2) + ncu;
+  const int* err = reinterpret_cast<const int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2) + ncu;
   if (hipMemcpyAsync(&e, err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
   if (hipStreamSynchronize(st) != hipSuccess) return -1;
   return e;

@@ -385,6 +385,8 @@ def test_wn_stack_one_persistent_launch(M, n_layers, B, Tn, tmp_path):
     of a single frame), a last tile of 8 columns (T = 520), 255 one-tile utterances (no neighbours at all).  Against the oracle, and BIT FOR BIT against
     the one-launch-per-layer path (a second process with SVOC_WN_STACK=0: the arithmetic per layer is the same instruction stream)."""
     import subprocess, sys, os
+    if any(os.environ.get(k) == "0" for k in ("SVOC_WN_STACK", "SVOC_WN_F25", "SVOC_FUSE_WN")):
+        pytest.skip("a variant run that switches the persistent stack launch (or the layer kernel under it) off")
     rng = np.random.default_rng(n_layers * 1000 + B)
     sd = sw.fill_state_dict(cases.wn_shapes(192, 5, n_layers, 0), 8700 + n_layers)
     m = load(M.modules.WN(192, 5, 1, n_layers, gin_channels=0), sd)

@@ -111,6 +111,20 @@ def test_bench_two_ranks_gloo_one_gpu(tmp_path):
     assert "error" not in sh and sh["ms_per_call"] > 0 and sh["equals_timed_step_output"] is True, sh
 
 
+def test_bench_two_ranks_one_gpu_full_size_bits():
+    """bench.py --gpus 2 with both ranks on ONE device at the headline shape (16 x 512 per rank): the persistent WN stack launches (csrc/wn_stack.hip)
+    of the two processes then compete for the CUs, and their workgroups wait for neighbours that are not resident yet.  `parallel.infer_sharded` must
+    still return the timed step's bits (round 5: with halo slots reused by layer parity it did not)."""
+    env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32
+    assert j["infer_sharded"]["equals_timed_step_output"] is True, j["infer_sharded"]
+
+
 def test_bench_single_gpu_line_schema():
     """bench.py at N=1 on the timed configuration (16 x 512, 2 steps, no CPU leg): ONE JSON line with the contract's keys, the
     roofline block (`frac` = executed multiply-adds over the peak, bounded by 1; `frac_direct_form`, which the Winograd kernels may

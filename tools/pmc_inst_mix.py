@@ -7,7 +7,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(int))
 def fam(n):
-    for k in ("conv_wino4_group", "conv_wino4_acc3", "conv_wino4_accum", "conv_wino4", "wn_layer_f25", "convt_wino", "conv_wino_group", "conv_wino", "conv_group", "conv_ksplit", "conv_mfma", "resblock_fused", "wn_layer_fused", "conv_post"):
+    for k in ("conv_wino4_group", "conv_wino4_acc3", "conv_wino4_pairacc", "conv_wino4_pair", "conv_wino4", "wn_stack_f25", "wn_layer_f25", "wn_small_f25", "convt_wino", "conv_wino_group", "conv_wino", "conv_group", "conv_ksplit", "conv_mfma", "resblock_fused", "wn_layer_fused", "conv_post"):
         if k in n:
             m = re.search(r"<([\d, ]+)>", n)
             return k + (("<" + m.group(1).replace(" ", "") + ">") if m else "")

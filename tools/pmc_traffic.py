@@ -22,11 +22,12 @@ def load(path):
 
 def is_model(n):
     return any(k in n for k in ("conv_mfma", "conv_group", "conv_ksplit", "conv_wino", "convt_wino", "convt_tail", "resblock_fused",
-                                "wn_layer_fused", "conv_post", "copy2d", "sequence_mask"))
+                                "wn_layer_fused", "wn_layer_f25", "wn_stack_f25", "wn_small_f25", "conv_post", "copy2d", "sequence_mask"))
 
 
 def gemm(n):
-    return any(k in n for k in ("conv_mfma", "conv_group", "conv_ksplit", "conv_wino", "convt_wino", "resblock_fused", "wn_layer_fused"))
+    return any(k in n for k in ("conv_mfma", "conv_group", "conv_ksplit", "conv_wino", "convt_wino", "resblock_fused", "wn_layer_fused", "wn_layer_f25",
+                                "wn_stack_f25", "wn_small_f25"))
 
 
 def rbytes(c):

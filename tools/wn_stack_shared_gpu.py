@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Two (or N) processes run the persistent WN stack launch on ONE GPU at the same time; each compares every output with its first one.
+    python tools/wn_stack_shared_gpu.py [nproc=2] [iters=150]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = f"""
+import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {ROOT!r} + '/tests')
+import torch
+from cases import sw
+from smart_vocoder_amd import modules
+m = modules.WN(192, 5, 1, 16)
+m.load_state_dict({{n: torch.from_numpy(v) for n, v in sw.fill_state_dict({{n: tuple(p.shape) for n, p in m.state_dict().items()}}, 7, 0.5).items()}})
+m = m.cuda().eval()
+g = torch.Generator().manual_seed(int(sys.argv[1]))
+x = (torch.randn(16, 192, 512, generator=g) * 0.5).cuda(); mask = torch.ones(16, 1, 512, device='cuda')
+ref = m(x, mask).clone(); torch.cuda.synchronize()
+bad = 0; worst = 0.0
+for it in range(int(sys.argv[2])):
+    y = m(x, mask)
+    if not torch.equal(y, ref): bad += 1; worst = max(worst, float((y - ref).abs().max()))
+torch.cuda.synchronize()
+print('rank', sys.argv[1], 'mismatching outputs', bad, 'of', sys.argv[2], 'worst abs diff', worst, flush=True)
+"""
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+iters = sys.argv[2] if len(sys.argv) > 2 else "150"
+ps = [subprocess.Popen([sys.executable, "-c", CHILD, str(r), iters], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for r in range(n)]
+for p in ps:
+    o, _ = p.communicate(timeout=900)
+    print(o.strip())
