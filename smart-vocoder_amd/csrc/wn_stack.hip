@@ -13,9 +13,8 @@
 // directions); the writer waits for its edge stores' acknowledgements (s_waitcnt vmcnt(0) - a workgroup-scope release fence) ahead of the workgroup
 // barrier behind which thread 0 raises the counter; the reader's edge loads are issued behind the barrier that follows the successful poll.  No
 // L2 write-back or invalidate is involved, so the weight images stay cached.  Every (layer, tile, edge) has a halo slot of its OWN, written once per
-// launch: a first version reused two slots by layer parity (a tile can be at most one layer ahead of its neighbour) and returned wrong edges when two
-// processes shared the GPU (tools/r05_two_ranks_one_gpu.sh: the timed step and infer_sharded of a two-rank bench on one device differed; with one slot
-// per layer they agree bit for bit, agent-scope release / acquire fences around the parity slots did not help and cost 6 ms per step).
+// launch.  The hand-shake counters are cleared by the last workgroup to LEAVE a launch, not by a memset ahead of it (see launch_wn_stack_f25: inside a
+// replayed plan on a shared GPU the launch found them uncleared - nobody waited, and with two slots reused by layer parity the edges were visibly wrong).
 // Per layer it is wn_layer_f25_kernel's arithmetic, instruction for instruction (F(2,5) in_layer on v_mfma_f32_16x16x4_f32 with the K halves on
 // two waves, gate from exp2 / rcp, res_skip as the VALU-free 32x32x2 stream): results are bit-identical to the per-layer launches.
 // H = 192, k = 5, dilation 1, no conditioning input (the path's five WN stacks: models.py:35-47, modules.py:324-343).
@@ -41,7 +40,9 @@ struct WnStackArgs {
   const WnStackLayer* layers;                           // [NL], in device memory (a by-value array indexed by the layer would be copied to scratch)
   int ksg2; int NL; int T;
   float* halo;                                          // [WNS_MAXL (layer)][tiles][2 (left edge, right edge)][H][2]: a slot is written ONCE per launch
-  int* done;                                            // [tiles]: layers completed (zeroed ahead of the launch)
+  int* ticket;                                          // tiles handed out so far    } zero when a launch starts: the LAST workgroup to leave a launch
+  int* exited;                                          // workgroups that have left   } clears the three of them for the next one (no memset node:
+  int* done;                                            // [tiles]: layers completed   } see launch_wn_stack_f25)
   int* err;                                             // raised when a bounded wait gave up
   long long* dbg;
 };
@@ -62,8 +63,15 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
   const int kh = wave >= NPAIRS ? 1 : 0;                    // K half
   const int pi = wave - kh * NPAIRS;                        // row pair
   const int l31 = lane & 31;
-  const int b = blockIdx.z, tile = blockIdx.x, ntx = gridDim.x;
-  const int gt = b * ntx + tile, ntiles = ntx * gridDim.z;
+  // Tiles are handed out in the order in which the workgroups actually START (a ticket), not by block id: the started-and-unfinished tiles then
+  // always are a run of consecutive tiles whose predecessors have finished, and such a run of more than n_layers + one utterance's tiles makes progress
+  // whatever the hardware's dispatch order is.  (By block id, two processes on one GPU - each XCD serving its share of both launches - could hold each
+  // other's missing neighbours: observed as 30 s stalls ending in the error word.)
+  const int ntx = gridDim.x, ntiles = ntx * gridDim.z;
+  if (tid == 0) reinterpret_cast<int*>(RED)[0] = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int gt = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(RED)[0]);
+  const int b = gt / ntx, tile = gt - b * ntx;
   const int t0 = tile * 32;
   const int NL = p.NL;
   const bool has_left = tile > 0, has_right = tile + 1 < ntx;
@@ -327,6 +335,19 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = fin[r] * mk;
     }
   }
+  // ---- leave: the last workgroup out clears the hand-shake state for the next launch (every other workgroup's counter traffic is behind its own
+  // increment of `exited`: release fence, then the increment)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) reinterpret_cast<int*>(RED)[1] = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (reinterpret_cast<const int*>(RED)[1] == ntiles - 1) {
+    for (int i = threadIdx.x; i < ntiles; i += 768) __hip_atomic_store(p.done + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(p.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -335,7 +356,7 @@ bool wn_stack_enabled() {
   return on;
 }
 // scratch: halo buffer | per-tile layer counters | error word | (64-byte aligned) the layers' pointer table
-static size_t wn_stack_table_offset() { return (((size_t)WNS_MAXL * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 1) * sizeof(float) + 63) / 64 * 64; }
+static size_t wn_stack_table_offset() { return (((size_t)WNS_MAXL * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 3) * sizeof(float) + 63) / 64 * 64; }
 size_t wn_stack_scratch_bytes() { return wn_stack_table_offset() + WNS_MAXL * sizeof(WnStackLayer); }
 // The stack applies while every tile has a CU of its own (the workgroups wait for their neighbours) and the per-layer kernel would be the F(2,5) one.
 bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T) {
@@ -360,10 +381,15 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   a.ksg2 = rs_l[0]->ksg_total; a.NL = NL; a.T = T;
   const int ntx = (T + 31) / 32, ncu = device_cu_count();
   a.halo = scratch;
-  a.done = reinterpret_cast<int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2);
+  a.ticket = reinterpret_cast<int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2);
+  a.exited = a.ticket + 1;
+  a.done = a.ticket + 2;
   a.err = a.done + ncu;
   a.dbg = nullptr;
-  SVOC_HIP(hipMemsetAsync(a.done, 0, (size_t)ncu * sizeof(int), st));      // (the error word behind the counters is sticky: zeroed when the scratch is allocated)
+  // The counters are NOT cleared by a memset ahead of the launch: a first version did that, and inside a captured plan replayed while another
+  // process shared the GPU the launch found them uncleared (tickets beyond the grid: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; before tickets
+  // existed: layer counters already raised, i.e. no waiting at all and edges of the launch before - which tests that repeat one input cannot see).
+  // The last workgroup to leave a launch clears them; kernel -> kernel order on the stream does the rest; wn_stack_prepare() zeroes them once.
   double flops = 0, exec = 0;
   for (int i = 0; i < NL; ++i) {
     flops += (in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;
@@ -398,7 +424,7 @@ int wn_stack_error(const float* scratch, hipStream_t st) {
   if (!scratch) return 0;
   const int ncu = device_cu_count();
   int e = 0;
-  const int* err = reinterpret_cast<const int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2) + ncu;
+  const int* err = reinterpret_cast<const int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2) + 2 + ncu;
   if (hipMemcpyAsync(&e, err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
   if (hipStreamSynchronize(st) != hipSuccess) return -1;
   return e;

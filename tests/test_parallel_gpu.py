@@ -125,6 +125,43 @@ def test_bench_two_ranks_one_gpu_full_size_bits():
     assert j["infer_sharded"]["equals_timed_step_output"] is True, j["infer_sharded"]
 
 
+_SHARED_GPU_CHILD = """
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/tests')
+import cases
+from cases import sw
+from smart_vocoder_amd import models
+net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+net.load_state_dict({{k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}}, strict=False)
+net = net.cuda().eval()
+seed = int(sys.argv[1])
+ins = [(torch.from_numpy(sw.synthetic_mel(seed + i, 16, 512)).cuda(), torch.from_numpy(sw.synthetic_eps(seed + i, 16, 512)).cuda()) for i in range(2)]
+ln = torch.full((16,), 512, dtype=torch.int64).cuda()
+refs = []
+for it in range(14):
+    mel, eps = ins[it % 2]
+    o = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+    if it < 2: refs.append(o.clone())
+    elif not torch.equal(o, refs[it % 2]): print("MISMATCH at call", it, float((o - refs[it % 2]).abs().max())); sys.exit(3)
+torch.cuda.synchronize()
+assert not torch.equal(refs[0], refs[1])
+print("OK")
+"""
+
+
+def test_two_processes_one_gpu_alternating_inputs():
+    """Two processes run the full path at 16 x 512 on ONE device at the same time, each alternating between two inputs (captured-plan replay from the
+    second sight on): every call must reproduce the first call on that input bit for bit.  The persistent WN stack launches of the two processes then
+    compete for the CUs; a launch that found its hand-shake counters uncleared (round 5: a memset node ahead of the launch was not a dependable
+    ordering inside a replayed plan) would take the edges of the call BEFORE - of the other input - and differ."""
+    code = _SHARED_GPU_CHILD.format(root=cases.ROOT)
+    ps = [subprocess.Popen([sys.executable, "-c", code, str(4100 + 10 * r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in ps]
+    for p, o in zip(ps, outs):
+        assert p.returncode == 0 and o.strip().endswith("OK"), o[-2000:]
+
+
 def test_bench_single_gpu_line_schema():
     """bench.py at N=1 on the timed configuration (16 x 512, 2 steps, no CPU leg): ONE JSON line with the contract's keys, the
     roofline block (`frac` = executed multiply-adds over the peak, bounded by 1; `frac_direct_form`, which the Winograd kernels may

@@ -12,14 +12,22 @@ m = modules.WN(192, 5, 1, 16)
 m.load_state_dict({{n: torch.from_numpy(v) for n, v in sw.fill_state_dict({{n: tuple(p.shape) for n, p in m.state_dict().items()}}, 7, 0.5).items()}})
 m = m.cuda().eval()
 g = torch.Generator().manual_seed(int(sys.argv[1]))
-x = (torch.randn(16, 192, 512, generator=g) * 0.5).cuda(); mask = torch.ones(16, 1, 512, device='cuda')
-ref = m(x, mask).clone(); torch.cuda.synchronize()
-bad = 0; worst = 0.0
+# consecutive launches work on DIFFERENT inputs: a stale halo word (the slot's content from the launch before) must not pass for the right one
+xs = [(torch.randn(16, 192, 512, generator=g) * 0.5).cuda() for _ in range(3)]; mask = torch.ones(16, 1, 512, device='cuda')
+import os
+os.environ_backup = os.environ.get("SVOC_WN_STACK")
+refs = []
+from smart_vocoder_amd import _native
+for x in xs:
+    refs.append(m(x, mask).clone()); torch.cuda.synchronize()
+import time
+t0 = time.time(); bad = 0; worst = 0.0
 for it in range(int(sys.argv[2])):
+    x, ref = xs[it % 3], refs[it % 3]
     y = m(x, mask)
     if not torch.equal(y, ref): bad += 1; worst = max(worst, float((y - ref).abs().max()))
 torch.cuda.synchronize()
-print('rank', sys.argv[1], 'mismatching outputs', bad, 'of', sys.argv[2], 'worst abs diff', worst, flush=True)
+print('rank', sys.argv[1], 'mismatching outputs', bad, 'of', sys.argv[2], 'worst abs diff', worst, 'seconds', round(time.time() - t0, 2), flush=True)
 """
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 iters = sys.argv[2] if len(sys.argv) > 2 else "150"
