@@ -197,4 +197,36 @@ __device__ __forceinline__ float4 w4_output_transform(const f32x16 (&M)[NACC], c
   }
 }
 
+// The same for accumulator elements i and i + 1 (i even: an aligned register pair of every accumulator) in packed fp32 math (round 5): the output
+// transform is VALU work on the consumers' SIMDs, where it cannot overlap anybody's MFMAs - 15 packed instructions per two rows instead of 30 (F(4,4));
+// the same operations in the same order on each row, so results are bit-identical to w4_output_transform.
+template <class Geo, int NACC>
+__device__ __forceinline__ void w4_output_transform2(const f32x16 (&M)[NACC], const int i, float4& ya, float4& yb) {
+  auto P = [&](int p) -> f32x2 { return (f32x2){M[p][i], M[p][i + 1]}; };
+  auto fma2 = [](float c, f32x2 a, f32x2 b) -> f32x2 { return __builtin_elementwise_fma((f32x2){c, c}, a, b); };
+  const f32x2 t1 = P(1) + P(2), t2 = P(1) - P(2), t3 = P(3) + P(4), t4 = P(3) - P(4);
+  f32x2 y0, y1, y2, y3;
+  if constexpr (Geo::F44) {
+    static_assert(NACC >= 7, "seven products");
+    const f32x2 t5 = P(5) + P(6), t6 = P(5) - P(6);
+    y0 = (P(0) + t1) + (t3 + t5);
+    y1 = fma2(0.5f, t6, fma2(2.f, t4, t2));
+    y2 = fma2(0.25f, t5, fma2(4.f, t3, t1));
+    y3 = fma2(0.125f, t6, fma2(8.f, t4, t2));
+  } else {
+    y0 = P(0) + (t1 + t3);
+    y1 = fma2(2.f, t4, t2);
+    y2 = fma2(4.f, t3, t1);
+    y3 = fma2(8.f, t4, t2) + P(5);
+    if constexpr (Geo::ND > 0 || NACC == 8) { y1 += P(6); y2 += P(7); }
+  }
+  ya = make_float4(y0.x, y1.x, y2.x, y3.x);
+  yb = make_float4(y0.y, y1.y, y2.y, y3.y);
+}
+// a += b on the two halves of a float4 (two packed adds)
+__device__ __forceinline__ void w4_add4(float4& a, const float4& b) {
+  const f32x2 lo = (f32x2){a.x, a.y} + (f32x2){b.x, b.y}, hi = (f32x2){a.z, a.w} + (f32x2){b.z, b.w};
+  a = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 }  // namespace svoc

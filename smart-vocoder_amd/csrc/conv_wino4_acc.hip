@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
         if constexpr (!PIPE) rq(cur, Q);
         float4 vo[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<G11, NACC>(M, 4 * Q + r);
+        for (int r = 0; r < 4; r += 2) w4_output_transform2<G11, NACC>(M, 4 * Q + r, vo[r], vo[r + 1]);
         if constexpr (PIPE && Q < 3) {
           __builtin_amdgcn_sched_barrier(0);                 // the next quarter's loads go out here, not behind this quarter's stores
           rq(nxt, Q + 1);
@@ -316,10 +316,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          vo[r].x = ((vo[r].x + cur[r].x) + cur[4 + r].x) + cur[8 + r].x;
-          vo[r].y = ((vo[r].y + cur[r].y) + cur[4 + r].y) + cur[8 + r].y;
-          vo[r].z = ((vo[r].z + cur[r].z) + cur[4 + r].z) + cur[8 + r].z;
-          vo[r].w = ((vo[r].w + cur[r].w) + cur[4 + r].w) + cur[8 + r].w;
+          w4_add4(vo[r], cur[r]); w4_add4(vo[r], cur[4 + r]); w4_add4(vo[r], cur[8 + r]);      // ((vo + res_3) + res_7) + res_11, packed
           if (dodiv) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
         }
 #pragma unroll

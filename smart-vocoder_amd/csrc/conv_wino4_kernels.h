@@ -495,7 +495,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
         constexpr int Q = decltype(q_c)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<Geo, NACC>(M, 4 * Q + r);
+        for (int r = 0; r < 4; r += 2) w4_output_transform2<Geo, NACC>(M, 4 * Q + r, vo[r], vo[r + 1]);
       };
       auto divide = [&](float4 (&vo)[4]) {                 // x / div as x * (1 / div) with one residual correction (as conv_wino.hip)
         const float dv = p.div, rc = 1.0f / dv;
@@ -526,7 +526,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
             float4 vo[4];
             ytrans(q_c, vo);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w; }
+            for (int r = 0; r < 4; ++r) w4_add4(vo[r], rv[r]);
             if (p.flags & F_DIV) divide(vo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) stq(ybase + (size_t)(8 * Q) * ylb + yo4[r], vo[r]);
@@ -560,7 +560,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) rv[r] = ld4(rbase + (size_t)(8 * Q) * rlb + ro4[r]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w; }
+            for (int r = 0; r < 4; ++r) w4_add4(vo[r], rv[r]);
           }
           if (p.flags & F_ACC) {
             float4 yv[4];

@@ -246,7 +246,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
   auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
     constexpr int Q = decltype(q_c)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<G1, NACC>(M, 4 * Q + r);
+    for (int r = 0; r < 4; r += 2) w4_output_transform2<G1, NACC>(M, 4 * Q + r, vo[r], vo[r + 1]);
   };
   for (int ti = 0; ti < my_tiles; ++ti) {
     int bz, n2, m0, off2;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
         ytrans(q_c, vo);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w;
+          w4_add4(vo[r], rv[r]);
           *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q + r) * ylb) = vo[r];
         }
       };
@@ -487,7 +487,7 @@ __device__ __forceinline__ void pairacc_consume(const PairMember& pm, const Pair
   auto ytrans = [&](auto q_c, float4 (&vo)[4]) {
     constexpr int Q = decltype(q_c)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vo[r] = w4_output_transform<G1, NACC>(M, 4 * Q + r);
+    for (int r = 0; r < 4; r += 2) w4_output_transform2<G1, NACC>(M, 4 * Q + r, vo[r], vo[r + 1]);
   };
   // ---------------- phase A: c1 into the accumulators, lrelu(c1) -> the intermediate tile (zero outside [0, L))
   init_bias(pm.bias1);
@@ -544,12 +544,12 @@ __device__ __forceinline__ void pairacc_consume(const PairMember& pm, const Pair
 #pragma unroll
         for (int r = 0; r < 4; ++r) yv[r] = *reinterpret_cast<const float4*>(ybase + (size_t)(8 * Q + r) * ylb);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { rv[r].x += yv[r].x; rv[r].y += yv[r].y; rv[r].z += yv[r].z; rv[r].w += yv[r].w; }
+        for (int r = 0; r < 4; ++r) w4_add4(rv[r], yv[r]);
       }
       ytrans(q_c, vo);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        vo[r].x += rv[r].x; vo[r].y += rv[r].y; vo[r].z += rv[r].z; vo[r].w += rv[r].w;
+        w4_add4(vo[r], rv[r]);
         if (ediv) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
         *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q + r) * ylb) = vo[r];
       }
