@@ -120,7 +120,7 @@ def dominant_kernel_probe(net, mel, ln, eps, steps=2):
     """Per-launch duration of the dominant kernel, measured live with HIP events on the launch stream by the library's
     event profiler (every GEMM-family launch bracketed by hipEventRecord): the grouped launch of the C=128 stage's
     three undilated convolutions k=11/7/3 (conv_wino4_group_kernel<1,4,0,true>: k=11/7 in Winograd F(4,4) form, k=3 in F(4,3);
-    F(4,3) throughout when SVOC_W4_F44=0; conv_wino_group_kernel<1,4>, F(2,3), when SVOC_WINO_F4=0; conv_group_kernel when
+    conv_wino_group_kernel<1,4>, F(2,3), when SVOC_WINO_F4=0; conv_group_kernel when
     SVOC_WINO=0).  Runs after the timed region."""
     from smart_vocoder_amd import _native
     _native.profile_enable(True)
@@ -476,9 +476,9 @@ def main():
                            "winograd_form_floor_ms": stats["executed_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "direct_form_floor_ms": stats["conv_flops"] / args.steps / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                            "traffic": None,
-                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group|_acc3|_pair)_kernel (every ResBlock convolution of the decoder, all four stages: Winograd F(4,4) for k=7/11, F(4,3) for k=3; SVOC_W4_F44=0: F(4,3) throughout), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, wn_layer_fused(_ks)_kernel (fallbacks: resblock_fused_ct_kernel, conv_wino(_group)_kernel F(2,3), conv_group_kernel)",
+                           "kernel": "fp32 MFMA implicit-GEMM family: conv_wino4(_group|_acc3|_pair)_kernel (every ResBlock convolution of the decoder, all four stages: Winograd F(4,4) for k=7/11, F(4,3) for k=3), convt_wino_kernel (F(4,2), upsamplers), conv_mfma_kernel, wn_layer_fused(_ks)_kernel (fallbacks: resblock_fused_ct_kernel, conv_wino(_group)_kernel F(2,3), conv_group_kernel)",
                            "note": "achieved/frac = executed 2*MAC / time (<= peak). Shares of the direct form's multiply-adds issued per kernel size k=3/7/11: "
-                                   "F(4,3) (k=3; every k with SVOC_W4_F44=0) 1/2, 4/7, 6.5/11; F(4,4) (default for k=7/11 in every stage) 3.5/7, 5.25/11 (merged accumulate launch: k=3 1.75/3 too); "
+                                   "F(4,3) (k=3) 1/2; F(4,4) (k=7/11 in every stage) 3.5/7, 5.25/11 (merged accumulate launch: k=3 1.75/3 too); "
                                    "F(2,3) (fall-back) 2/3, 5/7, 8/11; F(4,2) upsamplers 5/8; F(2,5) WN in_layers 3/5; everything else 1. "
                                    "achieved_direct_form/frac_direct_form = algorithmic direct-form 2*MAC (SURVEY.md 8d) / time, NOT bounded by the peak; "
                                    "winograd_form_floor_ms = executed FLOPs of one step at 157.3 TFLOP/s",

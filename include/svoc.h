@@ -73,7 +73,7 @@ int svoc_stats_reset(void);
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches);
 int64_t svoc_stats_convolutions(void);
 /* 2 x the multiply-adds the matrix pipe ISSUED for those launches: equal to conv_flops for direct-form kernels; per Winograd
- * form, as a share of the direct form for k = 3 / 7 / 11: F(4,3) (the default for every ResBlock convolution) 1/2, 4/7, 6.5/11;
+ * form, as a share of the direct form for k = 3 / 7 / 11: F(4,3) (k = 3) 1/2;
  * F(4,4) (default for k = 7 / 11 of every F(4,3)-eligible shape; four-tap groups in seven products) 3.5/7, 5.25/11;
  * F(2,3) (fall-back) 2/3, 5/7, 8/11; F(4,2) (upsamplers, k = 2 stride) 5/8; F(2,5) (WN in_layers, k = 5) 3/5.
  * bench.py's roofline.achieved / frac is this / time (/ peak). */
@@ -299,7 +299,7 @@ int svoc_conv1d(void* stream, const float* x, const float* weight_v, const float
  * and L % 4 == 0, computed in Winograd form: F(4,3) (csrc/conv_wino4.hip: Cout in 128- / 64-row blocks with an even number of
  * 32-channel chunks, or the single 32 x 32 block of the last MRF stage) - what every ResBlock convolution of the decoder runs -
  * with k = 7 / 11 of EVERY F(4,3)-eligible shape (128-, 64- and 32-row blocks alike) in F(4,4) form (csrc/conv_wino4.h,
- * instantiated in csrc/conv_wino44_r{4,2,1}.hip; SVOC_W4_F44=0: F(4,3) for every kernel size);
+ * instantiated in csrc/conv_wino44_r{4,2,1}.hip);
  * F(2,3) (csrc/conv_wino.hip) for the other shapes and with SVOC_WINO_F4=0.  svoc_stats_executed_flops tells which form ran.
  * (Inside the decoder the grouped launches additionally hand tensors over window-major between a dilated convolution and the one
  * behind it, and merge the three chains' last convolutions: csrc/conv_wino4.hip, csrc/conv_wino4_acc.hip - not reachable from here.)

@@ -76,11 +76,8 @@ bool wino4_enabled() {
   static const bool on = !(getenv("SVOC_WINO_F4") && atoi(getenv("SVOC_WINO_F4")) == 0);      // SVOC_WINO_F4=0: the F(2,3) kernels
   return on;
 }
-// SVOC_W4_F44=0: k = 7 / 11 in F(4,3) form as well (six-product groups + left-over taps) instead of F(4,4)
-bool wino44_enabled() {
-  static const bool on = wino4_enabled() && !(getenv("SVOC_W4_F44") && atoi(getenv("SVOC_W4_F44")) == 0);
-  return on;
-}
+// k = 7 / 11 run in F(4,4) form wherever the F(4,3) family applies (the F(4,3) form of those kernel sizes was an A/B arm until round 5)
+bool wino44_enabled() { return wino4_enabled(); }
 // SVOC_W4_C32=0: the C = 32 stage keeps the fused direct-form ResBlock kernel (resblock_fused.hip)
 bool wino4_c32_enabled() {
   static const bool on = wino4_enabled() && !(getenv("SVOC_W4_C32") && atoi(getenv("SVOC_W4_C32")) == 0);
@@ -98,25 +95,25 @@ unsigned wino4_grid(long long total) { return (unsigned)std::min<long long>(tota
 // the instantiations, one translation unit per row-tile layout and form (conv_wino4_launch.h)
 template <int NRT, bool F44> int wino4_launch_nrt(const WinoArgs& w, int K, int D, long long total, hipStream_t st);
 template <int NRT, bool F44> int wino4_launch_group_nrt(const WinoGroup& g, int D, int in_perm, int out_perm, long long total, hipStream_t st);
-#define SVOC_W4_EXTERN(NRT, F44)                                                                                          \
-  extern template int wino4_launch_nrt<NRT, F44>(const WinoArgs&, int, int, long long, hipStream_t);                      \
-  extern template int wino4_launch_group_nrt<NRT, F44>(const WinoGroup&, int, int, int, long long, hipStream_t);
-SVOC_W4_EXTERN(4, false) SVOC_W4_EXTERN(2, false) SVOC_W4_EXTERN(1, false) SVOC_W4_EXTERN(4, true) SVOC_W4_EXTERN(2, true) SVOC_W4_EXTERN(1, true)
+#define SVOC_W4_EXTERN(NRT)                                                                                               \
+  extern template int wino4_launch_nrt<NRT, false>(const WinoArgs&, int, int, long long, hipStream_t);                    \
+  extern template int wino4_launch_nrt<NRT, true>(const WinoArgs&, int, int, long long, hipStream_t);                     \
+  extern template int wino4_launch_group_nrt<NRT, true>(const WinoGroup&, int, int, int, long long, hipStream_t);
+SVOC_W4_EXTERN(4) SVOC_W4_EXTERN(2) SVOC_W4_EXTERN(1)
 #undef SVOC_W4_EXTERN
-#define SVOC_W4_BY_LAYOUT(FN, ...)                                                                                        \
-  (f44 ? (NRT == 4 ? FN<4, true>(__VA_ARGS__) : (NRT == 2 ? FN<2, true>(__VA_ARGS__) : FN<1, true>(__VA_ARGS__)))         \
-       : (NRT == 4 ? FN<4, false>(__VA_ARGS__) : (NRT == 2 ? FN<2, false>(__VA_ARGS__) : FN<1, false>(__VA_ARGS__))))
 
-// f44: the weight image is in F(4,4) form (k = 7 / 11)
+// f44: the weight image is in F(4,4) form (k = 7 / 11); k = 3: F(4,3)
 int wino4_launch(const WinoArgs& w, int K, int D, int NRT, bool f44, long long total, hipStream_t st) {
-  if (f44 && K < 7) return 1;
-  return SVOC_W4_BY_LAYOUT(wino4_launch_nrt, w, K, D, total, st);
+  if (f44 != (K >= 7)) return 1;
+  if (f44) return NRT == 4 ? wino4_launch_nrt<4, true>(w, K, D, total, st) : (NRT == 2 ? wino4_launch_nrt<2, true>(w, K, D, total, st) : wino4_launch_nrt<1, true>(w, K, D, total, st));
+  return NRT == 4 ? wino4_launch_nrt<4, false>(w, K, D, total, st) : (NRT == 2 ? wino4_launch_nrt<2, false>(w, K, D, total, st) : wino4_launch_nrt<1, false>(w, K, D, total, st));
 }
 // in_perm (D = 1): 0, or the dilation of the convolutions that wrote the members' inputs window-major; out_perm (D > 1): nonzero =
-// the members write window-major
+// the members write window-major.  Members k = 11 / 7 in F(4,4) form, k = 3 in F(4,3)
 int wino4_launch_group(const WinoGroup& g, int D, int NRT, int in_perm, int out_perm, bool f44, long long total, hipStream_t st) {
-  return SVOC_W4_BY_LAYOUT(wino4_launch_group_nrt, g, D, in_perm, out_perm, total, st);
+  if (!f44) return 1;
+  return NRT == 4 ? wino4_launch_group_nrt<4, true>(g, D, in_perm, out_perm, total, st)
+                  : (NRT == 2 ? wino4_launch_group_nrt<2, true>(g, D, in_perm, out_perm, total, st) : wino4_launch_group_nrt<1, true>(g, D, in_perm, out_perm, total, st));
 }
-#undef SVOC_W4_BY_LAYOUT
 
 }  // namespace svoc

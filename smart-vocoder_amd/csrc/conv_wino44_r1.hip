@@ -5,5 +5,5 @@
 #include "conv_wino4_launch.h"
 
 namespace svoc {
-SVOC_W4_INSTANTIATE(1, true)
+SVOC_W4_INSTANTIATE_F44(1)
 }  // namespace svoc

@@ -349,8 +349,8 @@ int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, bool f44, long lo
   g.a[0].flags |= a[2].flags & F_DIV;                       // the division by the number of chains rides on the last member
   g.a[0].div = a[2].div;
   g.total = (int)total;
-#define SVOC_W4M(P) (f44 ? (NRT == 4 ? acc3_launch_n<4, P, true>(g, st) : (NRT == 2 ? acc3_launch_n<2, P, true>(g, st) : acc3_launch_n<1, P, true>(g, st))) \
-                         : (NRT == 4 ? acc3_launch_n<4, P>(g, st) : (NRT == 2 ? acc3_launch_n<2, P>(g, st) : acc3_launch_n<1, P>(g, st))))
+  if (!f44) return 1;                                      // (the F(4,3) form of the merged launch went with SVOC_W4_F44 in round 5)
+#define SVOC_W4M(P) (NRT == 4 ? acc3_launch_n<4, P, true>(g, st) : (NRT == 2 ? acc3_launch_n<2, P, true>(g, st) : acc3_launch_n<1, P, true>(g, st)))
   if (in_perm == 5) return SVOC_W4M(5);
   if (in_perm == 3) return SVOC_W4M(3);
   return SVOC_W4M(0);

@@ -662,9 +662,7 @@ bool wino4_pair_enabled() {
 // tiles a launch would have (the engine's size gate)
 bool wino44_enabled();
 long long wino4_pair_tiles(int C, int L, int B, int D1) {
-  const int w = wino44_enabled()
-                    ? (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1, true>::W2 : (D1 == 3 ? PairGeo<11, 3, 1, true>::W2 : PairGeo<11, 5, 1, true>::W2)) : PairGeo<11, 1, 2, true>::W2)
-                    : (C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1>::W2 : (D1 == 3 ? PairGeo<11, 3, 1>::W2 : PairGeo<11, 5, 1>::W2)) : PairGeo<11, 1, 2>::W2);
+  const int w = C == 32 ? (D1 == 1 ? PairGeo<11, 1, 1, true>::W2 : (D1 == 3 ? PairGeo<11, 3, 1, true>::W2 : PairGeo<11, 5, 1, true>::W2)) : PairGeo<11, 1, 2, true>::W2;
   return 3LL * B * ((L + w - 1) / w);
 }
 // The three chains' c1 (dilation D1) -> c2 pairs of one MRF step at C = 32 / 64; members k = 11, 7, 3.  1 = not eligible.
@@ -672,7 +670,7 @@ long long wino4_pair_tiles(int C, int L, int B, int D1) {
 // and k = 3 members, the last one dividing by `div` (the number of chains)
 int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2, const float* const* x, float* const* y, long long bs, int ld,
                       int B, int L, int D1, float slope, hipStream_t st, int accum, float div) {
-  if (!wino4_pair_enabled() || B <= 0 || (L & 3) || (ld & 3) || (bs & 3) || !(D1 == 1 || D1 == 3 || D1 == 5)) return 1;
+  if (!wino4_pair_enabled() || !wino44_enabled() || B <= 0 || (L & 3) || (ld & 3) || (bs & 3) || !(D1 == 1 || D1 == 3 || D1 == 5)) return 1;
   if (accum && (!wino44_enabled() || y[0] != y[1] || y[1] != y[2] || !(div > 0.f))) return 1;
   if (64LL * ld * 4 >= (1LL << 31)) return 1;               // the producers' staging loads: 32-bit offsets within one batch element
   static const int ks[3] = {11, 7, 3};
@@ -712,7 +710,7 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
 #define SVOC_W4P(F) (C == 32 ? (D1 == 1 ? pair_launch_d<1, 1, F>(g, st) : (D1 == 3 ? pair_launch_d<3, 1, F>(g, st) : pair_launch_d<5, 1, F>(g, st))) \
                              : pair_launch_d<1, 2, F>(g, st))
   const int rc = accum ? (D1 == 1 ? pairacc_launch_d<1, true>(g, st) : (D1 == 3 ? pairacc_launch_d<3, true>(g, st) : pairacc_launch_d<5, true>(g, st)))
-                       : (wino44_enabled() ? SVOC_W4P(true) : SVOC_W4P(false));
+                       : SVOC_W4P(true);
 #undef SVOC_W4P
   prof_end(st, prof_idx);
   if (rc != SVOC_OK) return rc < 0 ? rc : SVOC_ERR_UNSUPPORTED;

@@ -2,5 +2,5 @@
 #include "conv_wino4_launch.h"
 
 namespace svoc {
-SVOC_W4_INSTANTIATE(1, false)
+SVOC_W4_INSTANTIATE_K3(1)
 }  // namespace svoc

@@ -2,5 +2,5 @@
 #include "conv_wino4_launch.h"
 
 namespace svoc {
-SVOC_W4_INSTANTIATE(2, false)
+SVOC_W4_INSTANTIATE_K3(2)
 }  // namespace svoc

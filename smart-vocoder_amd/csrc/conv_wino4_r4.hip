@@ -2,5 +2,5 @@
 #include "conv_wino4_launch.h"
 
 namespace svoc {
-SVOC_W4_INSTANTIATE(4, false)
+SVOC_W4_INSTANTIATE_K3(4)
 }  // namespace svoc

@@ -110,9 +110,9 @@ def _wino_f4_expected(C, co, k, d, L):
 
 def _wino_f44_expected(C, co, k, d, L):
     """F(4,4) (conv_wino4.h, round 4): every shape the F(4,3) kernels take runs k = 7 / 11 as four-tap groups in seven products each,
-    no left-over taps; k = 3 stays F(4,3).  SVOC_W4_F44=0: F(4,3) everywhere."""
+    no left-over taps; k = 3 stays F(4,3)."""
     import os
-    return _wino_f4_expected(C, co, k, d, L) and os.environ.get("SVOC_W4_F44") != "0" and k >= 7
+    return _wino_f4_expected(C, co, k, d, L) and k >= 7
 
 
 @pytest.mark.parametrize("C,co,k,d,L,B,res", [(128, 128, 3, 1, 4096, 2, True), (128, 128, 7, 1, 1000, 3, True), (128, 128, 11, 1, 4100, 1, False),

@@ -3,14 +3,13 @@ reads once per process, so each variant runs a slice of the parity suite in a su
 choice is listed here (tests/test_abi.py::test_every_kernel_switch_has_a_variant_run checks the two lists against each other).  Round 5
 removed the switches (and the code) that only an environment variable could reach - A/B arms whose verdict is recorded in DESIGN.md:
 SVOC_W4_{ACCUM,ACC3,PERM,PRIO,PAIR,PAIR64}, SVOC_FUSE_V, SVOC_FUSE64, SVOC_WINO_WS, SVOC_WINO_WM, SVOC_WN_CT, SVOC_WN_KSPLIT, SVOC_LN_V2,
-SVOC_XCD, SVOC_CT_ROWS256, SVOC_CT_TAIL, SVOC_STREAMS (kernels those arms shared with a shape-reachable path are covered by shape:
+SVOC_XCD, SVOC_CT_ROWS256, SVOC_CT_TAIL, SVOC_STREAMS, SVOC_W4_F44 (kernels those arms shared with a shape-reachable path are covered by shape:
 tests/test_gpu_parity.py::test_fallback_shapes).
 
   SVOC_FUSE=0 SVOC_FUSE_WN=0     unfused fallbacks: two convolutions per ResBlock iteration / WN layer (any shape the fused kernels refuse)
   SVOC_GROUP=0                   MRF chains on separate streams for every stage (chains that disagree on the dilation order; short inputs)
   SVOC_WINO=0                    direct-form kernels instead of Winograd (kernel sizes other than 3 / 7 / 11, dilations other than 1 / 3 / 5)
   SVOC_WINO_F4=0                 Winograd F(2,3) kernels instead of F(4,3) / F(4,4) (odd row-block counts, unaligned rows, L % 4 != 0)
-  SVOC_W4_F44=0                  k = 7 / 11 in F(4,3) form (six-product groups + left-over taps) instead of F(4,4)
   SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv (short inputs)
   SVOC_WN_SMALL_F25=0            short inputs: WN layers as two K-split convolutions instead of one launch per layer (wn_small.hip)
   SVOC_WN_STACK=0                WN stacks one launch per layer instead of one persistent launch per stack (more 32-column tiles than CUs; conditioning input)
@@ -43,7 +42,6 @@ VARIANTS = {
     "ungrouped": ({"SVOC_GROUP": "0"}, DEC),
     "no_winograd": ({"SVOC_WINO": "0"}, DEC),
     "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
-    "winograd_f43_for_k7_k11": ({"SVOC_W4_F44": "0"}, DEC),
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),
     "wn_one_launch_per_layer": ({"SVOC_WN_STACK": "0"}, WNS + " or test_c2_full_size_vs_oracle"),

@@ -21,7 +21,7 @@ for _ in range(int(os.environ.get("WBURST", "25"))): run()
 torch.cuda.synchronize(); N.check(lib.svoc_debug_set_stamp_buffer(None))
 D = buf.cpu().numpy(); D = D[D[:, 5] == 4]
 G = (k + 1) // 4; ND = G - 1; nm = (C // 32) * 16 * (6 * G + 4 * ND)
-if k >= 7 and os.environ.get("SVOC_W4_F44", "1") != "0" and os.environ.get("SVOC_WINO_F4") != "0": nm = (C // 32) * 16 * 7 * G      # F(4,4)
+if k >= 7 and os.environ.get("SVOC_WINO_F4") != "0": nm = (C // 32) * 16 * 7 * G      # F(4,4)
 tiles = D[:, 0]; tot = D[:, 1] / tiles; bar = D[:, 2] / tiles; mf = D[:, 3] / tiles; epi = D[:, 4] / tiles
 print(f"C={C} k={k} d={d}: {len(D)} workgroups x {tiles.mean():.1f} tiles; per tile (consumer wave 0), cycles: total {tot.mean():.0f} | barrier waits {bar.mean():.0f} | "
       f"MFMA streams {mf.mean():.0f} ({mf.mean() / nm:.1f} per MFMA, {nm} MFMAs) | epilogue {epi.mean():.0f} | rest {np.mean(tot - bar - mf - epi):.0f}")
