@@ -40,9 +40,8 @@ struct WnStackArgs {
   const WnStackLayer* layers;                           // [NL], in device memory (a by-value array indexed by the layer would be copied to scratch)
   int ksg2; int NL; int T;
   float* halo;                                          // [WNS_MAXL (layer)][tiles][2 (left edge, right edge)][H][2]: a slot is written ONCE per launch
-  int* ticket;                                          // tiles handed out so far    } zero when a launch starts: the LAST workgroup to leave a launch
-  int* exited;                                          // workgroups that have left   } clears the three of them for the next one (no memset node:
-  int* done;                                            // [tiles]: layers completed   } see launch_wn_stack_f25)
+  int* exited;                                          // [17] exit counters (two levels) } zero when a launch starts: the LAST workgroup to leave a launch
+  int* done;                                            // [tiles]: layers completed   } clears both for the next one (no memset node: see launch_wn_stack_f25)
   int* err;                                             // raised when a bounded wait gave up
   long long* dbg;
 };
@@ -63,14 +62,13 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
   const int kh = wave >= NPAIRS ? 1 : 0;                    // K half
   const int pi = wave - kh * NPAIRS;                        // row pair
   const int l31 = lane & 31;
-  // Tiles are handed out in the order in which the workgroups actually START (a ticket), not by block id: the started-and-unfinished tiles then
-  // always are a run of consecutive tiles whose predecessors have finished, and such a run of more than n_layers + one utterance's tiles makes progress
-  // whatever the hardware's dispatch order is.  (By block id, two processes on one GPU - each XCD serving its share of both launches - could hold each
-  // other's missing neighbours: observed as 30 s stalls ending in the error word.)
+  // Block -> tile through xcd_linear: the hardware deals workgroups to the eight XCDs round robin (block % 8), xcd_linear gives XCD c a CONTIGUOUS run of
+  // tiles, and an XCD starts its blocks in order - so the tiles an XCD holds at any time are consecutive, neighbours share an XCD (and its L2) except at
+  // seven seams (none at 16 x 512, where a run is two whole utterances), and on a shared GPU a run of more than n_layers resident tiles always finishes its
+  // low end and frees CUs.  (Plain block order put neighbours on different XCDs: two processes on one GPU then held each other's missing neighbours, 30 s
+  // stalls.  Tickets drawn from one device-wide counter were order-proof but cost 42 us per launch: 256 serialised device-scope atomics.)
   const int ntx = gridDim.x, ntiles = ntx * gridDim.z;
-  if (tid == 0) reinterpret_cast<int*>(RED)[0] = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const int gt = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(RED)[0]);
+  const int gt = xcd_linear((int)(blockIdx.x + gridDim.x * blockIdx.z), ntiles, 1);
   const int b = gt / ntx, tile = gt - b * ntx;
   const int t0 = tile * 32;
   const int NL = p.NL;
@@ -335,17 +333,18 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = fin[r] * mk;
     }
   }
-  // ---- leave: the last workgroup out clears the hand-shake state for the next launch (every other workgroup's counter traffic is behind its own
-  // increment of `exited`: release fence, then the increment)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  if (threadIdx.x == 0) reinterpret_cast<int*>(RED)[1] = __hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (reinterpret_cast<const int*>(RED)[1] == ntiles - 1) {
-    for (int i = threadIdx.x; i < ntiles; i += 768) __hip_atomic_store(p.done + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(p.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.exited, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- leave: the last workgroup out clears the hand-shake state for the next launch.  Thread 0 alone (it is the only one that writes counters):
+  // its counter stores acknowledged, then a TWO-LEVEL exit count - sixteen sub-counters by tile number, whose last arrivals count on a top counter -
+  // because 256 device-scope atomics on ONE word serialise at ~170 ns each (a single exit counter cost every launch 45 us).
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const int sub = gt & 15;
+    const int in_sub = (ntiles - sub + 15) >> 4, nsub = ntiles < 16 ? ntiles : 16;
+    if (__hip_atomic_fetch_add(p.exited + 1 + sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1) {
+      if (__hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1) {
+        for (int i = 0; i < ntiles; ++i) __hip_atomic_store(p.done + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 17; ++i) __hip_atomic_store(p.exited + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -356,7 +355,7 @@ bool wn_stack_enabled() {
   return on;
 }
 // scratch: halo buffer | per-tile layer counters | error word | (64-byte aligned) the layers' pointer table
-static size_t wn_stack_table_offset() { return (((size_t)WNS_MAXL * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 3) * sizeof(float) + 63) / 64 * 64; }
+static size_t wn_stack_table_offset() { return (((size_t)WNS_MAXL * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 20) * sizeof(float) + 63) / 64 * 64; }
 size_t wn_stack_scratch_bytes() { return wn_stack_table_offset() + WNS_MAXL * sizeof(WnStackLayer); }
 // The stack applies while every tile has a CU of its own (the workgroups wait for their neighbours) and the per-layer kernel would be the F(2,5) one.
 bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T) {
@@ -381,14 +380,13 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   a.ksg2 = rs_l[0]->ksg_total; a.NL = NL; a.T = T;
   const int ntx = (T + 31) / 32, ncu = device_cu_count();
   a.halo = scratch;
-  a.ticket = reinterpret_cast<int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2);
-  a.exited = a.ticket + 1;
-  a.done = a.ticket + 2;
+  a.exited = reinterpret_cast<int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2);      // [17]: top counter, sixteen sub-counters
+  a.done = a.exited + 17;
   a.err = a.done + ncu;
   a.dbg = nullptr;
   // The counters are NOT cleared by a memset ahead of the launch: a first version did that, and inside a captured plan replayed while another
-  // process shared the GPU the launch found them uncleared (tickets beyond the grid: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; before tickets
-  // existed: layer counters already raised, i.e. no waiting at all and edges of the launch before - which tests that repeat one input cannot see).
+  // process shared the GPU the launch found them uncleared (layer counters already raised, i.e. no waiting at all and edges of the launch before - which
+  // tests that repeat one input cannot see; a ticket counter tried at the time ran past the grid: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION).
   // The last workgroup to leave a launch clears them; kernel -> kernel order on the stream does the rest; wn_stack_prepare() zeroes them once.
   double flops = 0, exec = 0;
   for (int i = 0; i < NL; ++i) {
@@ -424,7 +422,7 @@ int wn_stack_error(const float* scratch, hipStream_t st) {
   if (!scratch) return 0;
   const int ncu = device_cu_count();
   int e = 0;
-  const int* err = reinterpret_cast<const int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2) + 2 + ncu;
+  const int* err = reinterpret_cast<const int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2) + 17 + ncu;
   if (hipMemcpyAsync(&e, err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
   if (hipStreamSynchronize(st) != hipSuccess) return -1;
   return e;
