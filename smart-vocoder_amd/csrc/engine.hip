@@ -36,7 +36,9 @@ struct WNStack {
   int H = 0, K = 0, DR = 1, NL = 0, gin = 0;
   std::vector<std::unique_ptr<PackedConv>> in_l, rs_l;
   std::vector<std::unique_ptr<DevBuf>> in_f25;            // in_layers in Winograd F(2,5) form where wn_fused.hip serves the shape
-  std::vector<std::unique_ptr<DevBuf>> rs16;              // res_skip layers 0 .. NL-2 as 16x16x4 A operands (wn_small.hip: short inputs)
+  std::vector<std::unique_ptr<DevBuf>> rs16;              // res_skip layers as 16x16x4 A operands (wn_small.hip: short inputs; the last one: wn_mesh.hip)
+  std::vector<std::unique_ptr<DevBuf>> in_mesh;           // in_layers in wn_mesh.hip's order (a permutation of in_f25)
+  DevBuf mesh_ws;                                           // wn_mesh.hip: x / acts hand-over rows, flags, error word, layer table
   std::unique_ptr<PackedConv> cond;
   DevBuf ws;
   DevBuf stack_ws;                                          // wn_stack.hip: halo buffer + per-tile layer counters + error word
@@ -55,11 +57,20 @@ struct WNStack {
       if (i < NL - 1) { rp.Cout = 2 * H; rp.split_at = H; } else { rp.Cout = H; }
       rs_l.emplace_back(new PackedConv());
       SVOC_TRY(pack_conv_named(*rs_l.back(), rp, tab, prefix + "res_skip_layers." + std::to_string(i), st));
-      if (i < NL - 1) {
-        rs16.emplace_back(new DevBuf());
-        if (K == 5 && d == 1) SVOC_TRY(pack_wn_rs16_named(*rs16.back(), H, rp.Cout, tab, prefix + "res_skip_layers." + std::to_string(i), st));
-      }
+      rs16.emplace_back(new DevBuf());
+      if (K == 5 && d == 1) SVOC_TRY(pack_wn_rs16_named(*rs16.back(), H, rp.Cout, tab, prefix + "res_skip_layers." + std::to_string(i), st));
+      in_mesh.emplace_back(new DevBuf());
+      if (K == 5 && d == 1) SVOC_TRY(pack_wn_mesh(*in_mesh.back(), in_f25.back()->f(), st));
       d *= DR;
+    }
+    if (wn_mesh_applies(H, K, DR, NL, 1, 32)) {      // (conditioned calls - g given - take the per-layer chain)
+      const PackedConv* il[16]; const float* wm[16]; const float* wr[16];
+      bool all = NL <= 16;
+      for (int i = 0; i < NL && all; ++i) { il[i] = in_l[i].get(); wm[i] = in_mesh[i]->f(); wr[i] = rs16[i]->f(); all = wm[i] != nullptr && wr[i] != nullptr; }
+      if (all) {
+        SVOC_TRY(mesh_ws.ensure(wn_mesh_scratch_bytes()));
+        SVOC_TRY(wn_mesh_prepare(mesh_ws.f(), il, wm, wr, NL, st));
+      }
     }
     if (gin > 0) {
       PackSpec cp{}; cp.Cin = gin; cp.Cout = 2 * H * NL; cp.K = 1;
@@ -109,6 +120,14 @@ struct WNStack {
     const float* src = x; long long src_bs = x_bs; int src_ld = x_ld;
     // Short inputs (wn_small.hip): ONE launch per layer - the previous layer's res_skip at the head of the kernel that computes the
     // F(2,5) in_layer and the gate - and the last layer's res_skip as a convolution behind the chain
+    // ... the shortest of them (at most ncu / 24 column tiles) as ONE persistent launch (wn_mesh.hip)
+    if (!g && mesh_ws.p && wn_layer_prefers_unfused(B, T) && wn_mesh_applies(H, K, DR, NL, B, T)) {
+      const PackedConv* il[16]; const PackedConv* rl[16];
+      for (int i = 0; i < NL; ++i) { il[i] = in_l[i].get(); rl[i] = rs_l[i].get(); }
+      const int r = launch_wn_mesh_f25(il, rl, NL, H, src, src_bs, src_ld, out, out_bs, out_ld, mask, mask_bs, mesh_ws.f(), B, T, st);
+      if (r < 0) return r;
+      if (r == 0) return SVOC_OK;
+    }
     {
       bool chain = wn_small_enabled() && wn_layer_prefers_unfused(B, T) && K == 5 && DR == 1;
       for (int i = 0; i < NL && chain; ++i) chain = in_f25[i]->p != nullptr && (i == NL - 1 || rs16[i]->p != nullptr);

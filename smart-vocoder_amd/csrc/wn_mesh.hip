@@ -1,0 +1,467 @@
+// A whole WN stack for SHORT inputs in ONE persistent launch (round 5, VERDICT r4 item 3: the 1 x 200 call; reference modules.py:148-176).
+//
+// Short inputs (wn_small.hip) ran a stack as one launch per layer, six workgroups per 32-column tile: 22 us per layer at 1 x 200, of which ~14 us are
+// matrix-pipe time of the ONE CU a workgroup owns (every one of the six recomputes the previous layer's 192 x 192 residual GEMM on 48 columns; the
+// F(2,5) in_layer of its 64 rows is 1152 MFMAs on three waves per SIMD) - with 42 of 256 CUs busy.  Here the layer is cut the other way and the cuts
+// talk to each other inside one launch:
+//   * TWELVE workgroups per 32-column tile; workgroup r owns channels 16 r .. 16 r + 15 of everything: the in_layer's tanh rows 16 r .. and sigmoid
+//     rows H + 16 r .., hence those rows of the gated acts; the res_skip's residual rows 16 r .. (x) and skip rows H + 16 r .. (out).  Nothing is
+//     recomputed: per layer a workgroup issues 576 + 192 MFMAs of v_mfma_f32_16x16x4_f32, its eight waves splitting the in_layer's K eight ways.
+//   * per layer two hand-overs through device memory instead of two launches: the acts rows (all twelve workgroups of a tile need all 192 rows for
+//     the 1 x 1) and the x rows (the twelve of the tile and of its two neighbours need them: the k = 5 halo).  Producer: device-coherent stores (sc1:
+//     write-through), s_waitcnt vmcnt(0), workgroup barrier, thread 0 raises the workgroup's flag.  Consumer: wave 0 polls the 12 (acts) or 36 (x)
+//     flags with ONE load per poll, barrier, sc1 loads of the tile.  No grid-wide barrier, no atomics on a shared word.
+//   * the layer's weights (72 + 48 registers per lane) are requested BEFORE the waits that precede their use - they are in flight while the
+//     workgroup polls.
+//   * the skip sum lives in registers for the whole stack; x rows in a double buffer by layer parity (the neighbour tile may still be reading
+//     x_{i-1} when this tile's x_i is ready; x_{i+1} is only written after the neighbour's acts of layer i-1, i.e. after its last read of x_{i-1});
+//     acts in a single buffer (a workgroup writes acts_i behind its tile's twelve x_i flags, each raised after that workgroup's last read of
+//     acts_{i-1}).
+// Every workgroup of the launch must be resident at once: the launcher takes the stack only while the grid is at most HALF the CUs (two
+// processes sharing a GPU then both fit; wn_stack.hip's bounded waits and error word otherwise).  Flags are cleared by the last workgroup out.
+// H = 192, k = 5, dilation 1, no conditioning input; n_layers >= 2.
+#include "svoc_internal.h"
+#include "wino_common.h"
+#include "wn_f25.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace svoc {
+
+constexpr int WNM_R = 12;                                   // workgroups per column tile
+constexpr int WNM_AROW = 48;                                // acts tile row stride (columns 0 .. 31 used; 48: the B reads of the 1 x 1 are conflict-free)
+constexpr int WNM_MAXL = 16;
+constexpr int WNM_LDS_FLOATS = WNF_H * WNF_XROW + 6 * WNF_PLANE;
+static_assert(WNF_H * WNM_AROW <= 6 * WNF_PLANE && 8 * 16 * 64 <= 6 * WNF_PLANE, "acts tile and reduction area alias the planes");
+
+struct WnMeshLayer {
+  const float* wm;                                       // in_layer: mesh image (pack_wn_mesh_kernel)
+  const float* bias1;                                    // its bias, paired tile order (PackedConv)
+  const float* wrs;                                      // res_skip: 16x16x4 image (pack_wn_rs16_kernel), bias in natural order behind it
+  int rs_tiles; int pad_;                                // 24 (last layer: 12) row tiles in that image
+};
+struct WnMeshArgs {
+  const float* x; long long x_bs; int x_ld;             // stack input [B][H][x_ld] (masked by the caller)
+  float* out; long long out_bs; int out_ld;             // the stack's output (skip sum * mask)
+  const float* mask; long long mask_bs;
+  const WnMeshLayer* layers;                            // [NL], device memory
+  int NL; int T; int ntx;
+  float* xg; int xg_ld; long long xg_bs; long long xg_par;   // x rows: [2 (layer parity)][B][H][xg_ld], column t at 4 + t (four zero columns either side)
+  float* ag; int ag_ld; long long ag_bs;                // acts rows: [B][H][32 ntx]
+  int* fa; int* fx;                                     // [tiles][12]: acts layers written / x layers written
+  int* exited; int* err;                                // [17] two-level exit count; error word
+};
+
+typedef unsigned int wnm_u32x4 __attribute__((ext_vector_type(4)));
+
+// device-coherent (sc1) 16-byte load / 4-byte store through a buffer descriptor: what another XCD's workgroup wrote is read from memory, not from
+// this XCD's L2 (aux bit 4 = sc1 on gfx94x / gfx950)
+__device__ __forceinline__ float4 wnm_ld16_sc1(const __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  const wnm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16);
+  return *reinterpret_cast<const float4*>(&t);
+}
+__device__ __forceinline__ void wnm_st4_sc1(const __amdgpu_buffer_rsrc_t rs, float v, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 16);
+}
+
+// wave 0: wait until the `n` flags f[0 .. n) (lanes with valid == false excepted) have reached `want`; bounded by 30 s of wall time
+__device__ __forceinline__ void wnm_wait(const int* f, int n, bool valid, int want, int* err) {
+  const int lane = threadIdx.x & 63;
+  const bool mine = lane < n && valid;
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  while (true) {
+    const int v = mine ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+    if (__builtin_amdgcn_ballot_w64(v < want) == 0) break;
+    __builtin_amdgcn_s_sleep(1);
+    if (__builtin_amdgcn_s_memrealtime() - t_start > 3000000000ull) {
+      if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
+  constexpr int H = WNF_H, XROW = WNF_XROW, PLANE = WNF_PLANE, NQ = WNF_NQ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const XT = lds;                                    // x_i tile [H][40]: columns t0 - 4 .. t0 + 35
+  float* const PLN = lds + H * XROW;                        // V_p [6][H][16]
+  float* const AT = PLN;                                    // acts tile [H][48] (columns t0 .. t0 + 31), between the layers
+  float* const RED = PLN;                                   // [8 waves][16][64] partial outputs, behind the stream
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  const int g = xcd_linear((int)blockIdx.x, nwg, 1);       // consecutive workgroups (a tile's twelve, neighbouring tiles) on one XCD
+  const int gt = g / WNM_R, r = g - gt * WNM_R;
+  const int ntx = p.ntx, ntiles = nwg / WNM_R;
+  const int b = gt / ntx, tile = gt - b * ntx;
+  const int t0 = tile * 32;
+  const int NL = p.NL, T = p.T;
+  const __amdgpu_buffer_rsrc_t xg_rs = __builtin_amdgcn_make_buffer_rsrc(p.xg, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ag_rs = __builtin_amdgcn_make_buffer_rsrc(p.ag, 0, 0x7fffffff, 0x00020000);
+  const int rt2 = wave & 1, nt = (wave >> 1) & 1;           // the 1 x 1: waves 0 .. 3 = (residual | skip tile, column half)
+  float skip[4] = {0.f, 0.f, 0.f, 0.f};                     // waves 1, 3: out rows 16 r + 4 k4 + i, column t0 + 16 nt + col
+
+  auto uni = [](const float* q) -> const float* {
+    const unsigned long long u = (unsigned long long)q;
+    return reinterpret_cast<const float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+  };
+
+  // the in_layer weights of this wave: 18 sixteen-byte loads = the A operands of its 72 MFMAs (in flight across the waits)
+  float4 wv[18];
+  auto request_in = [&](int li) {
+    const float* wm = uni(p.layers[li].wm);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wm), 0, 0x7fffffff, 0x00020000);
+    const int w0 = __builtin_amdgcn_readfirstlane((r * 8 + wave) * 18 * 1024);
+    const int vo = (int)(threadIdx.x & 63) * 16;
+#pragma unroll
+    for (int l = 0; l < 18; ++l) {
+      const wnm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, w0 + l * 1024, 0);
+      wv[l] = *reinterpret_cast<const float4*>(&t);
+    }
+  };
+  request_in(0);
+
+  for (int li = 0; li <= NL; ++li) {
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                          // (per-layer addresses are rebuilt, not hoisted and kept live: wn_stack.hip)
+    const int tid = tid_, lane = tid & 63;
+    const int col = lane & 15, k4 = lane >> 4;
+
+    // =============================================================== res_skip of layer li - 1
+    if (li > 0) {
+      const bool last = li == NL;                           // the last layer's 1 x 1 has H rows, all of them skip
+      const WnMeshLayer lp = p.layers[li - 1];
+      const float* wrs = uni(lp.wrs);
+      const int rs_tiles = __builtin_amdgcn_readfirstlane(lp.rs_tiles);
+      float4 aw[12];
+      const bool gemm_wave = wave < 4 && (rt2 == 1 || !last);
+      if (gemm_wave) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wrs), 0, 0x7fffffff, 0x00020000);
+        const int ti = (rt2 == 1 && !last) ? WNM_R + r : r;
+        const int wb = __builtin_amdgcn_readfirstlane(ti * 12 * 1024);
+#pragma unroll
+        for (int ks4 = 0; ks4 < 12; ++ks4) {
+          const wnm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, wb + ks4 * 1024, 0);
+          aw[ks4] = *reinterpret_cast<const float4*>(&t);
+        }
+      }
+      if (wave == 0) wnm_wait(p.fa + gt * WNM_R, WNM_R, true, li, p.err);
+      __syncthreads();
+      {   // acts_{li-1} tile: H rows x 32 columns = 1536 sixteen-byte groups, three per thread
+        const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)b * p.ag_bs + t0) * 4));
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int it = tid + 512 * u;
+          const int c = it >> 3, g4 = it & 7;
+          const float4 q = wnm_ld16_sc1(ag_rs, (c * p.ag_ld + 4 * g4) * 4, sb);
+          *reinterpret_cast<float4*>(AT + c * WNM_AROW + 4 * g4) = q;
+        }
+      }
+      __syncthreads();
+      if (gemm_wave) {
+        wn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* bp = AT + k4 * WNM_AROW + 16 * nt + col;
+#pragma unroll
+        for (int ks4 = 0; ks4 < 12; ++ks4) {
+          const float4 a = aw[ks4];
+          const float* bq = bp + 16 * ks4 * WNM_AROW;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[4 * WNM_AROW], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[8 * WNM_AROW], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[12 * WNM_AROW], acc, 0, 0, 0);
+        }
+        const float* rsbias = wrs + rs_tiles * 12 * 256;
+        const int t = t0 + 16 * nt + col;
+        if (rt2 == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) skip[i] += acc[i] + rsbias[(last ? 0 : H) + 16 * r + 4 * k4 + i];
+        } else {   // x_li = (x_{li-1} + rs) * mask: this workgroup's sixteen rows of the centre columns -> the buffer of parity li
+          const float mk = t < T ? p.mask[(long long)b * p.mask_bs + t] : 0.f;
+          const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)(li & 1) * p.xg_par + (long long)b * p.xg_bs + 4 + t0) * 4));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ch = 16 * r + 4 * k4 + i;
+            const float v = (XT[ch * XROW + 4 + 16 * nt + col] + (acc[i] + rsbias[ch])) * mk;
+            wnm_st4_sc1(xg_rs, v, (ch * p.xg_ld + 16 * nt + col) * 4, sb);
+          }
+        }
+      }
+      if (last) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the x stores are acknowledged (write-through) ...
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.fx + gt * WNM_R + r, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
+    }
+
+    // =============================================================== in_layer + gate of layer li
+    if (li == 0) {   // the stack's input: all H channels, columns [t0 - 4, t0 + 36), zero outside [0, T)
+      constexpr int R4 = XROW / 4, total = H * R4;
+      const float* xb = p.x + (long long)b * p.x_bs;
+      const bool vec = ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (p.x_ld & 3) == 0 && (p.x_bs & 3) == 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = tid + 512 * u;
+        if (it < total) {
+          const int c = it / R4, g4 = it - c * R4;
+          const int t = t0 - 4 + 4 * g4;
+          const float* row = xb + (long long)c * p.x_ld;
+          float4 q;
+          if (vec && t >= 0 && t + 3 < T) q = *reinterpret_cast<const float4*>(row + t);
+          else {
+            q.x = (t >= 0 && t < T) ? row[t] : 0.f;
+            q.y = (t + 1 >= 0 && t + 1 < T) ? row[t + 1] : 0.f;
+            q.z = (t + 2 >= 0 && t + 2 < T) ? row[t + 2] : 0.f;
+            q.w = (t + 3 >= 0 && t + 3 < T) ? row[t + 3] : 0.f;
+          }
+          *reinterpret_cast<float4*>(XT + c * XROW + 4 * g4) = q;
+        }
+      }
+    } else {
+      if (wave == 0) {   // x_li of this tile's and the two neighbours' workgroups: 36 flags, one load per poll
+        const int d = lane / WNM_R - 1;
+        const bool valid = lane < 3 * WNM_R && tile + d >= 0 && tile + d < ntx;
+        wnm_wait(p.fx + (gt - 1) * WNM_R, 3 * WNM_R, valid, li, p.err);
+      }
+      __syncthreads();
+      constexpr int R4 = XROW / 4, total = H * R4;        // 1920 sixteen-byte groups; buffer column 4 + t <-> tile column t - t0 + 4
+      const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)(li & 1) * p.xg_par + (long long)b * p.xg_bs + t0) * 4));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = tid + 512 * u;
+        if (it < total) {
+          const int c = it / R4, g4 = it - c * R4;
+          float4 q = wnm_ld16_sc1(xg_rs, (c * p.xg_ld + 4 * g4) * 4, sb);
+          // the four columns left of the first tile / right of the last one are the convolution's zero padding (the buffer's pad columns are not
+          // relied upon: with another (B, T) the same words are data columns)
+          if ((g4 == 0 && tile == 0) || (g4 == R4 - 1 && tile == ntx - 1)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(XT + c * XROW + 4 * g4) = q;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- input transform (wn_fused.hip): window q of channel c reads tile columns 2q + 2 .. 2q + 7
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int c = (tid >> 4) + 32 * u, q = tid & 15;
+      const float* rp = XT + c * XROW + 2 * q + 2;
+      const float2 f0 = *reinterpret_cast<const float2*>(rp), f1 = *reinterpret_cast<const float2*>(rp + 2), f2 = *reinterpret_cast<const float2*>(rp + 4);
+      const float d0 = f0.x, d1 = f0.y, d2 = f1.x, d3 = f1.y, d4 = f2.x, d5 = f2.y;
+      const float a_ = __builtin_fmaf(-4.f, d2, d4), b_ = __builtin_fmaf(-4.f, d1, d3);
+      const float c_ = d4 - d2, e_ = 2.f * (d3 - d1);
+      float* o = PLN + c * NQ + q;
+      o[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+      o[PLANE] = a_ + b_;
+      o[2 * PLANE] = a_ - b_;
+      o[3 * PLANE] = c_ + e_;
+      o[4 * PLANE] = c_ - e_;
+      o[5 * PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    }
+    __syncthreads();
+    // ---- the stream: this wave's 24 channels (six k-steps) x six products x (tanh tile, sigmoid tile) = 72 MFMAs; 36 fragment reads two ahead
+    wn_f32x4 M[2][6];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) M[tl][q] = (wn_f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int NST = 36;
+      const unsigned baddr = (unsigned)(size_t)PLN + (unsigned)(((24 * wave + k4) * NQ + col) * 4);
+      float fb[2];
+      auto rdb = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        if constexpr (I < NST) {
+          constexpr int KS_ = I / 6, P_ = I % 6;
+          fb[I & 1] = wino_lds_rd<(P_ * PLANE + KS_ * 4 * NQ) * 4>(baddr);
+        }
+      };
+      auto step = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int P_ = I % 6;
+        {
+          float& bq = fb[I & 1];
+          if constexpr (I + 1 < NST) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq));
+        }
+        const float4 av = wv[I / 2];
+        const float bv = fb[I & 1];
+        M[0][P_] = __builtin_amdgcn_mfma_f32_16x16x4f32(wino_pick(av, (2 * I) & 3), bv, M[0][P_], 0, 0, 0);
+        M[1][P_] = __builtin_amdgcn_mfma_f32_16x16x4f32(wino_pick(av, (2 * I + 1) & 3), bv, M[1][P_], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdb(std::integral_constant<int, I + 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      rdb(std::integral_constant<int, 0>{}); rdb(std::integral_constant<int, 1>{});
+      wino_static_for<0, NST>(step);
+    }
+    __syncthreads();                                         // every wave is done with the planes: the reduction area takes their place
+    // ---- output transform of the partial sums -> RED[wave][j][lane], j = 8 tile + 2 i + o
+    {
+      float* rm = RED + (wave * 16) * 64 + lane;
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float s12 = M[tl][1][i] + M[tl][2][i], d12 = M[tl][1][i] - M[tl][2][i];
+          const float s34 = M[tl][3][i] + M[tl][4][i], d34 = M[tl][3][i] - M[tl][4][i];
+          rm[(8 * tl + 2 * i) * 64] = M[tl][0][i] + (s12 + s34);
+          rm[(8 * tl + 2 * i + 1) * 64] = __builtin_fmaf(2.f, d34, d12) + M[tl][5][i];
+        }
+    }
+    __syncthreads();
+    // ---- reduction over the eight K parts + bias + gate: wave w takes (i, o) = (w / 2, w % 2) of every lane
+    {
+      const float* bias1 = uni(p.layers[li].bias1);
+      float vA = 0.f, vB = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        vA += RED[(w * 16 + wave) * 64 + lane];
+        vB += RED[(w * 16 + 8 + wave) * 64 + lane];
+      }
+      const int ch = 16 * r + 4 * k4 + (wave >> 1);
+      const int m = 2 * col + (wave & 1);
+      vA += bias1[64 * (ch >> 5) + (ch & 31)];
+      vB += bias1[64 * (ch >> 5) + 32 + (ch & 31)];
+      const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)b * p.ag_bs + t0) * 4));
+      wnm_st4_sc1(ag_rs, gate_tanh_sigmoid(vA, vB), (ch * p.ag_ld + m) * 4, sb);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(p.fa + gt * WNM_R + r, li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the next layer's weights are requested behind the flag: they travel while the flags of the others do (loads return in order - requested ahead
+    // of the flag they would hold back the s_waitcnt above, requested later they would hold back the acts tile)
+    if (li + 1 < NL) request_in(li + 1);
+  }
+
+  // ---- out = skip sum * mask (modules.py:175): rows 16 r + 4 k4 + i, columns t0 + 16 nt + col
+  if (wave < 4 && rt2 == 1) {
+    const int lane = threadIdx.x & 63, col = lane & 15, k4 = lane >> 4;
+    const int t = t0 + 16 * nt + col;
+    if (t < T) {
+      const float mk = p.mask[(long long)b * p.mask_bs + t];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p.out[(long long)b * p.out_bs + (long long)(16 * r + 4 * k4 + i) * p.out_ld + t] = skip[i] * mk;
+    }
+  }
+  // ---- leave: the last workgroup out clears the flags for the next launch (two-level exit count: wn_stack.hip)
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int sub = g & 15;
+    const int in_sub = (nwg - sub + 15) >> 4, nsub = nwg < 16 ? nwg : 16;
+    if (__hip_atomic_fetch_add(p.exited + 1 + sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1) {
+      if (__hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1) {
+        for (int i = 0; i < ntiles * WNM_R; ++i) {
+          __hip_atomic_store(p.fa + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.fx + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int i = 0; i < 17; ++i) __hip_atomic_store(p.exited + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// Mesh image of one in_layer from its F(2,5) image (pack_wn_f25_kernel: [pair 6][K half 2][k-step 24][product 6][lane 64][row tile 4]): a pure
+// permutation.  [workgroup r 12][wave 8][load 18][lane 64][4]: component f = 4 load + j of lane (k4, rr) is U_prod[tile * H + 16 r + rr][24 wave + 4 ks + k4]
+// with ks = f / 12, prod = (f % 12) / 2, tile = f % 2 (0: tanh row, 1: sigmoid row) - the order the stream consumes them in.
+__global__ void pack_wn_mesh_kernel(const float* __restrict__ f25, float* __restrict__ img, int total) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int j = e & 3, lane = (e >> 2) & 63;
+  int rest = e >> 8;
+  const int l = rest % 18; rest /= 18;
+  const int w = rest & 7, r = rest >> 3;
+  const int f = 4 * l + j, ks = f / 12, prod = (f % 12) >> 1, tl = f & 1;
+  const int c = 16 * r + (lane & 15), chan = 24 * w + 4 * ks + (lane >> 4);
+  const int pi = c >> 5, rt = (tl << 1) | ((c & 31) >> 4), kh = chan / 96, ks24 = (chan % 96) >> 2;
+  // (chan & 3) == lane >> 4 and c & 15 == lane & 15: the lane is the same in both images
+  img[e] = f25[(((((long long)pi * 2 + kh) * WNF_KS + ks24) * 6 + prod) * 64 + lane) * 4 + rt];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool wn_mesh_enabled() {
+  static const bool on = wn_f25_enabled() && !(getenv("SVOC_WN_MESH") && atoi(getenv("SVOC_WN_MESH")) == 0);      // SVOC_WN_MESH=0: one launch per layer (wn_small.hip)
+  return on;
+}
+static int wnm_max_tiles() { return device_cu_count() / 2 / WNM_R; }
+// scratch: x rows (two parities) | acts rows | flags fa, fx | exit counters [17] | error word | (64-byte aligned) layer table
+static size_t wnm_x_floats() { const int mt = wnm_max_tiles(); return (size_t)2 * WNF_H * (32 * mt + 8 * mt); }      // every utterance's rows carry 8 pad columns; B <= tiles
+static size_t wnm_a_floats() { return (size_t)WNF_H * 32 * wnm_max_tiles(); }
+static size_t wnm_flag_offset() { return (wnm_x_floats() + wnm_a_floats()) * sizeof(float); }
+static size_t wnm_table_offset() { return (wnm_flag_offset() + ((size_t)2 * WNM_R * wnm_max_tiles() + 18) * sizeof(int) + 63) / 64 * 64; }
+size_t wn_mesh_scratch_bytes() { return wnm_table_offset() + WNM_MAXL * sizeof(WnMeshLayer); }
+size_t wn_mesh_image_floats() { return (size_t)WNM_R * 8 * 18 * 256; }
+bool wn_mesh_applies(int H, int K, int dil_rate, int NL, int B, int T) {
+  if (!wn_mesh_enabled() || H != WNF_H || K != 5 || dil_rate != 1 || NL < 2 || NL > WNM_MAXL || B <= 0 || T <= 0) return false;
+  const long long tiles = (long long)std::max(B, variant_batch(B)) * ((T + 31) / 32);
+  return tiles <= wnm_max_tiles();
+}
+int pack_wn_mesh(DevBuf& img, const float* f25, hipStream_t st) {
+  if (!wn_mesh_enabled() || !f25) return SVOC_OK;
+  const int total = (int)wn_mesh_image_floats();
+  SVOC_TRY(img.ensure((size_t)(total + 1024) * sizeof(float)));
+  hipLaunchKernelGGL(pack_wn_mesh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f25, img.f(), total);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+// Zeroes the scratch area (pad columns, flags, counters) and writes the layer table (once, when the WN module is created)
+int wn_mesh_prepare(float* scratch, const PackedConv* const* in_l, const float* const* wm, const float* const* wrs, int NL, hipStream_t st) {
+  if (!scratch || NL > WNM_MAXL || NL < 2) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "wn_mesh_prepare: bad arguments");
+  WnMeshLayer t[WNM_MAXL] = {};
+  for (int i = 0; i < NL; ++i) { t[i].wm = wm[i]; t[i].bias1 = in_l[i]->bias.f(); t[i].wrs = wrs[i]; t[i].rs_tiles = i == NL - 1 ? 12 : 24; }
+  SVOC_HIP(hipMemsetAsync(scratch, 0, wnm_table_offset(), st));
+  SVOC_HIP(hipMemcpyAsync(reinterpret_cast<char*>(scratch) + wnm_table_offset(), t, sizeof(t), hipMemcpyHostToDevice, st));
+  SVOC_HIP(hipStreamSynchronize(st));                      // `t` lives on this stack frame
+  return SVOC_OK;
+}
+// 1 = not eligible (the caller runs the per-layer chain)
+int launch_wn_mesh_f25(const PackedConv* const* in_l, const PackedConv* const* rs_l, int NL, int H, const float* x, long long x_bs, int x_ld, float* out,
+                       long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st) {
+  if (!scratch || !wn_mesh_applies(H, in_l[0]->ktaps, 1, NL, B, T)) return 1;
+  for (int i = 0; i < NL; ++i) {
+    const bool last = i == NL - 1;
+    if (!in_l[i]->paired || in_l[i]->Cin != H || in_l[i]->Cout != 2 * H || in_l[i]->ktaps != 5 || in_l[i]->dil != 1 || rs_l[i]->Cin != H || rs_l[i]->ktaps != 1 ||
+        (last ? rs_l[i]->Cout != H : rs_l[i]->Cout != 2 * H)) return 1;
+  }
+  WnMeshArgs a{};
+  a.x = x; a.x_bs = x_bs; a.x_ld = x_ld;
+  a.out = out; a.out_bs = out_bs; a.out_ld = out_ld;
+  a.mask = mask; a.mask_bs = mask_bs;
+  a.layers = reinterpret_cast<const WnMeshLayer*>(reinterpret_cast<const char*>(scratch) + wnm_table_offset());
+  a.NL = NL; a.T = T; a.ntx = (T + 31) / 32;
+  a.xg = scratch; a.xg_ld = 32 * a.ntx + 8; a.xg_bs = (long long)H * a.xg_ld; a.xg_par = a.xg_bs * B;
+  a.ag = scratch + wnm_x_floats(); a.ag_ld = 32 * a.ntx; a.ag_bs = (long long)H * a.ag_ld;
+  if ((size_t)2 * a.xg_par > wnm_x_floats() || (size_t)a.ag_bs * B > wnm_a_floats()) return 1;
+  a.fa = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + wnm_flag_offset());
+  a.fx = a.fa + WNM_R * wnm_max_tiles();
+  a.exited = a.fx + WNM_R * wnm_max_tiles();
+  a.err = a.exited + 17;
+  double flops = 0, exec = 0;
+  for (int i = 0; i < NL; ++i) {
+    flops += (in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;
+    exec += (0.6 * in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;
+  }
+  stats_add_conv(flops, 2 * NL, exec);
+  int prof_idx = -1;
+  if (prof_enabled()) {
+    char d[160];
+    snprintf(d, sizeof(d), "meshWN H%-4d k5  d1  N%-7d B%-3d %d layers, one launch, F(2,5)", H, T, B, NL);
+    prof_idx = prof_begin(st, d, flops);
+  }
+  auto kern = wn_mesh_f25_kernel;
+  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntx * B * WNM_R)), dim3(512), (size_t)WNM_LDS_FLOATS * sizeof(float), st, a);
+  prof_end(st, prof_idx);
+  SVOC_HIP(hipGetLastError());
+  return SVOC_OK;
+}
+int wn_mesh_error(const float* scratch, hipStream_t st) {
+  if (!scratch) return 0;
+  int e = 0;
+  const int* err = reinterpret_cast<const int*>(reinterpret_cast<const char*>(scratch) + wnm_flag_offset()) + 2 * WNM_R * wnm_max_tiles() + 17;
+  if (hipMemcpyAsync(&e, err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  return e;
+}
+
+}  // namespace svoc

@@ -318,9 +318,9 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
 // res_skip of a non-last layer (2H x H x 1) as A operands of v_mfma_f32_16x16x4_f32: [row tile 24][k-step group 12][lane][4]; lane =
 // (k4 = lane / 16, r = lane % 16) holds W[16 rt + r][16 ks4 + 4 j + k4] in component j; behind it the bias in natural order [2H].
 __global__ void pack_wn_rs16_kernel(const float* __restrict__ src, const float* __restrict__ scale, const float* __restrict__ bias,
-                                    float* __restrict__ img, int total) {
+                                    float* __restrict__ img, int total, int rows) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total + 2 * WNS_H) return;
+  if (e >= total + rows) return;
   if (e >= total) { img[e] = bias ? bias[e - total] : 0.f; return; }
   const int j = e & 3, lane = (e >> 2) & 63, ks4 = (e >> 8) % 12, rt = (e >> 8) / 12;
   const int row = 16 * rt + (lane & 15), ch = 16 * ks4 + 4 * j + (lane >> 4);
@@ -344,25 +344,26 @@ bool wn_small_enabled() {
   static const bool on = wn_f25_enabled() && !(getenv("SVOC_WN_SMALL_F25") && atoi(getenv("SVOC_WN_SMALL_F25")) == 0);
   return on;
 }
-// Image of `prefix` (a res_skip layer with 2H output rows of a WN with H = 192); leaves `img` empty when the kernel does not apply.
+// Image of `prefix` (a res_skip layer with 2H output rows of a WN with H = 192, or the last layer's with H rows: wn_mesh.hip); leaves `img`
+// empty when the kernel does not apply.
 int pack_wn_rs16_named(DevBuf& img, int H, int Cout, const TensorTable& tab, const std::string& prefix, hipStream_t st) {
-  if (!wn_small_enabled() || H != WNS_H || Cout != 2 * H) return SVOC_OK;
+  if (!wn_small_enabled() || H != WNS_H || (Cout != 2 * H && Cout != H)) return SVOC_OK;
   const svoc_tensor* w = tab.find(prefix + ".weight");
   const svoc_tensor* v = tab.find(prefix + ".weight_v");
   const svoc_tensor* g = tab.find(prefix + ".weight_g");
   const svoc_tensor* bs = tab.find(prefix + ".bias");
   const svoc_tensor* src = w ? w : v;
   if (!src || (!w && !g)) SVOC_FAIL(SVOC_ERR_MISSING_TENSOR, "missing tensor %s.weight / .weight_v / .weight_g", prefix.c_str());
-  if (src->ndim != 3 || src->shape[0] != 2 * H || src->shape[1] != H || src->shape[2] != 1) SVOC_FAIL(SVOC_ERR_SHAPE, "tensor %s has the wrong shape", src->name);
-  const int total = 24 * 12 * 256;
-  SVOC_TRY(img.ensure((size_t)(total + 2 * H + 1024) * sizeof(float)));
+  if (src->ndim != 3 || src->shape[0] != Cout || src->shape[1] != H || src->shape[2] != 1) SVOC_FAIL(SVOC_ERR_SHAPE, "tensor %s has the wrong shape", src->name);
+  const int total = (Cout / 16) * 12 * 256;
+  SVOC_TRY(img.ensure((size_t)(total + Cout + 1024) * sizeof(float)));
   DevBuf scale;
   if (!w) {
-    SVOC_TRY(scale.ensure((size_t)2 * H * sizeof(float)));
-    hipLaunchKernelGGL(wns_scale_kernel, dim3((unsigned)(2 * H)), dim3(256), 0, st, (const float*)src->data, (const float*)g->data, scale.f(), H);
+    SVOC_TRY(scale.ensure((size_t)Cout * sizeof(float)));
+    hipLaunchKernelGGL(wns_scale_kernel, dim3((unsigned)Cout), dim3(256), 0, st, (const float*)src->data, (const float*)g->data, scale.f(), H);
   }
-  hipLaunchKernelGGL(pack_wn_rs16_kernel, dim3((unsigned)((total + 2 * H + 255) / 256)), dim3(256), 0, st, (const float*)src->data,
-                     w ? nullptr : scale.f(), bs ? (const float*)bs->data : nullptr, img.f(), total);
+  hipLaunchKernelGGL(pack_wn_rs16_kernel, dim3((unsigned)((total + Cout + 255) / 256)), dim3(256), 0, st, (const float*)src->data,
+                     w ? nullptr : scale.f(), bs ? (const float*)bs->data : nullptr, img.f(), total, Cout);
   SVOC_HIP(hipGetLastError());
   SVOC_HIP(hipStreamSynchronize(st));
   return SVOC_OK;

@@ -423,6 +423,40 @@ np.save({str(tmp_path / 'y.npy')!r}, y.cpu().numpy())
     assert np.array_equal(np.load(str(tmp_path / "y.npy")), y.cpu().numpy()), "persistent stack differs from the per-layer launches"
 
 
+@pytest.mark.parametrize("n_layers,B,Tn", [(16, 1, 200), (8, 1, 200), (8, 2, 100), (2, 10, 7), (3, 1, 320), (4, 2, 33)])
+def test_wn_mesh_short_inputs_one_persistent_launch(M, n_layers, B, Tn):
+    """A whole WN stack for SHORT inputs in ONE persistent launch (csrc/wn_mesh.hip; reference modules.py:148-176): twelve workgroups per
+    32-column tile that hand acts rows and x rows (with the k = 5 halo of the neighbouring tiles) to each other twice per layer.  BASELINE
+    configs[0] (1 x 200: seven tiles, the last of 8 columns), ragged batches, ten one-tile utterances (no neighbours), the largest grid the
+    launcher takes (1 x 320: ten tiles = 120 of 256 CUs), a last tile of ONE column.  Against the oracle; run to run bit-identical."""
+    import os
+    if any(os.environ.get(k) == "0" for k in ("SVOC_WN_MESH", "SVOC_WN_F25", "SVOC_WN_SMALL", "SVOC_WN_SMALL_F25", "SVOC_FUSE_WN")):
+        pytest.skip("a variant run that switches the short-input kernels off")
+    rng = np.random.default_rng(n_layers * 1000 + B)
+    sd = sw.fill_state_dict(cases.wn_shapes(192, 5, n_layers, 0), 8900 + n_layers)
+    m = load(M.modules.WN(192, 5, 1, n_layers, gin_channels=0), sd)
+    x = T(cases.rnd(9000 + B, "x", (B, 192, Tn), 1.0))
+    lens = [Tn] + [int(rng.integers(1, Tn + 1)) for _ in range(B - 1)]
+    mask = T(cases.lengths_mask(lens, Tn))
+    M.native.stats_reset()
+    y = m((x * mask).cuda(), mask.cuda())
+    st = M.native.stats_get()
+    assert st["conv_launches"] == 1, st                       # ONE launch for the 2 * n_layers convolutions
+    assert st["convolutions"] == 2 * n_layers
+    with torch.no_grad():
+        ref = O.wn(sdT(sd), "", x * mask, mask, None, hidden=192, kernel_size=5, dilation_rate=1, n_layers=n_layers)
+    check(f"wn mesh n{n_layers} B{B} T{Tn}", y, ref.numpy())
+    for _ in range(20):                                         # the hand-overs leave no run-to-run difference, the flags are clean for the next launch
+        assert torch.equal(y, m((x * mask).cuda(), mask.cuda()))
+    xo = T(cases.rnd(9050 + B, "xo", (2, 192, 150), 1.0))    # another (B, T) lays the hand-over rows out differently: nothing of it may be read afterwards
+    m(xo.cuda(), torch.ones(2, 1, 150).cuda())
+    assert torch.equal(y, m((x * mask).cuda(), mask.cuda()))
+    x2 = T(cases.rnd(9100 + B, "x2", (B, 192, Tn), 1.0))     # ... and nothing of the previous input survives in the hand-over rows
+    with torch.no_grad():
+        ref2 = O.wn(sdT(sd), "", x2 * mask, mask, None, hidden=192, kernel_size=5, dilation_rate=1, n_layers=n_layers)
+    check(f"wn mesh n{n_layers} B{B} T{Tn} second input", m((x2 * mask).cuda(), mask.cuda()), ref2.numpy())
+
+
 @pytest.mark.parametrize("name", list(cases.POSTERIOR_CASES))
 def test_posterior_encoder(M, name):
     c = cases.POSTERIOR_CASES[name]
