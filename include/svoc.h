@@ -87,6 +87,13 @@ double svoc_stats_executed_flops(void);
  * 8e "8-GPU output == 1-GPU output bitwise"); used by parallel.infer_sharded(bitwise=True).  Process-global; returns the
  * previous value.  Replaces nothing in the reference (it has one code path per op: torch's). */
 int svoc_set_variant_batch(int n);
+/* Two kernels of the path are PERSISTENT launches whose workgroups wait for each other (a whole WN stack per launch: csrc/wn_stack.hip,
+ * csrc/wn_mesh.hip).  Alone on a GPU - one process per GPU is the deployment - every workgroup is resident and nothing
+ * waits for long; when MANY processes share one GPU two such launches can hold each other's CUs, so every wait is bounded by 30 s of wall time:
+ * a workgroup that gives up raises a host-visible word, the call's outputs are wrong, and the NEXT svoc_wn_forward / svoc_synth_infer (or this
+ * function, which needs no synchronisation) fails with SVOC_ERR_HIP and clears the word.  Nothing in the reference corresponds (torch launches one
+ * kernel per op). */
+int svoc_check_async_error(void);
 
 /* Diagnostics: bracket every convolution launch with HIP events and aggregate by layer shape. */
 int svoc_profile_enable(int on);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "svoc_stats_convolutions": (_L, []),
     "svoc_stats_executed_flops": (C.c_double, []),
     "svoc_set_variant_batch": (_I, [_I]),
+    "svoc_check_async_error": (_I, []),
     "svoc_profile_enable": (_I, [_I]),
     "svoc_profile_report": (_I, [C.c_char_p, _I]),
     "svoc_debug_set_stamp_buffer": (_I, [_P]),
@@ -223,6 +224,11 @@ def set_variant_batch(n):
     """Kernel variants are chosen as if the batch held `n` utterances (0: the real batch); returns the previous value.
     See include/svoc.h svoc_set_variant_batch."""
     return lib().svoc_set_variant_batch(int(n))
+
+
+def check_async_error():
+    """Raises when a persistent WN launch of an earlier call gave up one of its bounded waits (include/svoc.h svoc_check_async_error)."""
+    check(lib().svoc_check_async_error())
 
 
 class variant_batch:

@@ -97,6 +97,7 @@ struct WNStack {
   // x (already masked by the caller, as the reference's callers do) -> out; both [B][H][ld]
   int forward(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs,
               const float* g, int g_T, float* out, long long out_bs, int out_ld, int B, int T) {
+    SVOC_TRY(async_error_check());                          // a persistent launch of an earlier call that gave up a wait (svoc.h svoc_check_async_error)
     const int Tp = pad4(T);
     const long long per = (long long)H * Tp;
     const int gTp = g ? pad4(g_T) : 0;
@@ -1134,6 +1135,7 @@ struct Synth {
 
   int infer(hipStream_t st, const float* mel, const int64_t* lengths, const float* eps, float noise_scale, int max_len, float* o,
             float* x_mask, float* z, float* z_p, float* m_p, float* logs_p, int B, int T) {
+    SVOC_TRY(async_error_check());                          // (plan replays do not pass through WNStack::forward)
     const int Td = (max_len > 0 && max_len < T) ? max_len : T;
     const bool want_zp = z_p != nullptr;
     PlanKey key; key.B = B; key.T = T; key.Td = Td; key.noise = noise_scale; key.has_eps = eps != nullptr; key.want_zp = want_zp;

@@ -43,6 +43,29 @@ int ensure_max_dyn_lds(const void* kernel) {
   return SVOC_OK;
 }
 
+// Asynchronous failures of the persistent launches (wn_stack.hip, wn_mesh.hip): their workgroups wait for each other, the waits are bounded by wall
+// time, and a workgroup that gives up raises this word - pinned host memory the device writes through, so the host can read it without a
+// synchronisation.  It is looked at when the next call comes in (WNStack::forward, Synth::infer) and through svoc_check_async_error().
+static int* g_async_err = nullptr;
+int* async_error_word() {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (!g_async_err) {
+    void* q = nullptr;
+    if (hipHostMalloc(&q, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    memset(q, 0, 64);
+    g_async_err = static_cast<int*>(q);
+  }
+  return g_async_err;
+}
+int async_error_check() {
+  int* w = g_async_err;
+  if (!w) return SVOC_OK;
+  if (__atomic_load_n(w, __ATOMIC_RELAXED) == 0) return SVOC_OK;
+  __atomic_store_n(w, 0, __ATOMIC_RELAXED);
+  SVOC_FAIL(SVOC_ERR_HIP, "a persistent WN launch of an EARLIER call gave up waiting for its other workgroups after 30 s (the GPU is shared by more "
+                          "processes than the launch can be resident beside: SVOC_WN_STACK=0 SVOC_WN_MESH=0 select the per-layer launches); the outputs of that call are wrong");
+}
+
 static long long* g_stamp_buffer = nullptr;
 long long* debug_stamp_buffer() { return g_stamp_buffer; }
 void set_debug_stamp_buffer(long long* p) { g_stamp_buffer = p; }
@@ -356,6 +379,7 @@ int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_la
 int64_t svoc_stats_convolutions(void) { return svoc::stats_convs(); }
 double svoc_stats_executed_flops(void) { return svoc::stats_exec_flops(); }
 int svoc_set_variant_batch(int n) { return svoc::set_variant_batch(n); }
+int svoc_check_async_error(void) { return svoc::async_error_check(); }
 int svoc_profile_enable(int on) { svoc::prof_enable(on != 0); return SVOC_OK; }
 int svoc_profile_report(char* buf, int buflen) {
   if (!buf || buflen <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_profile_report: bad buffer");

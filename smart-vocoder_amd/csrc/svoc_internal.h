@@ -167,6 +167,8 @@ int variant_batch(int B);
 // Per-device launch prerequisites (misc_kernels.hip).  A process may drive several GPUs (one handle per device), so
 // neither the compute-unit count nor "this kernel may use 160 KiB of dynamic LDS" can live in a function-local static.
 int device_cu_count();                       // compute units of the CURRENT device (cached per device)
+int* async_error_word();                     // pinned host word the persistent launches raise when a bounded wait gives up (null: allocation failed)
+int async_error_check();                     // SVOC_OK, or fails (once) when that word was raised since the last check
 int ensure_max_dyn_lds(const void* kernel);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB) once per (kernel, device)
 
 struct ConvGroup { ConvArgs a[3]; int end[3]; };     // conv_group_kernel: end[i] = first workgroup id after problem i
@@ -234,7 +236,6 @@ bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T);
 int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, int H, const float* x, long long x_bs,
                         int x_ld, float* out, long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st);
 int wn_stack_prepare(float* scratch, const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, hipStream_t st);
-int wn_stack_error(const float* scratch, hipStream_t st);
 bool wn_layer_prefers_unfused(int B, int T);              // short inputs: fewer 32-column tiles than half the CUs (wn_fused.hip's size gate)
 // wn_mesh.hip: a whole WN stack for SHORT inputs in one persistent launch (twelve workgroups per 32-column tile, two hand-overs per layer)
 bool wn_mesh_enabled();
@@ -244,7 +245,6 @@ int pack_wn_mesh(DevBuf& img, const float* f25, hipStream_t st);
 int wn_mesh_prepare(float* scratch, const PackedConv* const* in_l, const float* const* wm, const float* const* wrs, int NL, hipStream_t st);
 int launch_wn_mesh_f25(const PackedConv* const* in_l, const PackedConv* const* rs_l, int NL, int H, const float* x, long long x_bs, int x_ld, float* out,
                        long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st);
-int wn_mesh_error(const float* scratch, hipStream_t st);
 // wn_small.hip: short inputs, one launch per layer: res_skip of the previous layer + F(2,5) in_layer + gate; 1 = does not apply
 bool wn_small_enabled();
 int pack_wn_rs16_named(DevBuf& img, int H, int Cout, const TensorTable& tab, const std::string& prefix, hipStream_t st);

@@ -76,7 +76,7 @@ __device__ __forceinline__ void wnm_wait(const int* f, int n, bool valid, int wa
     if (__builtin_amdgcn_ballot_w64(v < want) == 0) break;
     __builtin_amdgcn_s_sleep(1);
     if (__builtin_amdgcn_s_memrealtime() - t_start > 3000000000ull) {
-      if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
   }
@@ -435,7 +435,8 @@ int launch_wn_mesh_f25(const PackedConv* const* in_l, const PackedConv* const* r
   a.fa = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + wnm_flag_offset());
   a.fx = a.fa + WNM_R * wnm_max_tiles();
   a.exited = a.fx + WNM_R * wnm_max_tiles();
-  a.err = a.exited + 17;
+  a.err = async_error_word();                                // pinned host memory (misc_kernels.hip): looked at by the next call
+  if (!a.err) return 1;
   double flops = 0, exec = 0;
   for (int i = 0; i < NL; ++i) {
     flops += (in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;
@@ -455,13 +456,4 @@ int launch_wn_mesh_f25(const PackedConv* const* in_l, const PackedConv* const* r
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;
 }
-int wn_mesh_error(const float* scratch, hipStream_t st) {
-  if (!scratch) return 0;
-  int e = 0;
-  const int* err = reinterpret_cast<const int*>(reinterpret_cast<const char*>(scratch) + wnm_flag_offset()) + 2 * WNM_R * wnm_max_tiles() + 17;
-  if (hipMemcpyAsync(&e, err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-  if (hipStreamSynchronize(st) != hipSuccess) return -1;
-  return e;
-}
-
 }  // namespace svoc

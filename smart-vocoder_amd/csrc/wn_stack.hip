@@ -8,7 +8,7 @@
 // 768-thread, 154 KB workgroup per CU).  When the GPU is shared, part of the launch is resident at first: workgroups are dispatched in tile order, the
 // lowest resident tile's left neighbour has finished, and a window of more than n_layers resident tiles always lets its low end run to completion and
 // free its CUs - progress needs n_layers + 1 CUs, not all of them.  The waits are bounded all the same (30 s of wall time): a workgroup that gives up
-// raises an error word in the scratch area (wn_stack_error) and goes on - a wrong result, never a hung GPU.
+// raises a host-visible error word (async_error_word(): the next call fails, include/svoc.h svoc_check_async_error) and goes on - never a hung GPU.
 // Memory ordering (gfx950, one L2 per XCD): edges and counters are device-scope relaxed atomics (sc1: they bypass the non-coherent caches in both
 // directions); the writer waits for its edge stores' acknowledgements (s_waitcnt vmcnt(0) - a workgroup-scope release fence) ahead of the workgroup
 // barrier behind which thread 0 raises the counter; the reader's edge loads are issued behind the barrier that follows the successful poll.  No
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < li) {
           __builtin_amdgcn_s_sleep(2);
           if (__builtin_amdgcn_s_memrealtime() - t_start > 3000000000ull) {      // 30 s: give up, never hang
-            __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
         }
@@ -382,7 +382,8 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   a.halo = scratch;
   a.exited = reinterpret_cast<int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2);      // [17]: top counter, sixteen sub-counters
   a.done = a.exited + 17;
-  a.err = a.done + ncu;
+  a.err = async_error_word();                                // pinned host memory (misc_kernels.hip): looked at by the next call
+  if (!a.err) return 1;
   a.dbg = nullptr;
   // The counters are NOT cleared by a memset ahead of the launch: a first version did that, and inside a captured plan replayed while another
   // process shared the GPU the launch found them uncleared (layer counters already raised, i.e. no waiting at all and edges of the launch before - which
@@ -417,15 +418,4 @@ int wn_stack_prepare(float* scratch, const PackedConv* const* in_l, const Packed
   SVOC_HIP(hipStreamSynchronize(st));                      // `t` lives on this stack frame
   return SVOC_OK;
 }
-// the error word of the last stack launches that used `scratch` (host read: synchronises the stream); 0 = every wait was answered
-int wn_stack_error(const float* scratch, hipStream_t st) {
-  if (!scratch) return 0;
-  const int ncu = device_cu_count();
-  int e = 0;
-  const int* err = reinterpret_cast<const int*>(scratch + (size_t)WNS_MAXL * ncu * 2 * WNF_H * 2) + 17 + ncu;
-  if (hipMemcpyAsync(&e, err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-  if (hipStreamSynchronize(st) != hipSuccess) return -1;
-  return e;
-}
-
 }  // namespace svoc
