@@ -749,7 +749,7 @@ int launch_conv_wino4_accum(const PackedWino* const* pws, const ConvArgs* as, in
   // F(4,4) members (128-row layout): k = 7 / 11 carry that image; the merged launch needs k = 3 in the same form (its second image)
   const bool f44 = pws[1]->f44 && pws[2]->f44;
   if (pws[1]->f44 != pws[2]->f44 || pws[0]->f44 || !f44) return 1;
-  if (total * 3 / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
+  if (total * 3 / B * variant_batch(B) < mrf_min_tiles()) return 1;
   const int in_perm = as[0].wperm_in;
   if (as[1].wperm_in != in_perm || as[2].wperm_in != in_perm) return 1;
   // one set of accumulators for the three members (conv_wino4_acc.hip): every member a plain residual convolution, accumulated in chain order
@@ -804,7 +804,7 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   if (f4 && (!pws[0]->f44 || !pws[1]->f44 || pws[2]->f44)) return 1;
   // (the threshold counts the F(2,3) kernels' 64- / 128-column tiles whichever form runs: round 3's measured break-even for the
   // grouped launches - counting the F(4,3) tiles instead sent the 1 x 200 C = 128 / 64 stages to the direct kernels, +0.5 ms)
-  if (total / B * variant_batch(B) < 2LL * device_cu_count()) return 1;
+  if (total / B * variant_batch(B) < mrf_min_tiles()) return 1;
   const int in_perm = as[0].wperm_in, out_perm = as[0].wperm_out;
   for (int i = 1; i < n; ++i) if (as[i].wperm_in != in_perm || as[i].wperm_out != out_perm) return 1;
   if (query) return f4 ? 0 : 1;

@@ -573,7 +573,7 @@ struct Generator {
       };
       // C = 32 / 64, every step but the last: c1 -> c2 of the three chains in ONE launch, the intermediate tile in LDS (conv_wino4_pair.hip)
       if ((C == 32 || C == 64) && nk == 3 && !last && wino4_pair_enabled() &&
-          wino4_pair_tiles(C, L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= 2LL * device_cu_count()) {
+          wino4_pair_tiles(C, L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= mrf_min_tiles()) {
         const PackedWino* p1[3]; const PackedWino* p2[3];
         const float* xi[3]; float* yo[3];
         for (int q = 0; q < nk; ++q) {
@@ -595,7 +595,7 @@ struct Generator {
       // C = 32, the LAST step (round 5): c1 -> c2 of the three chains AND the sum over the chains in ONE launch - the pair kernel's accumulate form
       // (xs = (rb_11 + rb_7 + rb_3) / 3 built in place by the workgroup that owns the tile; replaces the window-major c1 launch + the merged accumulate launch)
       if (C == 32 && nk == 3 && last && wino4_pair_enabled() &&
-          wino4_pair_tiles(C, L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= 2LL * device_cu_count()) {
+          wino4_pair_tiles(C, L, variant_batch(B), rbs[stage * nk]->c1[it]->dil) >= mrf_min_tiles()) {
         const PackedWino* p1[3]; const PackedWino* p2[3];
         const float* xi[3]; float* yo[3];
         for (int q = 0; q < nk; ++q) {
@@ -758,8 +758,8 @@ struct Generator {
         SVOC_TRY(launch_conv(*ups[i], a, B, st));
       }
       const long long bs = (long long)cho * ldo;
-      // Short inputs: when the three chains' convolutions are too small for the grouped Winograd launches (fewer than two
-      // workgroups per CU in total) they would run one by one as K-split launches; the chains are independent until the
+      // Short inputs: when the three chains' convolutions are too small for the grouped Winograd launches (fewer than half a
+      // workgroup per CU in total: mrf_min_tiles()) they would run one by one as K-split launches; the chains are independent until the
       // final accumulate, so they go to the three chain streams instead and their latencies overlap.
       bool small_stage = false;
       {
@@ -767,7 +767,7 @@ struct Generator {
         const int mtl = cho / 32, wm = (mtl >= 4 && mtl % 4 == 0) ? 4 : 2;
         long long tiles = (long long)cfg.n_kernels * variant_batch(B) * ((Lo + (wm == 4 ? 63 : 127)) / (wm == 4 ? 64 : 128)) * ((mtl + wm - 1) / wm);
         if (mtl == 1) tiles = (long long)cfg.n_kernels * variant_batch(B) * ((Lo + 511) / 512);    // F(4,3), one row tile: 512 outputs per workgroup tile
-        small_stage = on && (tiles < 2LL * device_cu_count() || (mtl == 1 && (Lo & 3)));
+        small_stage = on && (tiles < mrf_min_tiles() || (mtl == 1 && (Lo & 3)));
       }
       if (use_streams && !small_stage && mrf_grouped(i, cho)) {
         // MRF with the chains' step-i convolutions grouped into single launches (conv_group_kernel)

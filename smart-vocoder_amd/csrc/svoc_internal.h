@@ -167,6 +167,7 @@ int variant_batch(int B);
 // Per-device launch prerequisites (misc_kernels.hip).  A process may drive several GPUs (one handle per device), so
 // neither the compute-unit count nor "this kernel may use 160 KiB of dynamic LDS" can live in a function-local static.
 int device_cu_count();                       // compute units of the CURRENT device (cached per device)
+long long mrf_min_tiles();                   // fewest tiles for the grouped / paired / accumulate Winograd launches of the MRF
 int* async_error_word();                     // pinned host word the persistent launches raise when a bounded wait gives up (null: allocation failed)
 int async_error_check();                     // SVOC_OK, or fails (once) when that word was raised since the last check
 int ensure_max_dyn_lds(const void* kernel);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB) once per (kernel, device)
