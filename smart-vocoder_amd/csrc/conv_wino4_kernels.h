@@ -126,7 +126,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     }
     const int pnblk_row = PERM > 0 ? (L + 4 * PERM - 1) / (4 * PERM) : 0;      // q blocks of a row
     // first q block a tile loads: the one that holds column xs (xs >= -4 PERM: the left halo is at most 8 columns)
-    auto pfirst = [&](int xs_) -> int { return (xs_ + 4 * PERM) / (4 * PERM) - 1; };
+    auto pfirst = [&](int xs_) -> int { constexpr int P4 = PERM > 0 ? 4 * PERM : 1; return (xs_ + P4) / P4 - 1; };      // (only called with PERM > 0)
     int tsrc[TPW];                                         // float offset inside `raw`: D = 1: the item's samples; D > 1: the item's raw row (the column follows the tile)
     int tdst[TPW];                                         // float offset of the item's entry inside plane 0 of a set
     int tent[TPW];                                         // D > 1: the item's entry index e

@@ -44,7 +44,7 @@ VARIANTS = {
     "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),
-    "wn_one_launch_per_layer": ({"SVOC_WN_STACK": "0"}, WNS + " or test_c2_full_size_vs_oracle"),
+    "wn_one_launch_per_layer": ({"SVOC_WN_STACK": "0"}, WNS),
     "wn_short_inputs_one_launch_per_layer": ({"SVOC_WN_MESH": "0"}, "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_wn or test_coupling or test_flow"),
     "wn_short_inputs_two_convolutions": ({"SVOC_WN_SMALL_F25": "0"}, SMALL + " or test_coupling or test_flow"),
     "no_small_shape_kernels": ({"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"}, SMALL),
