@@ -33,7 +33,8 @@ namespace svoc {
 constexpr int WNM_R = 12;                                   // workgroups per column tile
 constexpr int WNM_AROW = 48;                                // acts tile row stride (columns 0 .. 31 used; 48: the B reads of the 1 x 1 are conflict-free)
 constexpr int WNM_MAXL = 16;
-constexpr int WNM_LDS_FLOATS = WNF_H * WNF_XROW + 6 * WNF_PLANE;
+constexpr int WNM_FS = 32;                                  // ints between two flags
+constexpr int WNM_LDS_FLOATS = WNF_H * WNF_XROW + 6 * WNF_PLANE + WNM_MAXL * 8;      // x tile | planes | the layer table
 static_assert(WNF_H * WNM_AROW <= 6 * WNF_PLANE && 8 * 16 * 64 <= 6 * WNF_PLANE, "acts tile and reduction area alias the planes");
 
 struct WnMeshLayer {
@@ -48,10 +49,12 @@ struct WnMeshArgs {
   const float* mask; long long mask_bs;
   const WnMeshLayer* layers;                            // [NL], device memory
   int NL; int T; int ntx;
-  float* xg; int xg_ld; long long xg_bs; long long xg_par;   // x rows: [2 (layer parity)][B][H][xg_ld], column t at 4 + t (four zero columns either side)
+  float* xg; int xg_ld; long long xg_bs; long long xg_par;   // x rows: [2 (layer parity)][B][H][32 ntx] (rows start on a 128-byte line)
+  float* xh; long long xh_par;                          // their edges again, packed: [2][tiles][2 (first | last four columns)][H][4]
   float* ag; int ag_ld; long long ag_bs;                // acts rows: [B][H][32 ntx]
-  int* fa; int* fx;                                     // [tiles][12]: acts layers written / x layers written
+  int* fa; int* fx;                                     // [tiles][12] x WNM_FS ints (one 128-byte line per flag): acts layers written / x layers written
   int* exited; int* err;                                // [17] two-level exit count; error word
+  long long* dbg;                                       // diagnostics: [workgroup][16] wall-clock stamps (10 ns) of thread 0 in layer NL / 2 (tools/wn_mesh_timeline.py)
 };
 
 typedef unsigned int wnm_u32x4 __attribute__((ext_vector_type(4)));
@@ -72,7 +75,7 @@ __device__ __forceinline__ void wnm_wait(const int* f, int n, bool valid, int wa
   const bool mine = lane < n && valid;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
   while (true) {
-    const int v = mine ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+    const int v = mine ? __hip_atomic_load(f + lane * WNM_FS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
     if (__builtin_amdgcn_ballot_w64(v < want) == 0) break;
     __builtin_amdgcn_s_sleep(1);
     if (__builtin_amdgcn_s_memrealtime() - t_start > 3000000000ull) {
@@ -89,6 +92,11 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
   float* const PLN = lds + H * XROW;                        // V_p [6][H][16]
   float* const AT = PLN;                                    // acts tile [H][48] (columns t0 .. t0 + 31), between the layers
   float* const RED = PLN;                                   // [8 waves][16][64] partial outputs, behind the stream
+  // the layer table, copied once: read from device memory per layer its pointers were two dependent ~0.8 us round trips ahead of every weight request
+  WnMeshLayer* const TBL = reinterpret_cast<WnMeshLayer*>(PLN + 6 * PLANE);
+  static_assert(sizeof(WnMeshLayer) == 32, "eight words per layer");
+  if (threadIdx.x < (unsigned)p.NL * 8) reinterpret_cast<int*>(TBL)[threadIdx.x] = reinterpret_cast<const int*>(p.layers)[threadIdx.x];
+  __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwg = gridDim.x;
@@ -99,6 +107,7 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
   const int t0 = tile * 32;
   const int NL = p.NL, T = p.T;
   const __amdgpu_buffer_rsrc_t xg_rs = __builtin_amdgcn_make_buffer_rsrc(p.xg, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xh_rs = __builtin_amdgcn_make_buffer_rsrc(p.xh, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t ag_rs = __builtin_amdgcn_make_buffer_rsrc(p.ag, 0, 0x7fffffff, 0x00020000);
   const int rt2 = wave & 1, nt = (wave >> 1) & 1;           // the 1 x 1: waves 0 .. 3 = (residual | skip tile, column half)
   float skip[4] = {0.f, 0.f, 0.f, 0.f};                     // waves 1, 3: out rows 16 r + 4 k4 + i, column t0 + 16 nt + col
@@ -112,7 +121,7 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
   // the in_layer weights of this wave: 18 sixteen-byte loads = the A operands of its 72 MFMAs (in flight across the waits)
   float4 wv[18];
   auto request_in = [&](int li) {
-    const float* wm = uni(p.layers[li].wm);
+    const float* wm = uni(TBL[li].wm);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wm), 0, 0x7fffffff, 0x00020000);
     const int w0 = __builtin_amdgcn_readfirstlane((r * 8 + wave) * 18 * 1024);
     const int vo = (int)(threadIdx.x & 63) * 16;
@@ -123,32 +132,52 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
     }
   };
   request_in(0);
+  // the 1 x 1 of a layer: waves 0 .. 3; A operands (12 sixteen-byte loads), the four bias values of this lane's rows, the mask of its column.
+  // Requested AHEAD of the next layer's in_layer weights (loads return in order and the 1 x 1 comes first).
+  float4 aw[12];
+  float4 rsb = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto request_rs = [&](int layer) {
+    const bool last_ = layer == NL - 1;
+    if (wave < 4 && (rt2 == 1 || !last_)) {
+      const WnMeshLayer lp = TBL[layer];
+      const float* wrs = uni(lp.wrs);
+      const int rs_tiles = __builtin_amdgcn_readfirstlane(lp.rs_tiles);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wrs), 0, 0x7fffffff, 0x00020000);
+      const int ti = (rt2 == 1 && !last_) ? WNM_R + r : r;
+      const int wb = __builtin_amdgcn_readfirstlane(ti * 12 * 1024);
+      const int ln = (int)(threadIdx.x & 63);
+#pragma unroll
+      for (int ks4 = 0; ks4 < 12; ++ks4) {
+        const wnm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, ln * 16, wb + ks4 * 1024, 0);
+        aw[ks4] = *reinterpret_cast<const float4*>(&t);
+      }
+      // bias (natural order behind the image): rows 16 r + 4 k4 .. + 3 of the residual part, or of the skip part (last layer: the only part)
+      const int bo = __builtin_amdgcn_readfirstlane((rs_tiles * 12 * 256 + ((rt2 == 1 && !last_) ? WNF_H : 0) + 16 * r) * 4);
+      const wnm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (ln >> 4) * 16, bo, 0);
+      rsb = *reinterpret_cast<const float4*>(&t);
+    }
+  };
+  float mk_rs = 0.f;                                        // waves 0 .. 3: mask of column t0 + 16 nt + col
+  if (wave < 4) {
+    const int t = t0 + 16 * nt + (int)(threadIdx.x & 15);
+    mk_rs = t < T ? p.mask[(long long)b * p.mask_bs + t] : 0.f;
+  }
 
   for (int li = 0; li <= NL; ++li) {
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));                          // (per-layer addresses are rebuilt, not hoisted and kept live: wn_stack.hip)
     const int tid = tid_, lane = tid & 63;
     const int col = lane & 15, k4 = lane >> 4;
+    const bool stamped = p.dbg && li == NL / 2 && tid == 0;
+    auto stamp = [&](int i) { if (stamped) p.dbg[(long long)g * 16 + i] = (long long)__builtin_amdgcn_s_memrealtime(); };
 
     // =============================================================== res_skip of layer li - 1
     if (li > 0) {
       const bool last = li == NL;                           // the last layer's 1 x 1 has H rows, all of them skip
-      const WnMeshLayer lp = p.layers[li - 1];
-      const float* wrs = uni(lp.wrs);
-      const int rs_tiles = __builtin_amdgcn_readfirstlane(lp.rs_tiles);
-      float4 aw[12];
       const bool gemm_wave = wave < 4 && (rt2 == 1 || !last);
-      if (gemm_wave) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wrs), 0, 0x7fffffff, 0x00020000);
-        const int ti = (rt2 == 1 && !last) ? WNM_R + r : r;
-        const int wb = __builtin_amdgcn_readfirstlane(ti * 12 * 1024);
-#pragma unroll
-        for (int ks4 = 0; ks4 < 12; ++ks4) {
-          const wnm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, wb + ks4 * 1024, 0);
-          aw[ks4] = *reinterpret_cast<const float4*>(&t);
-        }
-      }
-      if (wave == 0) wnm_wait(p.fa + gt * WNM_R, WNM_R, true, li, p.err);
+      stamp(0);
+      if (wave == 0) wnm_wait(p.fa + gt * WNM_R * WNM_FS, WNM_R, true, li, p.err);
+      stamp(1);
       __syncthreads();
       {   // acts_{li-1} tile: H rows x 32 columns = 1536 sixteen-byte groups, three per thread
         const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)b * p.ag_bs + t0) * 4));
@@ -161,6 +190,7 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
         }
       }
       __syncthreads();
+      stamp(2);
       if (gemm_wave) {
         wn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* bp = AT + k4 * WNM_AROW + 16 * nt + col;
@@ -173,26 +203,29 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[8 * WNM_AROW], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[12 * WNM_AROW], acc, 0, 0, 0);
         }
-        const float* rsbias = wrs + rs_tiles * 12 * 256;
-        const int t = t0 + 16 * nt + col;
         if (rt2 == 1) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) skip[i] += acc[i] + rsbias[(last ? 0 : H) + 16 * r + 4 * k4 + i];
-        } else {   // x_li = (x_{li-1} + rs) * mask: this workgroup's sixteen rows of the centre columns -> the buffer of parity li
-          const float mk = t < T ? p.mask[(long long)b * p.mask_bs + t] : 0.f;
-          const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)(li & 1) * p.xg_par + (long long)b * p.xg_bs + 4 + t0) * 4));
+          for (int i = 0; i < 4; ++i) skip[i] += acc[i] + wino_pick(rsb, i);
+        } else {   // x_li = (x_{li-1} + rs) * mask: this workgroup's sixteen rows of the centre columns -> the buffer of parity li, edges also packed
+          const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)(li & 1) * p.xg_par + (long long)b * p.xg_bs + t0) * 4));
+          const int tc = 16 * nt + col;                     // tile column
+          const bool edge = tc < 4 || tc >= 28;
+          const int hb = __builtin_amdgcn_readfirstlane((int)(((long long)(li & 1) * p.xh_par + (long long)gt * 2 * H * 4) * 4));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int ch = 16 * r + 4 * k4 + i;
-            const float v = (XT[ch * XROW + 4 + 16 * nt + col] + (acc[i] + rsbias[ch])) * mk;
-            wnm_st4_sc1(xg_rs, v, (ch * p.xg_ld + 16 * nt + col) * 4, sb);
+            const float v = (XT[ch * XROW + 4 + tc] + (acc[i] + wino_pick(rsb, i))) * mk_rs;
+            wnm_st4_sc1(xg_rs, v, (ch * p.xg_ld + tc) * 4, sb);
+            if (edge) wnm_st4_sc1(xh_rs, v, (((tc >= 28 ? 1 : 0) * H + ch) * 4 + (tc & 3)) * 4, hb);
           }
         }
       }
       if (last) break;
+      stamp(3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the x stores are acknowledged (write-through) ...
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(p.fx + gt * WNM_R + r, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
+      if (tid == 0) __hip_atomic_store(p.fx + (gt * WNM_R + r) * WNM_FS, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
+      stamp(4);
     }
 
     // =============================================================== in_layer + gate of layer li
@@ -222,25 +255,33 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
       if (wave == 0) {   // x_li of this tile's and the two neighbours' workgroups: 36 flags, one load per poll
         const int d = lane / WNM_R - 1;
         const bool valid = lane < 3 * WNM_R && tile + d >= 0 && tile + d < ntx;
-        wnm_wait(p.fx + (gt - 1) * WNM_R, 3 * WNM_R, valid, li, p.err);
+        wnm_wait(p.fx + (gt - 1) * WNM_R * WNM_FS, 3 * WNM_R, valid, li, p.err);
       }
+      stamp(5);
       __syncthreads();
-      constexpr int R4 = XROW / 4, total = H * R4;        // 1920 sixteen-byte groups; buffer column 4 + t <-> tile column t - t0 + 4
+      // centre: H rows x 32 columns (one 128-byte line per row), three sixteen-byte groups per thread
       const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)(li & 1) * p.xg_par + (long long)b * p.xg_bs + t0) * 4));
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 3; ++u) {
         const int it = tid + 512 * u;
-        if (it < total) {
-          const int c = it / R4, g4 = it - c * R4;
-          float4 q = wnm_ld16_sc1(xg_rs, (c * p.xg_ld + 4 * g4) * 4, sb);
-          // the four columns left of the first tile / right of the last one are the convolution's zero padding (the buffer's pad columns are not
-          // relied upon: with another (B, T) the same words are data columns)
-          if ((g4 == 0 && tile == 0) || (g4 == R4 - 1 && tile == ntx - 1)) q = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(XT + c * XROW + 4 * g4) = q;
+        const int c = it >> 3, g4 = it & 7;
+        const float4 q = wnm_ld16_sc1(xg_rs, (c * p.xg_ld + 4 * g4) * 4, sb);
+        *reinterpret_cast<float4*>(XT + c * XROW + 4 + 4 * g4) = q;
+      }
+      // edges: the left neighbour's LAST four columns -> tile columns 0 .. 3, the right neighbour's FIRST four -> 36 .. 39 (packed: 3 KB each);
+      // outside the utterance: the convolution's zero padding
+      if (tid < 2 * H) {
+        const int side = tid >= H ? 1 : 0, c = tid - side * H;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (side == 0 ? tile > 0 : tile + 1 < ntx) {
+          const int hb = __builtin_amdgcn_readfirstlane((int)((long long)(li & 1) * p.xh_par * 4));
+          q = wnm_ld16_sc1(xh_rs, (((gt + (side ? 1 : -1)) * 2 + (side ? 0 : 1)) * H + c) * 16, hb);
         }
+        *reinterpret_cast<float4*>(XT + c * XROW + (side ? 36 : 0)) = q;
       }
     }
     __syncthreads();
+    stamp(6);
     // ---- input transform (wn_fused.hip): window q of channel c reads tile columns 2q + 2 .. 2q + 7
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
@@ -259,7 +300,27 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
       o[5 * PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
     }
     __syncthreads();
+    stamp(7);
     // ---- the stream: this wave's 24 channels (six k-steps) x six products x (tanh tile, sigmoid tile) = 72 MFMAs; 36 fragment reads two ahead
+    // WEIGHT TRAFFIC (195 KB per workgroup and layer = 1.3 us of the CU's 64 bytes per clock) is requested where nothing waits behind it.  Loads return in
+    // order - requested ahead of a flag's s_waitcnt, of a poll or of a tile they hold those back by as much - and a wave that issues eighteen 1 KB loads
+    // in a row stands still until the address path has taken them (requested in one go ahead of or behind the stream they made stream + output transform
+    // 4.2 us instead of 2.3: tools/wn_mesh_timeline.py).  So: the 1 x 1 operands of this layer here (their registers are free since the last 1 x 1), and the
+    // NEXT layer's in_layer operands INSIDE the stream - each sixteen-byte register set is requested again right behind the step that consumed it, one
+    // load per four MFMAs (128 matrix-pipe cycles: with two waves per SIMD exactly the address path's rate).
+    // (the stream's operands are marked as used first: they were requested in the iteration before, and across the loop's back edge the compiler no
+    // longer knows how old they are - its wait for them would be a wait for everything in flight, the new requests included)
+#pragma unroll
+    for (int l = 0; l < 18; ++l) asm volatile("" : "+v"(wv[l].x), "+v"(wv[l].y), "+v"(wv[l].z), "+v"(wv[l].w));
+    // bias of this thread's (tanh, sigmoid) pair in the gate: ahead of the weight requests as well
+    float2 gbias;
+    {
+      const float* bias1 = uni(TBL[li].bias1);
+      const int ch = 16 * r + 4 * k4 + (wave >> 1);
+      gbias.x = bias1[64 * (ch >> 5) + (ch & 31)];
+      gbias.y = bias1[64 * (ch >> 5) + 32 + (ch & 31)];
+    }
+    request_rs(li);
     wn_f32x4 M[2][6];
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
@@ -268,6 +329,10 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
     {
       constexpr int NST = 36;
       const unsigned baddr = (unsigned)(size_t)PLN + (unsigned)(((24 * wave + k4) * NQ + col) * 4);
+      const float* wmn = uni(TBL[li + 1 < NL ? li + 1 : li].wm);      // (the last layer requests its own again: no branch in the stream)
+      const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wmn), 0, 0x7fffffff, 0x00020000);
+      const int w0n = __builtin_amdgcn_readfirstlane((r * 8 + wave) * 18 * 1024);
+      const int von = lane * 16;
       float fb[2];
       auto rdb = [&](auto ic) {
         constexpr int I = decltype(ic)::value;
@@ -290,11 +355,16 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
         M[1][P_] = __builtin_amdgcn_mfma_f32_16x16x4f32(wino_pick(av, (2 * I + 1) & 3), bv, M[1][P_], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         rdb(std::integral_constant<int, I + 2>{});
+        if constexpr (I & 1) {                               // wv[I / 2] has been consumed: the next layer's set takes its place
+          const wnm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsn, von, w0n + (I / 2) * 1024, 0);
+          wv[I / 2] = *reinterpret_cast<const float4*>(&t);
+        }
         __builtin_amdgcn_sched_barrier(0);
       };
       rdb(std::integral_constant<int, 0>{}); rdb(std::integral_constant<int, 1>{});
       wino_static_for<0, NST>(step);
     }
+    stamp(8);
     __syncthreads();                                         // every wave is done with the planes: the reduction area takes their place
     // ---- output transform of the partial sums -> RED[wave][j][lane], j = 8 tile + 2 i + o
     {
@@ -310,9 +380,9 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
         }
     }
     __syncthreads();
+    stamp(9);
     // ---- reduction over the eight K parts + bias + gate: wave w takes (i, o) = (w / 2, w % 2) of every lane
     {
-      const float* bias1 = uni(p.layers[li].bias1);
       float vA = 0.f, vB = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
@@ -321,17 +391,16 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
       }
       const int ch = 16 * r + 4 * k4 + (wave >> 1);
       const int m = 2 * col + (wave & 1);
-      vA += bias1[64 * (ch >> 5) + (ch & 31)];
-      vB += bias1[64 * (ch >> 5) + 32 + (ch & 31)];
+      vA += gbias.x;
+      vB += gbias.y;
       const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)b * p.ag_bs + t0) * 4));
       wnm_st4_sc1(ag_rs, gate_tanh_sigmoid(vA, vB), (ch * p.ag_ld + m) * 4, sb);
     }
+    stamp(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(p.fa + gt * WNM_R + r, li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the next layer's weights are requested behind the flag: they travel while the flags of the others do (loads return in order - requested ahead
-    // of the flag they would hold back the s_waitcnt above, requested later they would hold back the acts tile)
-    if (li + 1 < NL) request_in(li + 1);
+    if (tid == 0) __hip_atomic_store(p.fa + (gt * WNM_R + r) * WNM_FS, li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp(11);
   }
 
   // ---- out = skip sum * mask (modules.py:175): rows 16 r + 4 k4 + i, columns t0 + 16 nt + col
@@ -352,8 +421,8 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
     if (__hip_atomic_fetch_add(p.exited + 1 + sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1) {
       if (__hip_atomic_fetch_add(p.exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1) {
         for (int i = 0; i < ntiles * WNM_R; ++i) {
-          __hip_atomic_store(p.fa + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(p.fx + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.fa + i * WNM_FS, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.fx + i * WNM_FS, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (int i = 0; i < 17; ++i) __hip_atomic_store(p.exited + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -384,11 +453,11 @@ bool wn_mesh_enabled() {
   return on;
 }
 static int wnm_max_tiles() { return device_cu_count() / 2 / WNM_R; }
-// scratch: x rows (two parities) | acts rows | flags fa, fx | exit counters [17] | error word | (64-byte aligned) layer table
-static size_t wnm_x_floats() { const int mt = wnm_max_tiles(); return (size_t)2 * WNF_H * (32 * mt + 8 * mt); }      // every utterance's rows carry 8 pad columns; B <= tiles
+// scratch: x rows (two parities) | their packed edges (two parities) | acts rows | flags fa, fx (a line each) | exit counters [17] | (64-byte aligned) layer table
+static size_t wnm_x_floats() { return (size_t)2 * WNF_H * 32 * wnm_max_tiles() + (size_t)2 * wnm_max_tiles() * 2 * WNF_H * 4; }      // rows + packed edges, two parities each
 static size_t wnm_a_floats() { return (size_t)WNF_H * 32 * wnm_max_tiles(); }
 static size_t wnm_flag_offset() { return (wnm_x_floats() + wnm_a_floats()) * sizeof(float); }
-static size_t wnm_table_offset() { return (wnm_flag_offset() + ((size_t)2 * WNM_R * wnm_max_tiles() + 18) * sizeof(int) + 63) / 64 * 64; }
+static size_t wnm_table_offset() { return (wnm_flag_offset() + ((size_t)2 * WNM_R * wnm_max_tiles() * WNM_FS + 32) * sizeof(int) + 63) / 64 * 64; }
 size_t wn_mesh_scratch_bytes() { return wnm_table_offset() + WNM_MAXL * sizeof(WnMeshLayer); }
 size_t wn_mesh_image_floats() { return (size_t)WNM_R * 8 * 18 * 256; }
 bool wn_mesh_applies(int H, int K, int dil_rate, int NL, int B, int T) {
@@ -429,14 +498,16 @@ int launch_wn_mesh_f25(const PackedConv* const* in_l, const PackedConv* const* r
   a.mask = mask; a.mask_bs = mask_bs;
   a.layers = reinterpret_cast<const WnMeshLayer*>(reinterpret_cast<const char*>(scratch) + wnm_table_offset());
   a.NL = NL; a.T = T; a.ntx = (T + 31) / 32;
-  a.xg = scratch; a.xg_ld = 32 * a.ntx + 8; a.xg_bs = (long long)H * a.xg_ld; a.xg_par = a.xg_bs * B;
+  a.xg = scratch; a.xg_ld = 32 * a.ntx; a.xg_bs = (long long)H * a.xg_ld; a.xg_par = a.xg_bs * B;
+  a.xh = scratch + (size_t)2 * H * 32 * wnm_max_tiles(); a.xh_par = (long long)a.ntx * B * 2 * H * 4;
   a.ag = scratch + wnm_x_floats(); a.ag_ld = 32 * a.ntx; a.ag_bs = (long long)H * a.ag_ld;
-  if ((size_t)2 * a.xg_par > wnm_x_floats() || (size_t)a.ag_bs * B > wnm_a_floats()) return 1;
+  if ((long long)a.ntx * B > wnm_max_tiles()) return 1;
   a.fa = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + wnm_flag_offset());
-  a.fx = a.fa + WNM_R * wnm_max_tiles();
-  a.exited = a.fx + WNM_R * wnm_max_tiles();
+  a.fx = a.fa + WNM_R * wnm_max_tiles() * WNM_FS;
+  a.exited = a.fx + WNM_R * wnm_max_tiles() * WNM_FS;
   a.err = async_error_word();                                // pinned host memory (misc_kernels.hip): looked at by the next call
   if (!a.err) return 1;
+  a.dbg = debug_stamp_buffer();
   double flops = 0, exec = 0;
   for (int i = 0; i < NL; ++i) {
     flops += (in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;
