@@ -94,6 +94,8 @@ int svoc_set_variant_batch(int n);
  * function, which needs no synchronisation) fails with SVOC_ERR_HIP and clears the word.  Nothing in the reference corresponds (torch launches one
  * kernel per op). */
 int svoc_check_async_error(void);
+/* diagnostics: raises that word from the host, exactly as a workgroup that gave up would (tests of the reporting path) */
+int svoc_debug_raise_async_error(void);
 
 /* Diagnostics: bracket every convolution launch with HIP events and aggregate by layer shape. */
 int svoc_profile_enable(int on);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "svoc_stats_executed_flops": (C.c_double, []),
     "svoc_set_variant_batch": (_I, [_I]),
     "svoc_check_async_error": (_I, []),
+    "svoc_debug_raise_async_error": (_I, []),
     "svoc_profile_enable": (_I, [_I]),
     "svoc_profile_report": (_I, [C.c_char_p, _I]),
     "svoc_debug_set_stamp_buffer": (_I, [_P]),

@@ -385,6 +385,12 @@ int64_t svoc_stats_convolutions(void) { return svoc::stats_convs(); }
 double svoc_stats_executed_flops(void) { return svoc::stats_exec_flops(); }
 int svoc_set_variant_batch(int n) { return svoc::set_variant_batch(n); }
 int svoc_check_async_error(void) { return svoc::async_error_check(); }
+int svoc_debug_raise_async_error(void) {
+  int* w = svoc::async_error_word();
+  if (!w) SVOC_FAIL(SVOC_ERR_NOMEM, "svoc_debug_raise_async_error: no pinned host memory");
+  __atomic_store_n(w, 1, __ATOMIC_RELAXED);
+  return SVOC_OK;
+}
 int svoc_profile_enable(int on) { svoc::prof_enable(on != 0); return SVOC_OK; }
 int svoc_profile_report(char* buf, int buflen) {
   if (!buf || buflen <= 0) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "svoc_profile_report: bad buffer");

@@ -457,6 +457,25 @@ def test_wn_mesh_short_inputs_one_persistent_launch(M, n_layers, B, Tn):
     check(f"wn mesh n{n_layers} B{B} T{Tn} second input", m((x2 * mask).cuda(), mask.cuda()), ref2.numpy())
 
 
+def test_persistent_launch_failure_is_reported_by_the_next_call(M):
+    """The persistent WN launches bound their waits (30 s) and a workgroup that gives up raises a word in pinned host memory
+    (include/svoc.h svoc_check_async_error).  Raised from the host here, exactly as the device would: the NEXT WN call fails with the reason, once;
+    the call after it runs; `check_async_error()` itself reports and clears as well."""
+    sd = sw.fill_state_dict(cases.wn_shapes(192, 5, 3, 0), 9300)
+    m = load(M.modules.WN(192, 5, 1, 3, gin_channels=0), sd)
+    x = T(cases.rnd(9301, "x", (1, 192, 100), 1.0)).cuda(); mask = torch.ones(1, 1, 100).cuda()
+    y = m(x, mask)
+    M.native.check_async_error()
+    M.native.check(M.native.lib().svoc_debug_raise_async_error())
+    with pytest.raises(RuntimeError, match="persistent WN launch"):
+        m(x, mask)
+    assert torch.equal(m(x, mask), y)
+    M.native.check(M.native.lib().svoc_debug_raise_async_error())
+    with pytest.raises(RuntimeError, match="persistent WN launch"):
+        M.native.check_async_error()
+    M.native.check_async_error()
+
+
 @pytest.mark.parametrize("name", list(cases.POSTERIOR_CASES))
 def test_posterior_encoder(M, name):
     c = cases.POSTERIOR_CASES[name]
