@@ -93,7 +93,7 @@ int svoc_set_variant_batch(int n);
  * a workgroup that gives up raises a host-visible word, the call's outputs are wrong, and the NEXT svoc_wn_forward / svoc_synth_infer (or this
  * function, which needs no synchronisation) fails with SVOC_ERR_HIP and clears the word.  Nothing in the reference corresponds (torch launches one
  * kernel per op). */
-int svoc_check_async_error(void);
+int svoc_check_async_error(void);             /* ABI 5 */
 /* diagnostics: raises that word from the host, exactly as a workgroup that gave up would (tests of the reporting path) */
 int svoc_debug_raise_async_error(void);
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVOC_LIB selects another build of the same library (A/B comparisons of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("SVOC_LIB") or os.path.join(_HERE, "csrc", "libsvoc_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

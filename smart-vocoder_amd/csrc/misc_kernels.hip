@@ -370,7 +370,7 @@ int k_fill(hipStream_t st, float* p, size_t n, float v) {
 
 extern "C" {
 const char* svoc_last_error(void) { return svoc::last_error(); }
-int svoc_abi_version(void) { return 4; }
+int svoc_abi_version(void) { return 5; }
 const char* svoc_build_arch(void) { return "gfx950"; }
 int svoc_stats_reset(void) { svoc::stats_reset(); return SVOC_OK; }
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches) {
