@@ -10,15 +10,18 @@
 //   * per layer two hand-overs through device memory instead of two launches: the acts rows (all twelve workgroups of a tile need all 192 rows for
 //     the 1 x 1) and the x rows (the twelve of the tile and of its two neighbours need them: the k = 5 halo).  Producer: device-coherent stores (sc1:
 //     write-through), s_waitcnt vmcnt(0), workgroup barrier, thread 0 raises the workgroup's flag.  Consumer: wave 0 polls the 12 (acts) or 36 (x)
-//     flags with ONE load per poll, barrier, sc1 loads of the tile.  No grid-wide barrier, no atomics on a shared word.
-//   * the layer's weights (72 + 48 registers per lane) are requested BEFORE the waits that precede their use - they are in flight while the
-//     workgroup polls.
+//     flags (a 128-byte line each) with ONE load per poll, barrier, sc1 loads of the tile.  No grid-wide barrier, no atomics on a shared word.
+//     x rows are 32 floats on a line of their own; the first and last four columns of a tile travel a second time, packed, for the neighbours.
+//   * the layer's weights (72 + 48 registers per lane, 195 KB per workgroup) are requested where nothing waits behind them: the 1 x 1 operands ahead of
+//     the in_layer's MFMA stream, the NEXT layer's in_layer operands inside it, each register set right behind the step that consumed it.
+//   * measured per layer at 1 x 200 (tools/wn_mesh_timeline.py, profiles/r05_wn_mesh_phase_stamps.txt): 10.4 us = acts hand-over 2.1 + 1 x 1 1.3 + x hand-over
+//     2.5 + transform 0.8 + stream and output transform 2.9 + gate 0.3 + 0.5.
 //   * the skip sum lives in registers for the whole stack; x rows in a double buffer by layer parity (the neighbour tile may still be reading
 //     x_{i-1} when this tile's x_i is ready; x_{i+1} is only written after the neighbour's acts of layer i-1, i.e. after its last read of x_{i-1});
 //     acts in a single buffer (a workgroup writes acts_i behind its tile's twelve x_i flags, each raised after that workgroup's last read of
 //     acts_{i-1}).
 // Every workgroup of the launch must be resident at once: the launcher takes the stack only while the grid is at most HALF the CUs (two
-// processes sharing a GPU then both fit; wn_stack.hip's bounded waits and error word otherwise).  Flags are cleared by the last workgroup out.
+// processes sharing a GPU then both fit; wn_stack.hip's bounded waits and host-visible error word otherwise).  Flags are cleared by the last workgroup out.
 // H = 192, k = 5, dilation 1, no conditioning input; n_layers >= 2.
 #include "svoc_internal.h"
 #include "wino_common.h"
