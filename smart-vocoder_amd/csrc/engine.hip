@@ -63,7 +63,7 @@ struct WNStack {
       if (K == 5 && d == 1) SVOC_TRY(pack_wn_mesh(*in_mesh.back(), in_f25.back()->f(), st));
       d *= DR;
     }
-    if (wn_mesh_applies(H, K, DR, NL, 1, 32)) {      // (conditioned calls - g given - take the per-layer chain)
+    if (wn_mesh_supported(H, K, DR, NL)) {      // (conditioned calls - g given - take the per-layer chain)
       const PackedConv* il[16]; const float* wm[16]; const float* wr[16];
       bool all = NL <= 16;
       for (int i = 0; i < NL && all; ++i) { il[i] = in_l[i].get(); wm[i] = in_mesh[i]->f(); wr[i] = rs16[i]->f(); all = wm[i] != nullptr && wr[i] != nullptr; }

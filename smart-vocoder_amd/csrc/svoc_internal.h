@@ -241,6 +241,7 @@ bool wn_layer_prefers_unfused(int B, int T);              // short inputs: fewer
 // wn_mesh.hip: a whole WN stack for SHORT inputs in one persistent launch (twelve workgroups per 32-column tile, two hand-overs per layer)
 bool wn_mesh_enabled();
 size_t wn_mesh_scratch_bytes();
+bool wn_mesh_supported(int H, int K, int dil_rate, int NL);
 bool wn_mesh_applies(int H, int K, int dil_rate, int NL, int B, int T);
 int pack_wn_mesh(DevBuf& img, const float* f25, hipStream_t st);
 int wn_mesh_prepare(float* scratch, const PackedConv* const* in_l, const float* const* wm, const float* const* wrs, int NL, hipStream_t st);

@@ -423,12 +423,15 @@ np.save({str(tmp_path / 'y.npy')!r}, y.cpu().numpy())
     assert np.array_equal(np.load(str(tmp_path / "y.npy")), y.cpu().numpy()), "persistent stack differs from the per-layer launches"
 
 
-@pytest.mark.parametrize("n_layers,B,Tn", [(16, 1, 200), (8, 1, 200), (8, 2, 100), (2, 10, 7), (3, 1, 320), (4, 2, 33)])
+@pytest.mark.parametrize("n_layers,B,Tn", [(16, 1, 200), (8, 1, 200), (8, 2, 100), (2, 10, 7), (3, 1, 320), (4, 2, 33),
+                                           (16, 1, 512), (8, 1, 640), (3, 2, 288), (4, 2, 200), (2, 5, 33)])
 def test_wn_mesh_short_inputs_one_persistent_launch(M, n_layers, B, Tn):
     """A whole WN stack for SHORT inputs in ONE persistent launch (csrc/wn_mesh.hip; reference modules.py:148-176): twelve workgroups per
     32-column tile that hand acts rows and x rows (with the k = 5 halo of the neighbouring tiles) to each other twice per layer.  BASELINE
     configs[0] (1 x 200: seven tiles, the last of 8 columns), ragged batches, ten one-tile utterances (no neighbours), the largest grid the
-    launcher takes (1 x 320: ten tiles = 120 of 256 CUs), a last tile of ONE column.  Against the oracle; run to run bit-identical."""
+    launcher takes with one tile per workgroup group (1 x 320: ten tiles = 120 of 256 CUs), a last tile of ONE column; then TWO tiles per group (11 .. 20
+    tiles): 1 x 512, the largest input (1 x 640), odd tile counts per utterance (2 x 288: nine tiles, 2 x 200: seven - the last group holds one tile), five
+    two-tile utterances.  Against the oracle; run to run bit-identical."""
     import os
     if any(os.environ.get(k) == "0" for k in ("SVOC_WN_MESH", "SVOC_WN_F25", "SVOC_WN_SMALL", "SVOC_WN_SMALL_F25", "SVOC_FUSE_WN")):
         pytest.skip("a variant run that switches the short-input kernels off")
