@@ -44,6 +44,6 @@ ls -la $O
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt200 --output-format csv -- python $R/tools/small_shape_run.py 1 200 20 > /dev/null 2>&1; python $R/tools/timeline.py /tmp/kt200 400 > $O/${TAG}_kernel_timeline_1x200_graph.txt 2>&1 )
 ls -la $O
 # round 5: the short-input persistent WN launch (phase stamps) and both persistent launches with several processes on the one GPU
-( cd $R && python tools/wn_mesh_timeline.py 1 200 16; python tools/wn_mesh_timeline.py 1 200 8; python tools/wn_mesh_timeline.py 2 150 8 ) > $O/${TAG}_wn_mesh_phase_stamps.txt 2>/dev/null
-( cd $R && for n in 2 4; do echo "== $n processes, 1 x 200 (csrc/wn_mesh.hip)"; timeout 200 python tools/wn_stack_shared_gpu.py $n 2000 1 200; done; for n in 2 4; do echo "== $n processes, 16 x 512 (csrc/wn_stack.hip)"; timeout 300 python tools/wn_stack_shared_gpu.py $n 200; done ) > $O/${TAG}_persistent_launches_shared_gpu.txt 2>&1
+( cd $R && python tools/wn_mesh_timeline.py 1 200 16; python tools/wn_mesh_timeline.py 1 200 8; python tools/wn_mesh_timeline.py 2 150 8; python tools/wn_mesh_timeline.py 1 512 16 ) > $O/${TAG}_wn_mesh_phase_stamps.txt 2>/dev/null
+( cd $R && for n in 2 4; do echo "== $n processes, 1 x 200 (csrc/wn_mesh.hip)"; timeout 200 python tools/wn_stack_shared_gpu.py $n 2000 1 200; done; echo "== 2 processes, 1 x 512 (csrc/wn_mesh.hip, two tiles per group)"; timeout 200 python tools/wn_stack_shared_gpu.py 2 2000 1 512; for n in 2 4; do echo "== $n processes, 16 x 512 (csrc/wn_stack.hip)"; timeout 300 python tools/wn_stack_shared_gpu.py $n 200; done ) > $O/${TAG}_persistent_launches_shared_gpu.txt 2>&1
 ls -la $O
