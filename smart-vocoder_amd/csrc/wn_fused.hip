@@ -792,7 +792,9 @@ __global__ void wnf_scale_kernel(const float* __restrict__ v, const float* __res
 bool wn_layer_prefers_unfused(int B, int T) {
   static const bool small_on = !(getenv("SVOC_WN_SMALL") && atoi(getenv("SVOC_WN_SMALL")) == 0);
   static const int tiles = getenv("SVOC_WN_SMALL_TILES") ? atoi(getenv("SVOC_WN_SMALL_TILES")) : 0;      // tunable: 32-column tiles below which a layer is "short"
-  return small_on && (long long)variant_batch(B) * ((T + 31) / 32) < (tiles > 0 ? tiles : device_cu_count() / 2);
+  // default 3/8 of the CUs (96 tiles; half of them until round 5): ms per infer call with the short-input chain | with the persistent stack launch at
+  // 72 tiles (9 x 256) 9.68 | 10.06, 80 (5 x 512) 10.18 | 10.58, 96 (6 x 512) 12.37 | 11.85, 112 (7 x 512) 13.79 | 13.33: profiles/r05_wn_short_input_threshold.txt
+  return small_on && (long long)variant_batch(B) * ((T + 31) / 32) < (tiles > 0 ? tiles : device_cu_count() * 3 / 8);
 }
 bool wn_f25_enabled() {
   static const bool on = !(getenv("SVOC_WN_F25") && atoi(getenv("SVOC_WN_F25")) == 0);      // SVOC_WN_F25=0: the direct-form layer kernels

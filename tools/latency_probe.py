@@ -10,7 +10,10 @@ from smart_vocoder_amd import models
 net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}, strict=False)
 net = net.cuda().eval()
-for (B, T) in ((1, 200), (1, 512), (4, 512), (16, 512), (32, 512), (8, 4096)):
+SHAPES = ((1, 200), (1, 512), (4, 512), (16, 512), (32, 512), (8, 4096))
+if len(sys.argv) > 1:      # python tools/latency_probe.py 2x512 6x512 ...
+    SHAPES = tuple(tuple(int(v) for v in a.split("x")) for a in sys.argv[1:])
+for (B, T) in SHAPES:
     mel = torch.from_numpy(sw.synthetic_mel(1, B, T)).cuda(); eps = torch.from_numpy(sw.synthetic_eps(1, B, T)).cuda()
     ln = torch.full((B,), T, dtype=torch.int64).cuda()
     for _ in range(3):
