@@ -25,7 +25,10 @@ static std::mutex g_dev_mu;
 // three streams: half a tile per CU.  (Two per CU until round 5 - round 3's break-even for the F(2,3) kernels; with the F(4,4) kernels, ms per
 // call at 2 / 1 / 0.5 / 0.25 / 0 tiles per CU: 1 x 200 2.56 / 2.55 / 2.44 / 2.52 / 2.52, 1 x 512 4.33 / 3.86 / 3.71 / 3.70 / 3.72, 4 x 512 unchanged:
 // profiles/r05_small_shape_tile_gates.txt.)
-long long mrf_min_tiles() { return device_cu_count() / 2; }
+long long mrf_min_tiles() {
+  static const long long cfg = getenv("SVOC_MRF_MIN_TILES") ? atoll(getenv("SVOC_MRF_MIN_TILES")) : -1;      // tunable, as SVOC_CT_MIN_TILES
+  return cfg >= 0 ? cfg : device_cu_count() / 2;
+}
 int device_cu_count() {
   static int cus[64] = {};
   int d = 0;
