@@ -54,7 +54,7 @@ VARIANTS = {
 
 
 def _jobs():
-    return max(1, int(os.environ.get("SVOC_VARIANT_JOBS", "4")))
+    return max(1, int(os.environ.get("SVOC_VARIANT_JOBS", "2")))
 
 
 def _run_variant(name):
@@ -72,8 +72,10 @@ def _run_variant(name):
 
 
 # The variant processes spend most of their time on the host (interpreter start, weight generation, the oracle's float64
-# convolutions), so SVOC_VARIANT_JOBS of them (default 4) run side by side: the first test starts them all, every test collects
-# its own result.  Parity only - nothing here is timed, so sharing the GPU is harmless.
+# convolutions), so SVOC_VARIANT_JOBS of them run side by side: the first test starts them all, every test collects its own result.
+# Parity only - nothing here is timed.  TWO at a time since round 5 (four until then): the persistent WN launches (csrc/wn_stack.hip,
+# csrc/wn_mesh.hip) are validated for two processes on one GPU; with four, launches of the 16-layer stack can hold each other's CUs until their
+# bounded waits give up (profiles/r05_z_persistent_launches_shared_gpu.txt) - reported, but a failed test all the same.
 _POOL = None
 _FUTURES = {}
 
