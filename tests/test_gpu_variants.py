@@ -35,7 +35,7 @@ pytestmark = pytest.mark.gpu
 DEC = ("test_conv1d_winograd or test_resblock1 or test_generator or test_infer_vs_reference_golden or test_infer_long_form_tiling")
 WNS = "test_wn or test_coupling or test_infer_vs_reference_golden or test_full_size_properties"
 SMALL = "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_generator or test_wn or test_resblock1"
-UPS = "test_conv_transpose or test_generator or test_infer_vs_reference_golden or test_c2_full_size_vs_oracle"
+UPS = "test_conv_transpose or test_generator or test_infer_vs_reference_golden or test_full_size_vs_reference_fixture"
 
 VARIANTS = {
     "unfused": ({"SVOC_FUSE": "0", "SVOC_FUSE_WN": "0"}, DEC + " or " + WNS),
