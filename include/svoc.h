@@ -88,14 +88,25 @@ double svoc_stats_executed_flops(void);
  * previous value.  Replaces nothing in the reference (it has one code path per op: torch's). */
 int svoc_set_variant_batch(int n);
 /* Two kernels of the path are PERSISTENT launches whose workgroups wait for each other (a whole WN stack per launch: csrc/wn_stack.hip,
- * csrc/wn_mesh.hip).  Alone on a GPU - one process per GPU is the deployment - every workgroup is resident and nothing
- * waits for long; when MANY processes share one GPU two such launches can hold each other's CUs, so every wait is bounded by 30 s of wall time:
- * a workgroup that gives up raises a host-visible word, the call's outputs are wrong, and the NEXT svoc_wn_forward / svoc_synth_infer (or this
- * function, which needs no synchronisation) fails with SVOC_ERR_HIP and clears the word.  Nothing in the reference corresponds (torch launches one
- * kernel per op). */
+ * csrc/wn_mesh.hip).  They are taken only while the runtime's occupancy calculator says the whole grid can be resident on the device
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs, asked once per kernel and device).  Alone on a GPU - one process per GPU is the deployment
+ *  - nothing waits for long; when other work shares the GPU two such launches can hold each other's CUs, so every wait is
+ * bounded by wall time: SVOC_PERSIST_TIMEOUT_MS, default 2000.  A workgroup that gives up
+ *   (1) turns its part of THAT call's result into NaN (the stack's output rows of its tile, and through them the call's waveform: the reference's
+ *       WN.forward, modules.py:148-176, cannot return a wrong finite tensor, and neither can this one),
+ *   (2) raises a host-visible word: the NEXT svoc_wn_forward / svoc_synth_infer - or svoc_check_async_error(), which needs no synchronisation and
+ *       can be called right behind the caller's own stream synchronisation of the affected call - fails with SVOC_ERR_HIP and clears the word,
+ *   (3) and from that report on the process runs one launch per WN layer (same function, bit-identical for the stack launch); captured plans are
+ *       captured again.
+ * Nothing in the reference corresponds (torch launches one kernel per op). */
 int svoc_check_async_error(void);             /* ABI 5 */
+/* *disabled = 1 once (3) has happened; *timeout_ms = the bound in force.  Either pointer may be NULL.  ABI 6 */
+int svoc_persist_state(int* disabled, int* timeout_ms);
 /* diagnostics: raises that word from the host, exactly as a workgroup that gave up would (tests of the reporting path) */
 int svoc_debug_raise_async_error(void);
+/* diagnostics (ABI 6): fault_tile >= 0 makes the workgroup of that 32-column tile withhold the flags its neighbours wait for in every persistent
+ * launch from now on (-1: off); timeout_ms > 0 overrides SVOC_PERSIST_TIMEOUT_MS (<= 0: the configured bound); reenable != 0 undoes (3). */
+int svoc_debug_persist_control(int fault_tile, int timeout_ms, int reenable);
 
 /* Diagnostics: bracket every convolution launch with HIP events and aggregate by layer shape. */
 int svoc_profile_enable(int on);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVOC_LIB selects another build of the same library (A/B comparisons of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("SVOC_LIB") or os.path.join(_HERE, "csrc", "libsvoc_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 
@@ -56,6 +56,8 @@ SIGNATURES = {
     "svoc_set_variant_batch": (_I, [_I]),
     "svoc_check_async_error": (_I, []),
     "svoc_debug_raise_async_error": (_I, []),
+    "svoc_persist_state": (_I, [_P, _P]),
+    "svoc_debug_persist_control": (_I, [_I, _I, _I]),
     "svoc_profile_enable": (_I, [_I]),
     "svoc_profile_report": (_I, [C.c_char_p, _I]),
     "svoc_debug_set_stamp_buffer": (_I, [_P]),
@@ -230,6 +232,19 @@ def set_variant_batch(n):
 def check_async_error():
     """Raises when a persistent WN launch of an earlier call gave up one of its bounded waits (include/svoc.h svoc_check_async_error)."""
     check(lib().svoc_check_async_error())
+
+
+def persist_state():
+    """(disabled, timeout_ms) of the persistent WN launches: `disabled` is True once a launch gave up a wait and the process fell back to one
+    launch per WN layer; `timeout_ms` is the bound of a wait (SVOC_PERSIST_TIMEOUT_MS).  include/svoc.h svoc_persist_state."""
+    d, t = C.c_int(0), C.c_int(0)
+    check(lib().svoc_persist_state(C.byref(d), C.byref(t)))
+    return bool(d.value), t.value
+
+
+def debug_persist_control(fault_tile=-1, timeout_ms=0, reenable=False):
+    """Diagnostics (tests): see include/svoc.h svoc_debug_persist_control."""
+    check(lib().svoc_debug_persist_control(int(fault_tile), int(timeout_ms), 1 if reenable else 0))
 
 
 class variant_batch:

@@ -982,6 +982,7 @@ struct Synth {
     auto mix = [&](const void* q) { h = (h ^ (unsigned long long)reinterpret_cast<uintptr_t>(q)) * 1099511628211ull; };
     mix(ws.p); mix(enc.ws.p); mix(dec.ws.p);
     for (auto* c : flow.rev_p) { mix(c->ws.p); mix(c->enc.ws.p); }
+    mix(reinterpret_cast<const void*>((uintptr_t)persist_epoch()));      // the persistent launches' controls changed (a wait was given up: per-layer launches from now on)
     return h;
   }
   struct PlanKey {

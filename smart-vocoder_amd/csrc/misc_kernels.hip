@@ -9,7 +9,9 @@
 #include <cstring>
 #include <algorithm>
 #include <mutex>
+#include <map>
 #include <set>
+#include <tuple>
 
 namespace svoc {
 
@@ -52,8 +54,11 @@ int ensure_max_dyn_lds(const void* kernel) {
 }
 
 // Asynchronous failures of the persistent launches (wn_stack.hip, wn_mesh.hip): their workgroups wait for each other, the waits are bounded by wall
-// time, and a workgroup that gives up raises this word - pinned host memory the device writes through, so the host can read it without a
-// synchronisation.  It is looked at when the next call comes in (WNStack::forward, Synth::infer) and through svoc_check_async_error().
+// time (SVOC_PERSIST_TIMEOUT_MS, default 2000), and a workgroup that gives up (a) turns its part of the SAME call's result into NaN - its mask
+// factor becomes NaN, so its x tile, the edges its neighbours fetch and its rows of the stack's output are NaN and the waveform of the call is not
+// finite - and (b) raises this word - pinned host memory the device writes through, so the host can read it without a synchronisation.  The word is
+// looked at when the next call comes in (WNStack::forward, Synth::infer) and through svoc_check_async_error(); the first time it is found raised the
+// process stops taking the persistent launches (the per-layer kernels compute the same function): persist_disabled().
 static int* g_async_err = nullptr;
 int* async_error_word() {
   std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -65,13 +70,58 @@ int* async_error_word() {
   }
   return g_async_err;
 }
+static std::atomic<int> g_persist_off{0}, g_persist_fault{-1}, g_persist_timeout_ms{-1};
+static std::atomic<unsigned> g_persist_epoch{0};
+bool persist_disabled() { return g_persist_off.load(std::memory_order_relaxed) != 0; }
+int persist_fault_tile() { return g_persist_fault.load(std::memory_order_relaxed); }
+unsigned persist_epoch() { return g_persist_epoch.load(std::memory_order_relaxed); }
+int persist_timeout_ms() {
+  static const int env = [] {
+    const char* e = getenv("SVOC_PERSIST_TIMEOUT_MS");
+    const long v = e ? atol(e) : 2000;
+    return (int)std::min<long>(std::max<long>(v, 1), 600000);
+  }();
+  const int o = g_persist_timeout_ms.load(std::memory_order_relaxed);
+  return o > 0 ? o : env;
+}
+unsigned long long persist_timeout_ticks() { return (unsigned long long)persist_timeout_ms() * 100000ull; }      // s_memrealtime: 100 MHz
+int persist_control(int fault_tile, int timeout_ms, int reenable) {
+  g_persist_fault.store(fault_tile, std::memory_order_relaxed);
+  g_persist_timeout_ms.store(timeout_ms, std::memory_order_relaxed);
+  if (reenable) g_persist_off.store(0, std::memory_order_relaxed);
+  g_persist_epoch.fetch_add(1, std::memory_order_relaxed);      // captured plans hold the old launch arguments: they are captured again
+  return SVOC_OK;
+}
 int async_error_check() {
   int* w = g_async_err;
   if (!w) return SVOC_OK;
   if (__atomic_load_n(w, __ATOMIC_RELAXED) == 0) return SVOC_OK;
-  __atomic_store_n(w, 0, __ATOMIC_RELAXED);
-  SVOC_FAIL(SVOC_ERR_HIP, "a persistent WN launch of an EARLIER call gave up waiting for its other workgroups after 30 s (the GPU is shared by more "
-                          "processes than the launch can be resident beside: SVOC_WN_STACK=0 SVOC_WN_MESH=0 select the per-layer launches); the outputs of that call are wrong");
+  if (__atomic_exchange_n(w, 0, __ATOMIC_ACQ_REL) == 0) return SVOC_OK;      // (another thread reported it)
+  g_persist_off.store(1, std::memory_order_relaxed);
+  g_persist_epoch.fetch_add(1, std::memory_order_relaxed);
+  SVOC_FAIL(SVOC_ERR_HIP, "a persistent WN launch of an EARLIER call gave up waiting for its other workgroups after %d ms (SVOC_PERSIST_TIMEOUT_MS): the GPU "
+                          "is shared by more work than the launch can be resident beside.  The outputs of that call are NaN where the launch gave up; this "
+                          "process runs one launch per WN layer from now on (SVOC_WN_STACK=0 SVOC_WN_MESH=0 select that from the start)", persist_timeout_ms());
+}
+// Workgroups of `kernel` (block threads, dynamic LDS bytes) that the CURRENT device can hold at one time, as the runtime's occupancy calculator sees
+// it - the residency the persistent launches need is asked for, not assumed (0: the query failed, the caller does not take the launch)
+int persist_capacity(const void* kernel, int threads, size_t lds_bytes) {
+  static std::map<std::tuple<const void*, int, int, size_t>, int> cache;
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) return 0;
+  const auto key = std::make_tuple(kernel, d, threads, lds_bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
+  if (ensure_max_dyn_lds(kernel) != SVOC_OK) return 0;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+  const int cap = per_cu > 0 ? per_cu * device_cu_count() : 0;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  cache[key] = cap;
+  return cap;
 }
 
 static long long* g_stamp_buffer = nullptr;
@@ -373,7 +423,7 @@ int k_fill(hipStream_t st, float* p, size_t n, float v) {
 
 extern "C" {
 const char* svoc_last_error(void) { return svoc::last_error(); }
-int svoc_abi_version(void) { return 5; }
+int svoc_abi_version(void) { return 6; }
 const char* svoc_build_arch(void) { return "gfx950"; }
 int svoc_stats_reset(void) { svoc::stats_reset(); return SVOC_OK; }
 int svoc_stats_get(int64_t* conv_launches, double* conv_flops, int64_t* other_launches) {
@@ -392,6 +442,12 @@ int svoc_debug_raise_async_error(void) {
   int* w = svoc::async_error_word();
   if (!w) SVOC_FAIL(SVOC_ERR_NOMEM, "svoc_debug_raise_async_error: no pinned host memory");
   __atomic_store_n(w, 1, __ATOMIC_RELAXED);
+  return SVOC_OK;
+}
+int svoc_debug_persist_control(int fault_tile, int timeout_ms, int reenable) { return svoc::persist_control(fault_tile, timeout_ms, reenable); }
+int svoc_persist_state(int* disabled, int* timeout_ms) {
+  if (disabled) *disabled = svoc::persist_disabled() ? 1 : 0;
+  if (timeout_ms) *timeout_ms = svoc::persist_timeout_ms();
   return SVOC_OK;
 }
 int svoc_profile_enable(int on) { svoc::prof_enable(on != 0); return SVOC_OK; }

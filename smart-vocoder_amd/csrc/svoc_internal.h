@@ -170,6 +170,16 @@ int device_cu_count();                       // compute units of the CURRENT dev
 long long mrf_min_tiles();                   // fewest tiles for the grouped / paired / accumulate Winograd launches of the MRF
 int* async_error_word();                     // pinned host word the persistent launches raise when a bounded wait gives up (null: allocation failed)
 int async_error_check();                     // SVOC_OK, or fails (once) when that word was raised since the last check
+// the persistent launches' run-time controls (misc_kernels.hip): bound of their waits in ticks of the 100 MHz wall counter (SVOC_PERSIST_TIMEOUT_MS,
+// default 2000), the tile whose workgroup withholds its flags (diagnostics: -1), "a wait was given up: per-layer launches from now on", a counter
+// that moves when any of them changes (captured plans are captured again), and what the occupancy calculator says a kernel's residency is
+unsigned long long persist_timeout_ticks();
+int persist_timeout_ms();
+int persist_fault_tile();
+bool persist_disabled();
+unsigned persist_epoch();
+int persist_control(int fault_tile, int timeout_ms, int reenable);
+int persist_capacity(const void* kernel, int threads, size_t lds_bytes);
 int ensure_max_dyn_lds(const void* kernel);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB) once per (kernel, device)
 
 struct ConvGroup { ConvArgs a[3]; int end[3]; };     // conv_group_kernel: end[i] = first workgroup id after problem i

@@ -22,8 +22,10 @@
 //     acts_{i-1}).
 //   * inputs of 11 .. 20 tiles (1 x 512): TWO neighbouring tiles per group of twelve workgroups (template parameter NT), one after the other with the
 //     layer's weights in registers once; everything above stays per tile.  17.8 us per layer for the two tiles at 1 x 512.
-// Every workgroup of the launch must be resident at once: the launcher takes the stack only while the grid is at most HALF the CUs (two
-// processes sharing a GPU then both fit; wn_stack.hip's bounded waits and host-visible error word otherwise).  Flags are cleared by the last workgroup out.
+// Every workgroup of the launch must be resident at once: the launcher takes the stack only while the grid is at most HALF of what the occupancy
+// calculator says the device holds of this kernel (two processes sharing a GPU then both fit).  Otherwise wn_stack.hip's rules: waits bounded by
+// SVOC_PERSIST_TIMEOUT_MS; a workgroup that gives up makes its mask factor NaN (its x rows, skip sums and so the call's result are NaN - never a finite
+// wrong tensor), stops waiting, and raises the host-visible error word.  Flags are cleared by the last workgroup out.
 // H = 192, k = 5, dilation 1, no conditioning input; n_layers >= 2.
 #include "svoc_internal.h"
 #include "wino_common.h"
@@ -39,7 +41,7 @@ constexpr int WNM_R = 12;                                   // workgroups per co
 constexpr int WNM_AROW = 48;                                // acts tile row stride (columns 0 .. 31 used; 48: the B reads of the 1 x 1 are conflict-free)
 constexpr int WNM_MAXL = 16;
 constexpr int WNM_FS = 32;                                  // ints between two flags
-constexpr int WNM_LDS_FLOATS = WNF_H * WNF_XROW + 6 * WNF_PLANE + WNM_MAXL * 8;      // x tile | planes | the layer table
+constexpr int WNM_LDS_FLOATS = WNF_H * WNF_XROW + 6 * WNF_PLANE + WNM_MAXL * 8 + 4;      // x tile | planes | the layer table | the give-up flag
 static_assert(WNF_H * WNM_AROW <= 6 * WNF_PLANE && 8 * 16 * 64 <= 6 * WNF_PLANE, "acts tile and reduction area alias the planes");
 
 struct WnMeshLayer {
@@ -59,6 +61,8 @@ struct WnMeshArgs {
   float* ag; int ag_ld; long long ag_bs;                // acts rows: [B][H][32 ntx]
   int* fa; int* fx;                                     // [tiles][12] x WNM_FS ints (one 128-byte line per flag): acts layers written / x layers written
   int* exited; int* err;                                // [17] two-level exit count; error word
+  unsigned long long timeout;                           // bound of a wait in ticks of the 100 MHz wall counter
+  int fault_tile;                                       // diagnostics: workgroup 0 of this tile never raises its x flags (-1: none)
   long long* dbg;                                       // diagnostics: [workgroup][16] wall-clock stamps (10 ns) of thread 0 in layer NL / 2 (tools/wn_mesh_timeline.py)
 };
 
@@ -74,8 +78,10 @@ __device__ __forceinline__ void wnm_st4_sc1(const __amdgpu_buffer_rsrc_t rs, flo
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 16);
 }
 
-// wave 0: wait until the `n` flags f[0 .. n) (lanes with valid == false excepted) have reached `want`; bounded by 30 s of wall time
-__device__ __forceinline__ void wnm_wait(const int* f, int n, bool valid, int want, int* err) {
+// wave 0: wait until the `n` flags f[0 .. n) (lanes with valid == false excepted) have reached `want`; bounded by `timeout` ticks of wall time.  A wait
+// that gives up sets *bad (LDS: the workgroup's results are NaN from then on, and it does not wait again) and raises the host's error word.
+__device__ __forceinline__ void wnm_wait(const int* f, int n, bool valid, int want, int* err, volatile int* bad, unsigned long long timeout) {
+  if (*bad != 0) return;
   const int lane = threadIdx.x & 63;
   const bool mine = lane < n && valid;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -83,8 +89,8 @@ __device__ __forceinline__ void wnm_wait(const int* f, int n, bool valid, int wa
     const int v = mine ? __hip_atomic_load(f + lane * WNM_FS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
     if (__builtin_amdgcn_ballot_w64(v < want) == 0) break;
     __builtin_amdgcn_s_sleep(1);
-    if (__builtin_amdgcn_s_memrealtime() - t_start > 3000000000ull) {
-      if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (__builtin_amdgcn_s_memrealtime() - t_start > timeout) {
+      if (lane == 0) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); *bad = 1; }
       break;
     }
   }
@@ -104,7 +110,9 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
   // the layer table, copied once: read from device memory per layer its pointers were two dependent ~0.8 us round trips ahead of every weight request
   WnMeshLayer* const TBL = reinterpret_cast<WnMeshLayer*>(PLN + 6 * PLANE);
   static_assert(sizeof(WnMeshLayer) == 32, "eight words per layer");
+  volatile int* const BAD = reinterpret_cast<volatile int*>(PLN + 6 * PLANE + WNM_MAXL * 8);
   if (threadIdx.x < (unsigned)p.NL * 8) reinterpret_cast<int*>(TBL)[threadIdx.x] = reinterpret_cast<const int*>(p.layers)[threadIdx.x];
+  if (threadIdx.x == 0) *BAD = 0;
   __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -194,9 +202,13 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
         if (j < nact) {
           const int gt = gt0 + j, t0 = (tile0 + j) * 32;
           if (j == 0) stamp(0);
-          if (wave == 0) wnm_wait(p.fa + gt * WNM_R * WNM_FS, WNM_R, true, li, p.err);
+          if (wave == 0) wnm_wait(p.fa + gt * WNM_R * WNM_FS, WNM_R, true, li, p.err, BAD, p.timeout);
           if (j == 0) stamp(1);
           __syncthreads();
+          if (*BAD != 0) {
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) mk_rs[jj] = __builtin_nanf("");
+          }
           {   // acts_{li-1} tile: H rows x 32 columns = 1536 sixteen-byte groups, three per thread
             const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)b * p.ag_bs + t0) * 4));
 #pragma unroll
@@ -243,7 +255,7 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
             if (j == 0) stamp(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the x stores are acknowledged (write-through) ...
             __syncthreads();                                      // (... and every wave is done with the acts tile)
-            if (tid == 0) __hip_atomic_store(p.fx + (gt * WNM_R + r) * WNM_FS, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
+            if (tid == 0 && !(gt == p.fault_tile && r == 0)) __hip_atomic_store(p.fx + (gt * WNM_R + r) * WNM_FS, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
             if (j == 0) stamp(4);
           } else __syncthreads();
         }
@@ -290,10 +302,14 @@ __global__ void __launch_bounds__(512) wn_mesh_f25_kernel(const WnMeshArgs p) {
           if (wave == 0) {   // x_li of this tile's and the two neighbours' workgroups: 36 flags, one load per poll
             const int d = lane / WNM_R - 1;
             const bool valid = lane < 3 * WNM_R && tile + d >= 0 && tile + d < ntx;
-            wnm_wait(p.fx + (gt - 1) * WNM_R * WNM_FS, 3 * WNM_R, valid, li, p.err);
+            wnm_wait(p.fx + (gt - 1) * WNM_R * WNM_FS, 3 * WNM_R, valid, li, p.err, BAD, p.timeout);
           }
           if (j == 0) stamp(5);
           __syncthreads();
+          if (*BAD != 0) {
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) mk_rs[jj] = __builtin_nanf("");
+          }
           // centre: H rows x 32 columns (one 128-byte line per row), three sixteen-byte groups per thread
           const int sb = __builtin_amdgcn_readfirstlane((int)(((long long)(li & 1) * p.xg_par + (long long)b * p.xg_bs + t0) * 4));
 #pragma unroll
@@ -492,7 +508,13 @@ bool wn_mesh_enabled() {
   static const bool on = wn_f25_enabled() && !(getenv("SVOC_WN_MESH") && atoi(getenv("SVOC_WN_MESH")) == 0);      // SVOC_WN_MESH=0: one launch per layer (wn_small.hip)
   return on;
 }
-static int wnm_max_groups() { return device_cu_count() / 2 / WNM_R; }      // twelve workgroups each: the grid stays within half the CUs
+// twelve workgroups each: the grid stays within half the CUs - and within half of what the occupancy calculator says the device holds of the kernel
+// (asked per launch form, cached; the scratch area is sized by the CU count)
+static int wnm_max_groups() { return device_cu_count() / 2 / WNM_R; }
+static int wnm_capacity(int NT) {
+  const void* k = NT == 1 ? (const void*)wn_mesh_f25_kernel<1> : (const void*)wn_mesh_f25_kernel<2>;
+  return std::min(persist_capacity(k, 512, (size_t)WNM_LDS_FLOATS * sizeof(float)), device_cu_count()) / 2 / WNM_R;
+}
 static int wnm_max_tiles() { return 2 * wnm_max_groups(); }                 // up to two tiles per group
 // scratch: x rows (two parities) | their packed edges (two parities) | acts rows | flags fa, fx (a line each) | exit counters [17] | (64-byte aligned) layer table
 static size_t wnm_x_floats() { return (size_t)2 * WNF_H * 32 * wnm_max_tiles() + (size_t)2 * wnm_max_tiles() * 2 * WNF_H * 4; }      // rows + packed edges, two parities each
@@ -504,15 +526,15 @@ size_t wn_mesh_image_floats() { return (size_t)WNM_R * 8 * 18 * 256; }
 // tiles per workgroup group for (B, T): 1 up to ten tiles, 2 (neighbouring tiles of one utterance) up to ten groups; 0 = the launch does not apply
 static int wnm_tiles_per_group(int B, int T) {
   const long long vb = std::max(B, variant_batch(B)), ntx = (T + 31) / 32;
-  if (vb * ntx <= wnm_max_groups()) return 1;
-  if (vb * ((ntx + 1) / 2) <= wnm_max_groups()) return 2;
+  if (vb * ntx <= wnm_max_groups()) return vb * ntx <= wnm_capacity(1) ? 1 : 0;
+  if (vb * ((ntx + 1) / 2) <= wnm_max_groups()) return vb * ((ntx + 1) / 2) <= wnm_capacity(2) ? 2 : 0;
   return 0;
 }
 bool wn_mesh_supported(int H, int K, int dil_rate, int NL) {      // the module: whatever the shapes that will come
   return wn_mesh_enabled() && H == WNF_H && K == 5 && dil_rate == 1 && NL >= 2 && NL <= WNM_MAXL;
 }
 bool wn_mesh_applies(int H, int K, int dil_rate, int NL, int B, int T) {
-  return wn_mesh_supported(H, K, dil_rate, NL) && B > 0 && T > 0 && wnm_tiles_per_group(B, T) != 0;
+  return wn_mesh_supported(H, K, dil_rate, NL) && !persist_disabled() && B > 0 && T > 0 && wnm_tiles_per_group(B, T) != 0;
 }
 int pack_wn_mesh(DevBuf& img, const float* f25, hipStream_t st) {
   if (!wn_mesh_enabled() || !f25) return SVOC_OK;
@@ -525,6 +547,7 @@ int pack_wn_mesh(DevBuf& img, const float* f25, hipStream_t st) {
 // Zeroes the scratch area (pad columns, flags, counters) and writes the layer table (once, when the WN module is created)
 int wn_mesh_prepare(float* scratch, const PackedConv* const* in_l, const float* const* wm, const float* const* wrs, int NL, hipStream_t st) {
   if (!scratch || NL > WNM_MAXL || NL < 2) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "wn_mesh_prepare: bad arguments");
+  if (!async_error_word()) SVOC_FAIL(SVOC_ERR_NOMEM, "wn_mesh_prepare: no pinned host memory for the error word");      // allocated here, never inside a caller's stream capture
   WnMeshLayer t[WNM_MAXL] = {};
   for (int i = 0; i < NL; ++i) { t[i].wm = wm[i]; t[i].bias1 = in_l[i]->bias.f(); t[i].wrs = wrs[i]; t[i].rs_tiles = i == NL - 1 ? 12 : 24; }
   SVOC_HIP(hipMemsetAsync(scratch, 0, wnm_table_offset(), st));
@@ -558,6 +581,8 @@ int launch_wn_mesh_f25(const PackedConv* const* in_l, const PackedConv* const* r
   a.err = async_error_word();                                // pinned host memory (misc_kernels.hip): looked at by the next call
   if (!a.err) return 1;
   a.dbg = debug_stamp_buffer();
+  a.timeout = persist_timeout_ticks();
+  a.fault_tile = persist_fault_tile();
   double flops = 0, exec = 0;
   for (int i = 0; i < NL; ++i) {
     flops += (in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;

@@ -7,10 +7,15 @@
 // the launch must be resident at once (they wait for each other): the launcher takes the stack only while there are no more tiles than CUs (one
 // 768-thread, 154 KB workgroup per CU).  When the GPU is shared, part of the launch is resident at first: workgroups are dispatched in tile order, the
 // lowest resident tile's left neighbour has finished, and a window of more than n_layers resident tiles always lets its low end run to completion and
-// free its CUs - progress needs n_layers + 1 CUs, not all of them.  The waits are bounded all the same (30 s of wall time): a workgroup that gives up
-// raises a host-visible error word (async_error_word(): the next call fails, include/svoc.h svoc_check_async_error) and goes on - never a hung GPU.
+// free its CUs - progress needs n_layers + 1 CUs, not all of them.  The waits are bounded all the same (SVOC_PERSIST_TIMEOUT_MS of wall time, default
+// 2 s; the launcher also asks the occupancy calculator whether the grid CAN be resident): a workgroup that gives up (a) poisons the call it is part
+// of - its mask factor becomes NaN, so its x tile, the edges its neighbours fetch from it and its rows of the stack's output are NaN from that layer
+// on, and the reference's WN.forward cannot return a wrong finite tensor either (modules.py:148-176) -, (b) stops waiting for the rest of the launch,
+// (c) raises a host-visible error word (async_error_word(): the next call fails with the reason and the process takes the per-layer launches from
+// then on, include/svoc.h svoc_check_async_error) - never a hung GPU, never a finite wrong result.
 // Memory ordering (gfx950, one L2 per XCD): edges and counters are device-scope relaxed atomics (sc1: they bypass the non-coherent caches in both
-// directions); the writer waits for its edge stores' acknowledgements (s_waitcnt vmcnt(0) - a workgroup-scope release fence) ahead of the workgroup
+// directions); the waves that store edges wait for the stores' acknowledgements with an explicit s_waitcnt vmcnt(0) (a workgroup-scope release fence
+// alone compiles to s_waitcnt lgkmcnt(0) on gfx950: ADVICE r5) ahead of the workgroup
 // barrier behind which thread 0 raises the counter; the reader's edge loads are issued behind the barrier that follows the successful poll.  No
 // L2 write-back or invalidate is involved, so the weight images stay cached.  Every (layer, tile, edge) has a halo slot of its OWN, written once per
 // launch.  The hand-shake counters are cleared by the last workgroup to LEAVE a launch, not by a memset ahead of it (see launch_wn_stack_f25: inside a
@@ -44,6 +49,8 @@ struct WnStackArgs {
   int* done;                                            // [tiles]: layers completed   } clears both for the next one (no memset node: see launch_wn_stack_f25)
   int* err;                                             // raised when a bounded wait gave up
   long long* dbg;
+  unsigned long long timeout;                           // bound of a wait in ticks of the 100 MHz wall counter (persist_timeout_ticks())
+  int fault_tile;                                       // diagnostics: this tile's workgroup never raises its layer counter (-1: none)
 };
 
 typedef unsigned int wnk_u32x4 __attribute__((ext_vector_type(4)));
@@ -55,6 +62,8 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
   float* const PLN = lds + H * WNF_XROW;                    // V_p [6][H][16]; the acts tile [H][33] aliases it from the gate on
   float* const AT = PLN;
   float* const RED = PLN + 6 * WNF_PLANE;                   // exchange area [12 waves][16][64]
+  volatile int* const BAD = reinterpret_cast<volatile int*>(lds + WNF_LDS_FLOATS);      // set by a wait that gave up: the workgroup's results are NaN from then on
+  if (threadIdx.x == 0) *BAD = 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -100,7 +109,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
     }
   }
   const bool col_ok = t0 + l31 < p.T;                       // this lane's column in phase B / the epilogue: t0 + l31
-  const float mk = col_ok ? p.mask[(long long)b * p.mask_bs + t0 + l31] : 0.f;
+  float mk = col_ok ? p.mask[(long long)b * p.mask_bs + t0 + l31] : 0.f;
   __syncthreads();
 
   for (int li = 0; li < NL; ++li) {
@@ -137,7 +146,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
     wload(a[0], w0); wload(a[1], w0 + 1024); wload(a[2], w0 + 2048);
     // ---- the neighbours' edges of x_li (what they computed in layer li - 1): tile columns 2, 3 (t0 - 2, t0 - 1) and 36, 37 (t0 + 32, t0 + 33)
     if (li > 0) {
-      if ((tid == 0 && has_left) || (tid == 64 && has_right)) {
+      if (((tid == 0 && has_left) || (tid == 64 && has_right)) && *BAD == 0) {      // (a workgroup that gave up once does not wait again)
         const int* f = p.done + (tid == 0 ? gt - 1 : gt + 1);
         // Bounded by WALL time (the 100 MHz counter), generously: when another process shares the GPU only part of this launch is resident at
         // first, and a workgroup then waits for CUs that the other process' kernels still hold (the low end of the resident window always runs to
@@ -146,13 +155,15 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < li) {
           __builtin_amdgcn_s_sleep(2);
-          if (__builtin_amdgcn_s_memrealtime() - t_start > 3000000000ull) {      // 30 s: give up, never hang
+          if (__builtin_amdgcn_s_memrealtime() - t_start > p.timeout) {      // give up, never hang: poison this call, tell the host
             __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *BAD = 1;
             break;
           }
         }
       }
       __syncthreads();
+      if (*BAD != 0) mk = __builtin_nanf("");
       // 2 sides x H rows x 2 columns = 768 values: one per thread.  Left neighbour's RIGHT edge -> my columns 2, 3; right neighbour's LEFT edge -> 36, 37
       {
         const int side = tid / (2 * H), r = (tid - side * 2 * H) >> 1, c = tid & 1;
@@ -307,6 +318,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
           xc[rr * WNF_XROW] = v;
           if (edge) __hip_atomic_store(hp + rr * 2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the edge stores are acknowledged (write-through) before the barrier behind which the counter rises
       } else if (col_ok) {   // out += rs[H:]
         float* const ob = p.out + (long long)b * p.out_bs + (long long)row0_ * p.out_ld + te_;
         if (li == 0) {
@@ -319,10 +331,10 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
           for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = fin[r];
         }
       }
-      // publish: the edge stores acknowledged (they are write-through), then the layer count of this tile
+      // publish: the edge stores acknowledged (above: the waves that made them waited), then the layer count of this tile
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();                                       // every wave's edge stores are ordered before the counter; the tile is whole for the next transform
-      if (tid == 0) __hip_atomic_store(p.done + gt, li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && gt != p.fault_tile) __hip_atomic_store(p.done + gt, li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (!kh && col_ok) {    // last layer: out = (out + rs) * mask
       float* const ob = p.out + (long long)b * p.out_bs + (long long)row0_ * p.out_ld + te_;
       if (li > 0) {
@@ -337,7 +349,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
   // its counter stores acknowledged, then a TWO-LEVEL exit count - sixteen sub-counters by tile number, whose last arrivals count on a top counter -
   // because 256 device-scope atomics on ONE word serialise at ~170 ns each (a single exit counter cost every launch 45 us).
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's counter stores are acknowledged before it counts itself out
     const int sub = gt & 15;
     const int in_sub = (ntiles - sub + 15) >> 4, nsub = ntiles < 16 ? ntiles : 16;
     if (__hip_atomic_fetch_add(p.exited + 1 + sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1) {
@@ -357,11 +369,16 @@ bool wn_stack_enabled() {
 // scratch: halo buffer | per-tile layer counters | error word | (64-byte aligned) the layers' pointer table
 static size_t wn_stack_table_offset() { return (((size_t)WNS_MAXL * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 20) * sizeof(float) + 63) / 64 * 64; }
 size_t wn_stack_scratch_bytes() { return wn_stack_table_offset() + WNS_MAXL * sizeof(WnStackLayer); }
-// The stack applies while every tile has a CU of its own (the workgroups wait for their neighbours) and the per-layer kernel would be the F(2,5) one.
+constexpr size_t WNS_LDS_BYTES = (size_t)WNF_LDS_FLOATS * sizeof(float) + 16;      // + the give-up flag
+// Workgroups of the launch that can be resident at one time: what the runtime's occupancy calculator says for this kernel's registers, threads and
+// LDS (one per CU with these figures), never more than the CU count the scratch area is sized for.  hipLaunchCooperativeKernel would make the same
+// check at launch time - and is not taken because the launch has to be capturable: DESIGN.md section 4.4d.
+static int wn_stack_capacity() { return std::min(persist_capacity((const void*)wn_stack_f25_kernel, 768, WNS_LDS_BYTES), device_cu_count()); }
+// The stack applies while every tile's workgroup can be resident at once (they wait for their neighbours) and the per-layer kernel would be the F(2,5) one.
 bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T) {
-  if (!wn_stack_enabled() || H != WNF_H || K != 5 || dil_rate != 1 || NL < 2 || NL > WNS_MAXL || B <= 0 || T <= 0) return false;
+  if (!wn_stack_enabled() || persist_disabled() || H != WNF_H || K != 5 || dil_rate != 1 || NL < 2 || NL > WNS_MAXL || B <= 0 || T <= 0) return false;
   const long long tiles = (long long)B * ((T + 31) / 32);
-  return !wn_layer_prefers_unfused(B, T) && tiles <= device_cu_count() && B <= 65535;
+  return !wn_layer_prefers_unfused(B, T) && tiles <= wn_stack_capacity() && B <= 65535;
 }
 // in_l / rs_l: the NL layers' packed convolutions; wpf[i]: their F(2,5) images; scratch: wn_stack_scratch_bytes() of device memory.  1 = not eligible.
 int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, int H, const float* x, long long x_bs,
@@ -385,6 +402,8 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   a.err = async_error_word();                                // pinned host memory (misc_kernels.hip): looked at by the next call
   if (!a.err) return 1;
   a.dbg = nullptr;
+  a.timeout = persist_timeout_ticks();
+  a.fault_tile = persist_fault_tile();
   // The counters are NOT cleared by a memset ahead of the launch: a first version did that, and inside a captured plan replayed while another
   // process shared the GPU the launch found them uncleared (layer counters already raised, i.e. no waiting at all and edges of the launch before - which
   // tests that repeat one input cannot see; a ticket counter tried at the time ran past the grid: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION).
@@ -403,7 +422,7 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   }
   auto kern = wn_stack_f25_kernel;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  hipLaunchKernelGGL(kern, dim3(ntx, 1, B), dim3(768), (size_t)WNF_LDS_FLOATS * sizeof(float), st, a);
+  hipLaunchKernelGGL(kern, dim3(ntx, 1, B), dim3(768), WNS_LDS_BYTES, st, a);
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;
@@ -411,6 +430,7 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
 // Zeroes the scratch area and writes the layers' pointer table behind it (once, when the WN module is created; the pointers do not move afterwards)
 int wn_stack_prepare(float* scratch, const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, hipStream_t st) {
   if (!scratch || NL > WNS_MAXL) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "wn_stack_prepare: bad arguments");
+  if (!async_error_word()) SVOC_FAIL(SVOC_ERR_NOMEM, "wn_stack_prepare: no pinned host memory for the error word");      // allocated here, never inside a caller's stream capture
   WnStackLayer t[WNS_MAXL] = {};
   for (int i = 0; i < NL; ++i) { t[i].wpf = wpf[i]; t[i].bias1 = in_l[i]->bias.f(); t[i].wp2 = rs_l[i]->wp.f(); t[i].bias2 = rs_l[i]->bias.f(); }
   SVOC_HIP(hipMemsetAsync(scratch, 0, wn_stack_table_offset(), st));

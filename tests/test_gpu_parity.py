@@ -6,6 +6,8 @@ Tolerances (fp32 path; the reference computes with oneDNN/ATen fp32 in a differe
   * full infer waveform (north_star): RMS error <= 1e-3, and relative RMS <= 1e-4
   * spline: 1e-3 max-abs (fp32 conditioning of the inverse), bin-edge flips tolerated
 """
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -461,21 +463,74 @@ def test_wn_mesh_short_inputs_one_persistent_launch(M, n_layers, B, Tn):
 
 
 def test_persistent_launch_failure_is_reported_by_the_next_call(M):
-    """The persistent WN launches bound their waits (30 s) and a workgroup that gives up raises a word in pinned host memory
+    """The persistent WN launches bound their waits (SVOC_PERSIST_TIMEOUT_MS) and a workgroup that gives up raises a word in pinned host memory
     (include/svoc.h svoc_check_async_error).  Raised from the host here, exactly as the device would: the NEXT WN call fails with the reason, once;
-    the call after it runs; `check_async_error()` itself reports and clears as well."""
+    from then on the process takes one launch per layer (same function) until the diagnostics switch re-enables the persistent launches;
+    `check_async_error()` itself reports and clears as well."""
     sd = sw.fill_state_dict(cases.wn_shapes(192, 5, 3, 0), 9300)
     m = load(M.modules.WN(192, 5, 1, 3, gin_channels=0), sd)
     x = T(cases.rnd(9301, "x", (1, 192, 100), 1.0)).cuda(); mask = torch.ones(1, 1, 100).cuda()
     y = m(x, mask)
     M.native.check_async_error()
-    M.native.check(M.native.lib().svoc_debug_raise_async_error())
-    with pytest.raises(RuntimeError, match="persistent WN launch"):
-        m(x, mask)
-    assert torch.equal(m(x, mask), y)
-    M.native.check(M.native.lib().svoc_debug_raise_async_error())
-    with pytest.raises(RuntimeError, match="persistent WN launch"):
+    assert M.native.persist_state()[0] is False
+    try:
+        M.native.check(M.native.lib().svoc_debug_raise_async_error())
+        with pytest.raises(RuntimeError, match="persistent WN launch"):
+            m(x, mask)
+        assert M.native.persist_state()[0] is True                 # safe mode: per-layer launches
+        M.native.stats_reset()
+        y_layers = m(x, mask)
+        assert M.native.stats_get()["conv_launches"] > 1
+        check("wn per-layer launches after a reported give-up", y_layers, y.cpu().numpy())
+        M.native.debug_persist_control(reenable=True)
+        assert M.native.persist_state()[0] is False
+        assert torch.equal(m(x, mask), y)
+        M.native.check(M.native.lib().svoc_debug_raise_async_error())
+        with pytest.raises(RuntimeError, match="persistent WN launch"):
+            M.native.check_async_error()
         M.native.check_async_error()
+    finally:
+        M.native.debug_persist_control(reenable=True)
+
+
+@pytest.mark.parametrize("kind,n_layers,B,Tn", [("stack", 8, 8, 520), ("stack", 16, 16, 512), ("mesh", 16, 1, 200), ("mesh", 8, 1, 512)])
+def test_persistent_launch_device_side_give_up_poisons_the_same_call(M, kind, n_layers, B, Tn):
+    """a workgroup of a persistent WN launch that gives up a wait ON THE DEVICE must make the call it corrupts visibly wrong.
+    The diagnostics switch makes the workgroup of tile 3 withhold the flags its neighbours wait for and bounds the waits by 5 ms: the neighbours give
+    up, their rows of THAT call's output are NaN (the reference's WN.forward, modules.py:148-176, cannot return a wrong finite tensor), the next call
+    fails with the reason, the process falls back to one launch per layer, and with the switch off again the launch is clean and bit-identical."""
+    sd = sw.fill_state_dict(cases.wn_shapes(192, 5, n_layers, 0), 9400 + n_layers)
+    m = load(M.modules.WN(192, 5, 1, n_layers, gin_channels=0), sd)
+    x = T(cases.rnd(9401 + B, "x", (B, 192, Tn), 1.0)).cuda(); mask = torch.ones(B, 1, Tn).cuda()
+    M.native.check_async_error()
+    M.native.stats_reset()
+    y = m(x, mask)
+    torch.cuda.synchronize()
+    assert M.native.stats_get()["conv_launches"] == 1                 # the persistent launch is what runs
+    assert torch.isfinite(y).all()
+    try:
+        M.native.debug_persist_control(fault_tile=3, timeout_ms=5)
+        assert M.native.persist_state() == (False, 5)
+        t0 = time.time()
+        yb = m(x, mask)                                              # returns success: nothing is known yet on the host ...
+        torch.cuda.synchronize()
+        assert time.time() - t0 < 5.0                                # (one bounded wait per workgroup, not one per layer)
+        assert not torch.isfinite(yb).all()                          # ... but the result says so
+        assert torch.isnan(yb[0, :, 64:96]).all() and torch.isnan(yb[0, :, 128:160]).all()      # tiles 2 and 4 waited for tile 3
+        with pytest.raises(RuntimeError, match="persistent WN launch"):
+            M.native.check_async_error()                             # right behind the caller's own synchronisation of the affected call
+        assert M.native.persist_state()[0] is True
+        M.native.stats_reset()
+        y_layers = m(x, mask)                                        # fallen back: one launch per layer, the fault switch does not reach it
+        assert M.native.stats_get()["conv_launches"] > 1
+        check(f"wn {kind} per-layer launches after a give-up", y_layers, y.cpu().numpy())
+    finally:
+        M.native.debug_persist_control(reenable=True)
+    M.native.stats_reset()
+    y2 = m(x, mask)
+    assert M.native.stats_get()["conv_launches"] == 1
+    assert torch.equal(y2, y)                                        # flags and counters were left clean by the launch that gave up
+    torch.cuda.synchronize()
     M.native.check_async_error()
 
 
@@ -1137,6 +1192,33 @@ def test_small_shape_graph_replay_is_bit_identical(M, net):
                 assert torch.equal(a, b), (rep, seed, i)
     st = M.native.stats_get()
     assert st["conv_launches"] > 0
+
+
+def test_device_side_give_up_makes_the_waveform_of_that_call_non_finite(M, net):
+    """... and through `SynthesizerTrn.infer`, direct launches and a captured plan alike: `o` of the affected call is not finite (what bench.py's
+    `finite` check and any caller that looks at its audio sees), the next call raises, later calls are clean."""
+    mel, ln, eps = (T(a).cuda() for a in cases.infer_inputs("c1"))
+    M.native.check_async_error()
+    o = [net.infer(mel, ln, noise_scale=0.667, eps=eps)[0] for _ in range(3)][-1]        # (the third call replays a plan)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    try:
+        for _ in range(2):                                           # first sight of the new launch arguments: direct launches; second: a fresh plan
+            M.native.debug_persist_control(fault_tile=1, timeout_ms=5, reenable=True)
+            ob = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+            torch.cuda.synchronize()
+            assert not torch.isfinite(ob).all()
+            with pytest.raises(RuntimeError, match="persistent WN launch"):
+                net.infer(mel, ln, noise_scale=0.667, eps=eps)
+        o_layers = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+        assert torch.isfinite(o_layers).all()
+        assert float((o_layers - o).pow(2).mean().sqrt()) <= 1e-5
+    finally:
+        M.native.debug_persist_control(reenable=True)
+    for _ in range(3):
+        assert torch.equal(net.infer(mel, ln, noise_scale=0.667, eps=eps)[0], o)
+    torch.cuda.synchronize()
+    M.native.check_async_error()
 
 
 def test_mel_encoder_standalone(M):
