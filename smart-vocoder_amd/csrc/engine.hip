@@ -94,6 +94,21 @@ struct WNStack {
   }
   int reserve(int B, int T, int g_T) { return ws.ensure(need(B, T, g_T)); }
 
+  // The weight images an unconditioned forward(B, T) streams, by the launch form it takes (0: the persistent mesh launch, 1: the short-input chain,
+  // 2: the stack launch / one fused kernel per layer) - for the prefetch pass at the head of Synth::body
+  int weight_path(int B, int T) const {
+    if (mesh_ws.p && wn_layer_prefers_unfused(B, T) && wn_mesh_applies(H, K, DR, NL, B, T)) return 0;
+    if (wn_small_enabled() && wn_layer_prefers_unfused(B, T) && K == 5 && DR == 1) return 1;
+    return 2;
+  }
+  void weight_buffers(int path, std::vector<std::pair<const void*, size_t>>& out) const {
+    for (int i = 0; i < NL; ++i) {
+      if (path == 0) { out.push_back({in_mesh[i]->p, in_mesh[i]->bytes}); out.push_back({rs16[i]->p, rs16[i]->bytes}); }
+      else if (path == 1) { out.push_back({in_f25[i]->p, in_f25[i]->bytes}); out.push_back({rs16[i]->p, rs16[i]->bytes}); if (i == NL - 1) out.push_back({rs_l[i]->wp.p, rs_l[i]->wp.bytes}); }
+      else { out.push_back({in_f25[i]->p ? in_f25[i]->p : in_l[i]->wp.p, in_f25[i]->p ? in_f25[i]->bytes : in_l[i]->wp.bytes}); out.push_back({rs_l[i]->wp.p, rs_l[i]->wp.bytes}); }
+    }
+  }
+
   // x (already masked by the caller, as the reference's callers do) -> out; both [B][H][ld]
   int forward(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* mask, long long mask_bs,
               const float* g, int g_T, float* out, long long out_bs, int out_ld, int B, int T) {
@@ -875,6 +890,7 @@ struct Synth {
   Flow flow;
   Generator dec;
   DevBuf ws;
+  WeightPrefetch wn_prefetch[3];                            // the five WN stacks' weight images, per launch form (WNStack::weight_path)
 
   int create(const svoc_synth_config& c, const TensorTable& tab, hipStream_t st) {
     cfg = c;
@@ -887,6 +903,12 @@ struct Synth {
     SVOC_TRY(flow.create(c.inter_channels, c.hidden_channels, c.flow_kernel_size, c.flow_dilation_rate, c.flow_n_layers, c.flow_n_flows,
                          c.gin_channels, tab, "flow.", st));
     SVOC_TRY(dec.create(c.dec, tab, "dec.", st));
+    for (int path = 0; path < 3; ++path) {
+      std::vector<std::pair<const void*, size_t>> bufs;
+      enc.weight_buffers(path, bufs);
+      for (auto* cp : flow.rev_p) cp->enc.weight_buffers(path, bufs);
+      SVOC_TRY(wn_prefetch[path].build(bufs, st));
+    }
     return SVOC_OK;
   }
 
@@ -933,6 +955,8 @@ struct Synth {
     SVOC_TRY(ws.ensure(own_bytes(B, T)));
     const Bufs w = bufs(B, T);
     SVOC_TRY(k_sequence_mask(st, lengths, w.mask, B, Tp));   // row stride Tp; entries >= T are never read
+    // the WN stacks' weight images back into the memory-side cache (the decoder of the call before moved ~5 MB per frame through it): misc_kernels.hip
+    SVOC_TRY(wn_prefetch[enc.weight_path(B, T)].run(st));
     {   // pre_enc 1x1, stored already multiplied by x_mask (models.py:38-42)
       ConvArgs a = mk_args();
       set_in(a, mel, (long long)cfg.n_mel * T, T, T);

@@ -266,6 +266,15 @@ int launch_wn_small_layer(const PackedConv& in_l, const float* wpf, const float*
                           long long gadd_bs, int gadd_ld, int gadd_ts, int skip_first, int B, int T, hipStream_t st);
 int pack_wn_f25_named(DevBuf& img, int H, int K, int dil, const TensorTable& tab, const std::string& prefix, hipStream_t st);
 
+// One streaming read over a set of weight images at the head of a call: puts them back into the 256 MB memory-side cache that the decoder's traffic
+// of the call before emptied (misc_kernels.hip prefetch_kernel)
+struct PrefetchSeg { const void* p; unsigned n16; unsigned pad_; };      // at most 64 KB: n16 sixteen-byte groups from p
+struct WeightPrefetch {
+  DevBuf tab; int n = 0; size_t bytes = 0;
+  int build(const std::vector<std::pair<const void*, size_t>>& bufs, hipStream_t st);
+  int run(hipStream_t st) const;
+};
+bool weight_prefetch_enabled();
 // ------------------------------------------------------------------ small kernels (misc_kernels.hip)
 int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, int T);
 int k_gate(hipStream_t st, const float* a, const float* b, float* y, int B, int H, int T);

@@ -422,6 +422,7 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   }
   auto kern = wn_stack_f25_kernel;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+  // (hipLaunchCooperativeKernel was measured and dropped: capturable on ROCm 7, but every cooperative launch costs ~0.5 ms - DESIGN.md section 4.4d)
   hipLaunchKernelGGL(kern, dim3(ntx, 1, B), dim3(768), WNS_LDS_BYTES, st, a);
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());

@@ -110,7 +110,7 @@ def test_every_kernel_switch_has_a_variant_run():
     for f in glob.glob(os.path.join(cases.ROOT, "smart-vocoder_amd", "csrc", "*.hip")) + glob.glob(os.path.join(cases.ROOT, "smart-vocoder_amd", "csrc", "*.h")):
         read |= set(re.findall(r'getenv\("(SVOC_[A-Z0-9_]+)"\)', open(f).read()))
     # not kernel choices: sizes / thresholds of the plan cache, the variant-batch preset, diagnostics
-    tunables = {"SVOC_CT_MIN_TILES", "SVOC_MRF_MIN_TILES", "SVOC_WN_SMALL_TILES", "SVOC_GRAPH_MAX_FRAMES", "SVOC_GRAPH_MIN_SEEN", "SVOC_VARIANT_BATCH", "SVOC_DBG_WALL", "SVOC_DBG_DUMP", "SVOC_DBG_ABL", "SVOC_RB_LDS_MIN", "SVOC_PERSIST_TIMEOUT_MS"}
+    tunables = {"SVOC_CT_MIN_TILES", "SVOC_MRF_MIN_TILES", "SVOC_WN_SMALL_TILES", "SVOC_GRAPH_MAX_FRAMES", "SVOC_GRAPH_MIN_SEEN", "SVOC_VARIANT_BATCH", "SVOC_DBG_WALL", "SVOC_DBG_DUMP", "SVOC_DBG_ABL", "SVOC_RB_LDS_MIN", "SVOC_PERSIST_TIMEOUT_MS", "SVOC_WN_PREFETCH"}
     tested = set()
     for env, _slice in V.VARIANTS.values():
         tested |= set(env)
