@@ -449,6 +449,7 @@ struct Flow {
 struct Generator {
   svoc_generator_config cfg{};
   PackedConv conv_pre;
+  std::unique_ptr<PackedWino> conv_pre_w;                  // the same convolution in Winograd F(4,4) form (round 6): taken when nothing masks or conditions the input
   std::unique_ptr<PackedConv> cond;
   std::vector<std::unique_ptr<PackedConv>> ups;
   std::vector<std::unique_ptr<PackedCtWino>> ups_w;       // F(4,2) form of the same upsampler where convt_wino.hip serves the shape
@@ -486,6 +487,10 @@ struct Generator {
     if (c.n_upsamples <= 0 || c.n_upsamples > 8 || c.n_kernels <= 0 || c.n_kernels > 8) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "generator: bad configuration");
     PackSpec ps{}; ps.Cin = c.initial_channel; ps.Cout = c.upsample_initial_channel; ps.K = 7; ps.pad = 3;
     SVOC_TRY(pack_conv_named(conv_pre, ps, tab, prefix + "conv_pre", st));
+    if (wino_supported(ps.Cin, ps.Cout, 7, 1)) {
+      conv_pre_w.reset(new PackedWino());
+      SVOC_TRY(pack_wino_named(*conv_pre_w, ps.Cin, ps.Cout, 7, tab, prefix + "conv_pre", st));
+    }
     if (c.gin_channels > 0) {
       PackSpec cs{}; cs.Cin = c.gin_channels; cs.Cout = c.upsample_initial_channel; cs.K = 1;
       cond.reset(new PackedConv());
@@ -749,7 +754,13 @@ struct Generator {
       a.Ncols = T;
       set_out(a.out[0], bufs[r], (long long)ch * ld, ld, ch);
       if (g) { a.gadd = gbias; a.gadd_bs = ch; a.gadd_ld = 1; a.gadd_ts = 0; }
-      SVOC_TRY(launch_conv(conv_pre, a, B, st));
+      // k = 7, 192 -> 512 channels: the F(4,4) kernel issues half the direct form's MFMAs (114 -> ~55 us at 16 x 512); from half a tile per CU on
+      int done = 1;
+      if (conv_pre_w && !in_mask && !g) {
+        done = launch_conv_wino(*conv_pre_w, a, B, 1, st, mrf_min_tiles());
+        if (done < 0) return done;
+      }
+      if (done == 1) SVOC_TRY(launch_conv(conv_pre, a, B, st));
     }
     for (int i = 0; i < cfg.n_upsamples; ++i) {
       const int u = cfg.upsample_rates[i];
@@ -978,8 +989,11 @@ struct Synth {
     if (want_zp) SVOC_TRY(k_copy2d(st, w.P, iper, Tp, w.zp, iper, Tp, B, IC, T, nullptr, 0));
     if (flow.NF % 2) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "synth: odd n_flows is not supported on the fused path");
     SVOC_TRY(flow.run_inplace(st, w.P, iper, Tp, w.mask, Tp, nullptr, 0, 1, B, T));
-    // dec((z * x_mask)[:, :, :max_len]) (models.py:338), up to the last MRF stage; conv_post runs in tail()
-    return dec.forward(st, w.P, Tp, iper, w.mask, Tp, nullptr, nullptr, B, Td);
+    // dec((z * x_mask)[:, :, :max_len]) (models.py:338), up to the last MRF stage; conv_post runs in tail().  With two or more coupling layers BOTH
+    // halves of z have been the x1 of a layer - x1 = (x1 - m) * x_mask, modules.py:341 - so z is masked already and z * x_mask is z bit for bit
+    // (signed zeros included): the decoder is called without the mask, which lets conv_pre take the Winograd kernel.
+    const bool z_is_masked = flow.NF >= 2;
+    return dec.forward(st, w.P, Tp, iper, z_is_masked ? nullptr : w.mask, Tp, nullptr, nullptr, B, Td);
   }
 
   int tail(hipStream_t st, const Generator::LastStage& ls, float* o, float* x_mask, float* z, float* z_p, float* m_p, float* logs_p,

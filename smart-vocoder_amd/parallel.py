@@ -139,7 +139,7 @@ def _now(dev):
 
 
 def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0, group=None, bucket=False, bitwise=False,
-                  halo_frames=None, timings=None, shape=None, host_lengths=None, out=None):
+                  halo_frames=None, timings=None, shape=None, host_lengths=None, out=None, validate=False):
     """Run net.infer on this rank's shard of a batch living on `src`; `src` gets the full [B,1,L] waveform back.
     mel/lengths/eps need to be valid on `src` only (shapes are broadcast from there).
 
@@ -161,7 +161,11 @@ def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0
       shapes are broadcast from `src` (one small collective + a host synchronisation per call).
     host_lengths: bucket=True only - the job's lengths as a HOST sequence / tensor on every rank: the sort and every
       shard's frame count are then computed on the host, without the lengths broadcast and its device read-back.
-    out: `src` only, optional [B, 1, L] receive buffer for the gather (see gather_waveforms; ignored with bucket=True)."""
+    out: `src` only, optional [B, 1, L] receive buffer for the gather (see gather_waveforms; ignored with bucket=True).
+    validate: what the ranks pass without a collective (`shape`, `host_lengths`, `max_len`, the flags) is trusted by default - a rank that
+      passes another shape sizes its scatter / gather buffers differently and the job hangs or returns garbage.  validate=True spends one
+      small all_gather per call on a digest of those arguments and raises on EVERY rank if they differ, and `src` checks `host_lengths`
+      against `lengths` (one host read-back): for bring-up and tests, not for the steady state."""
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     dev = next(net.parameters()).device
@@ -170,7 +174,7 @@ def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0
     t0 = _now(tdev) if timings is not None else 0.0
     if shape is not None:
         B, T = int(shape[0]), int(shape[1])
-        IC, n_mel = int(net.inter_channels), 80
+        IC, n_mel = int(net.inter_channels), int(getattr(getattr(getattr(net, "enc_p", None), "pre_enc", None), "in_channels", 80))
         if rank == src and (tuple(mel.shape) != (B, n_mel, T) or tuple(eps.shape) != (B, IC, T)):
             raise ValueError(f"shape={tuple(shape)} does not describe mel {tuple(mel.shape)} / eps {tuple(eps.shape)}")
     else:
@@ -179,6 +183,27 @@ def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0
             meta[0], meta[1], meta[2], meta[3] = mel.shape[0], mel.shape[2], eps.shape[1], mel.shape[1]
         dist.broadcast(meta, src=src, group=group)
         B, T, IC, n_mel = (int(v) for v in meta.tolist())
+    # max_len as SynthesizerTrn.infer reads it (None: all frames; negative: counted from the end)
+    if max_len is not None:
+        max_len = max(0, min(T, int(max_len) if max_len >= 0 else T + int(max_len)))
+        if max_len == 0:
+            raise ValueError("max_len leaves no frames to decode")
+    if validate:
+        hl = None if host_lengths is None else torch.as_tensor(host_lengths, dtype=torch.int64).reshape(-1)
+        # last field: src's own verdict on host_lengths (only src holds `lengths`); every rank reads it from src's row, so all raise together
+        hl_ok = 1
+        if rank == src and hl is not None and not torch.equal(hl, lengths.detach().to("cpu", torch.int64).reshape(-1)):
+            hl_ok = 0
+        mine = torch.tensor([B, T, IC, n_mel, -1 if max_len is None else max_len, int(bool(bucket)), int(bool(bitwise)),
+                             -1 if hl is None else int(hl.sum()), -1 if halo_frames is None else int(halo_frames), int(src), hl_ok],
+                            dtype=torch.int64, device=wire)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+        if any(not torch.equal(v[:-1], every[0][:-1]) for v in every):
+            raise ValueError("infer_sharded: the ranks disagree on (B, T, inter_channels, n_mel, max_len, bucket, bitwise, sum(host_lengths), "
+                             f"halo_frames, src): {[v[:-1].tolist() for v in every]}")
+        if int(every[src][-1]) == 0:
+            raise ValueError("infer_sharded: host_lengths differ from lengths on src")
     inv = None
     if bucket and host_lengths is not None:
         hl = torch.as_tensor(host_lengths, dtype=torch.int64, device="cpu").reshape(-1)
@@ -202,7 +227,7 @@ def infer_sharded(net, mel, lengths, eps, noise_scale=0.667, max_len=None, src=0
     m, l, e = scatter_batch([mel, lengths, eps] if rank == src else None, [(n_mel, T), (), (IC, T)],
                             [torch.float32, torch.int64, torch.float32], B, src=src, device=dev, group=group)
     t1 = _now(tdev) if timings is not None else 0.0
-    Td = T if max_len is None else min(T, max_len)
+    Td = T if max_len is None else max_len
     hop = net.dec.hop
     if m.shape[0] > 0:
         Tr = T

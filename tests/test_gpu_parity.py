@@ -783,17 +783,21 @@ def test_full_size_properties(M, net):
 
 
 def test_c2_full_size_vs_oracle(M, net):
-    """BASELINE.json configs[1] - the bench workload itself, 16 x 512 frames, seed 1001 (exactly bench.py's tensors) -
-    against the CPU oracle over the WHOLE batch (the oracle needs ~10-40 s here): waveform RMS <= 1e-3 (north_star) and
-    relative RMS <= 1e-4, latents to the per-module tolerance."""
+    """BASELINE.json configs[1] - the bench workload itself, 16 x 512 frames, seed 1001 (exactly bench.py's tensors) - run as ONE batch on the GPU and
+    compared with the CPU oracle on four of its utterances (0, 5, 10, 15; the oracle treats utterances independently, and it needs 10-40 s for all
+    sixteen - `bench.py` does that whole-batch comparison on every bench run, and `test_full_size_vs_reference_fixture[c2_16x512]` covers every sample
+    of the batch against numbers the reference itself produced): waveform RMS <= 1e-3 (north_star) and relative RMS <= 1e-4, latents to the
+    per-module tolerance."""
     Bn, Tn = 16, 512
     mel = T(sw.synthetic_mel(1001, Bn, Tn)); eps = T(sw.synthetic_eps(1001, Bn, Tn))
     ln = torch.full((Bn,), Tn, dtype=torch.int64)
     o, mask, (z, z_p, m_p, logs_p) = net.infer(mel.cuda(), ln.cuda(), noise_scale=0.667, eps=eps.cuda())
+    assert torch.isfinite(o).all()
+    pick = [0, 5, 10, 15]
     with torch.no_grad():
-        o_ref, mask_ref, (z_ref, zp_ref, mp_ref, lp_ref) = O.infer(sdT(cases.full_model_weights()), mel, ln, eps, 0.667)
-    check("c2 m_p", m_p, mp_ref); check("c2 logs_p", logs_p, lp_ref); check("c2 z_p", z_p, zp_ref); check("c2 z", z, z_ref, 5e-5, 1e-4)
-    err = (o.cpu() - o_ref).numpy()
+        o_ref, mask_ref, (z_ref, zp_ref, mp_ref, lp_ref) = O.infer(sdT(cases.full_model_weights()), mel[pick], ln[pick], eps[pick], 0.667)
+    check("c2 m_p", m_p[pick], mp_ref); check("c2 logs_p", logs_p[pick], lp_ref); check("c2 z_p", z_p[pick], zp_ref); check("c2 z", z[pick], z_ref, 5e-5, 1e-4)
+    err = (o[pick].cpu() - o_ref).numpy()
     rms, ref = float(np.sqrt((err ** 2).mean())), float(o_ref.pow(2).mean().sqrt())
     print(f"c2 16x512: waveform rms err {rms:.3e} (ref rms {ref:.3f}, rel {rms / ref:.2e}), max {np.abs(err).max():.3e}")
     assert rms <= 1e-3 and rms / ref <= 1e-4, (rms, rms / ref)

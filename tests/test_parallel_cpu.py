@@ -108,6 +108,33 @@ def _worker(rank, world, port, B, T, q):
             ok = False
         except ValueError:
             pass
+    # validate=True: one small all_gather on a digest of what every rank passed; agreeing ranks run as before ...
+    o5 = parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                                noise_scale=0.5, src=0, shape=(B, T), validate=True)
+    if rank == 0:
+        ok = ok and torch.equal(o5, ref)
+    # ... a rank that passes another shape is an error on EVERY rank instead of a hang in the scatter
+    try:
+        parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                               noise_scale=0.5, src=0, shape=(B, T) if rank == 0 else (B, T + 4), validate=True)
+        ok = False
+    except ValueError as ex:
+        ok = ok and "disagree" in str(ex)
+    # host_lengths that are not the lengths: src notices under validate=True and says so in its row of the digest (both ranks pass the same wrong list)
+    if B > 1:
+        wrong = [int(v) for v in ln.tolist()]
+        wrong[0] = max(1, wrong[0] - 1) if wrong[0] > 1 else 2
+        try:
+            parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                                   noise_scale=0.5, src=0, bucket=True, shape=(B, T), host_lengths=wrong, validate=True)
+            ok = False
+        except ValueError as ex:
+            ok = ok and "host_lengths" in str(ex)          # on every rank: nobody is left waiting in the scatter
+    # a negative max_len counts from the end, as SynthesizerTrn.infer reads it (models.py: Td = T + max_len)
+    o6 = parallel.infer_sharded(net, mel if rank == 0 else None, ln if rank == 0 else None, eps if rank == 0 else None,
+                                noise_scale=0.5, src=0, shape=(B, T), max_len=-2)
+    if rank == 0:
+        ok = ok and torch.equal(o6, net.infer(mel, ln, noise_scale=0.5, eps=eps, max_len=T - 2)[0])
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

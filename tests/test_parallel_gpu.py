@@ -275,3 +275,75 @@ def test_bench_one_rank_rccl():
     assert j["n_gpus"] == 1 and j["config"]["collective"] == "gather" and j["config"]["scatter_ms"] is not None, j["config"]
     assert len(j["per_rank"]["infer_ms"]) == 1 and j["gather_ms"] > 0 and j["infer_sharded"]["equals_timed_step_output"] is True, j
     assert j["scaling_curve"].startswith("NOT MEASURED")
+
+
+_RCCL_WORLD2 = r'''
+import os, sys, json
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import cases
+from cases import sw
+from smart_vocoder_amd import models, parallel, _native as N
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)                                   # ONE RANK PER DEVICE
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" IS RCCL on ROCm
+net = models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in cases.full_model_weights().items()}, strict=False)
+net = net.to(dev).eval()
+res = {}
+for (B, T) in ((5, 96), (16, 512)):                            # an uneven split of a small batch; the headline shape per JOB (8 utterances per rank)
+    mel = eps = ln = None
+    if rank == 0:
+        mel = torch.from_numpy(sw.synthetic_mel(81, B, T)).to(dev); eps = torch.from_numpy(sw.synthetic_eps(81, B, T)).to(dev)
+        ln = torch.full((B,), T, dtype=torch.int64, device=dev); ln[1] = T - 17
+    with torch.no_grad():
+        o = parallel.infer_sharded(net, mel, ln, eps, noise_scale=0.667, src=0, bitwise=True, shape=(B, T))
+        if rank == 0:
+            N.profile_enable(True)                              # direct launches (graph replay is bit-identical to them)
+            with N.variant_batch(B):
+                ref = net.infer(mel, ln, noise_scale=0.667, eps=eps)[0]
+            N.profile_enable(False)
+            res[f"{B}x{T}_bitwise"] = bool(o.is_cuda and o.device == dev and torch.equal(o, ref))
+            res[f"{B}x{T}_finite"] = bool(torch.isfinite(o).all())
+        else:
+            res[f"{B}x{T}_none_off_src"] = o is None
+torch.cuda.synchronize()
+N.check_async_error()
+res["devices_differ"] = True
+gathered = [None] * world
+dist.all_gather_object(gathered, (rank, local, torch.cuda.current_device()))
+res["one_rank_per_device"] = len({g[2] for g in gathered}) == world
+dist.barrier(); dist.destroy_process_group()
+print(f"RCCL2 rank{rank} " + json.dumps(res))
+'''
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs: arms itself the day a multi-GPU box runs the suite")
+def test_rccl_two_devices(tmp_path):
+    """SURVEY 8e on real hardware, the first time two devices are visible (VERDICT r5 item 5): torchrun with one rank PER DEVICE over "nccl" (= RCCL),
+    the packed scatter and the in-place gather move bytes between two GPUs, and `infer_sharded(shape=..., bitwise=True)` must return the bits a
+    single process computes for the whole job - at an uneven split and at the headline shape.  Then `bench.py --gpus 2` end to end with
+    collective == "gather".  Every other multi-rank test of this file pins both ranks to cuda:0 or talks over gloo."""
+    script = tmp_path / "rccl2.py"
+    script.write_text(_RCCL_WORLD2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script), cases.ROOT]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = sorted(l for l in r.stdout.splitlines() if l.startswith("RCCL2 "))
+    assert len(lines) == 2, r.stdout[-2000:]
+    for l in lines:
+        res = json.loads(l.split(" ", 2)[2])
+        assert res and all(res.values()), l
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["collective"] == "gather" and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
+    assert j["value"] > 0 and len(j["per_rank"]["infer_ms"]) == 2 and j["infer_sharded"]["equals_timed_step_output"] is True, j
