@@ -53,6 +53,13 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   float* const raw = wl;                                   // [KC][RAW], producers only
   float* const pl = wl + Geo::RAW_FLOATS;                  // two plane sets of PLF floats
   if (v0 >= vend) return;
+  if constexpr (DBG) {                                     // ablation 64: workgroups start 0 .. 3 quarters of ~16k cycles apart (are the store bursts of lock-step tiles the cost?)
+    if (p.abl & 64u) {
+      const long long t0 = (long long)__builtin_readcyclecounter(), dl = (long long)((blockIdx.x >> 3) & 3) * 4000;
+      while ((long long)__builtin_readcyclecounter() - t0 < dl) __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+    }
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,6 +67,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
   // Stamped build only: work REMOVED for the power / clock ablations of round 5 (results are wrong; the stamps give the effective clock):
   //   1 producers: no global loads behind the first    2 producers: no publish / transform behind stage 2 (barriers only)
   //   4 consumers: no epilogue    8 consumers: every weight request re-reads the image's first 4 KB (no L2 -> CU weight traffic)
+  //   16 the epilogue without its stores    32 the epilogue without its residual loads    64 staggered starts (round 6: what does the epilogue cost beyond its own cycles?)
   const unsigned abl = DBG ? p.abl : 0u;
   const int ntiles_all = vend - first;
   const int nch = p.nchunks;                               // 32-channel chunks
@@ -124,7 +132,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
         pgb[u] = (g / PERM) | ((g % PERM) << 16) | (row << 20);
       }
     }
-    const int pnblk_row = PERM > 0 ? (L + 4 * PERM - 1) / (4 * PERM) : 0;      // q blocks of a row
+    const int pnblk_row = PERM > 0 ? (L + 4 * PERM - 1) / (4 * (PERM > 0 ? PERM : 1)) : 0;      // q blocks of a row
     // first q block a tile loads: the one that holds column xs (xs >= -4 PERM: the left halo is at most 8 columns)
     auto pfirst = [&](int xs_) -> int { constexpr int P4 = PERM > 0 ? 4 * PERM : 1; return (xs_ + P4) / P4 - 1; };      // (only called with PERM > 0)
     int tsrc[TPW];                                         // float offset inside `raw`: D = 1: the item's samples; D > 1: the item's raw row (the column follows the tile)
@@ -390,7 +398,7 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     }
   };
   int cset = 0;                                            // three plane sets: set of the next stage
-  long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0;     // diagnostics (stamped build): consumer wave 0 of each workgroup
+  long long cyc_bar = 0, cyc_mf = 0, cyc_epi = 0, cyc_all0 = 0, cyc_drain = 0;     // diagnostics (stamped build): consumer wave 0 of each workgroup
   long long wall0 = 0;
   if constexpr (DBG) { cyc_all0 = (long long)__builtin_readcyclecounter(); wall0 = (long long)wall_clock64(); }
   for (int ti = 0; ti < my_tiles; ++ti) {
@@ -433,7 +441,9 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
     }
     const bool lane_ok = row_ok && ne < L;
     const bool res_only = res_flags && tile_full;
-    char* const ybase = reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld + n0);
+    // (ablation 256, stamped build: every tile's stores go to the first columns of batch element 0 - the same 64 KB per row block, L2-resident)
+    char* const ybase = (DBG && (abl & 256u)) ? reinterpret_cast<char*>(p.y + (long long)(mt * 32) * p.y_ld)
+                                              : reinterpret_cast<char*>(p.y + (long long)bz * p.y_bs + (long long)(mt * 32) * p.y_ld + n0);
     const char* const rbase = reinterpret_cast<const char*>(p.res + (long long)bz * p.res_bs + (long long)(mt * 32) * p.res_ld + n0);
     float4 rvA[8];                                         // residual of accumulator rows 0..7, requested under the tile's last stage
     auto stage = [&](int st_, auto par, auto hf) {
@@ -444,6 +454,10 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       __syncthreads();                                     // B_s: plane set s & 1 is complete, set (s - 1) & 1 may be overwritten
       if constexpr (DBG) c1 = (long long)__builtin_readcyclecounter();
       if (st_ == nst - 1 && res_only && lane_ok) {
+        if (DBG && (abl & 32u)) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) rvA[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else
 #pragma unroll
         for (int r = 0; r < 8; ++r) rvA[r] = ldq(rbase + (size_t)(8 * (r >> 2)) * rlb + ro4[r & 3]);
       }
@@ -528,11 +542,20 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) w4_add4(vo[r], rv[r]);
             if (p.flags & F_DIV) divide(vo);
+            if (DBG && ((abl & 16u) || ((abl & 512u) && Q > 0))) {      // ablation 16: the epilogue without its stores (the branch is never taken); 512: the first quarter's only
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stq(ybase + (size_t)(8 * Q) * ylb + yo4[r], vo[r]);
+              for (int r = 0; r < 4; ++r) if (vo[r].x == 1.2345678e38f) stq(ybase + (size_t)(8 * Q) * ylb + yo4[r], vo[r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) stq(ybase + (size_t)(8 * Q) * ylb + yo4[r], vo[r]);
+            }
           };
           quarter(std::integral_constant<int, 0>{}, rvA);
           float4 rvB[8];                                   // requested once the first quarter's accumulator registers are free
+          if (DBG && (abl & 32u)) {                        // ablation 32: the epilogue without its residual loads
+#pragma unroll
+            for (int r = 0; r < 8; ++r) rvB[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else
 #pragma unroll
           for (int r = 0; r < 8; ++r) rvB[r] = ldq(rbase + (size_t)(8 * (2 + (r >> 2))) * rlb + ro4[r & 3]);
           quarter(std::integral_constant<int, 1>{}, rvA + 4);
@@ -589,12 +612,18 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
       }
     }
     if constexpr (DBG) cyc_epi += (long long)__builtin_readcyclecounter() - ce0;
+    if constexpr (DBG) if (abl & 128u) {                   // ablation 128: drain the vector-memory queue behind the epilogue and time it: how long do the stores' acknowledgements take?
+      const long long cd0 = (long long)__builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      cyc_drain += (long long)__builtin_readcyclecounter() - cd0;
+    }
   }
   if constexpr (DBG) if (tid == 0) {      // [workgroup][16]: 0 tiles, 1 total cycles, 2 barrier waits, 3 MFMA streams, 4 epilogues, 5 marker, 6 HW_ID, 7 XCC_ID
     long long* d = p.dbg + 16 * (long long)(p.dbg_base + v0);
     d[0] = my_tiles; d[1] = (long long)__builtin_readcyclecounter() - cyc_all0; d[2] = cyc_bar; d[3] = cyc_mf; d[4] = cyc_epi; d[5] = 4;
     d[6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     d[7] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    d[12] = cyc_drain;
     d[10] = wall0; d[11] = (long long)wall_clock64();     // 100 MHz constant clock: effective shader clock = d[1] / (d[11] - d[10]) * 100 MHz
   }
 }
@@ -616,6 +645,9 @@ __device__ __forceinline__ void wino4_member(const WinoArgs& p, const int first,
 template <int D, int NRT, int PERM = 0, bool F44 = false>
 __global__ void __launch_bounds__(512, 2) conv_wino4_group_kernel(const WinoGroup g) {
   const int b = blockIdx.x, G_ = gridDim.x;
+  // (round 6, measured and not kept - profiles/r06_epilogue_store_cost_study.txt: the XCDs starting on different members, so that the k = 3 phase's write
+  // traffic is spread over the launch: 25.59 against 25.57 ms; the bias from an LDS copy instead of 16 global loads per tile: -350 cycles of a tile's
+  // set-up in the stamps, nothing in the step; non-temporal stores: a launch between profiler events 1 - 2 % faster, the replayed step unchanged)
   wino4_member<11, D, NRT, PERM, F44>(g.a[0], 0, g.end[0], b, G_);
   __syncthreads();
   wino4_member<7, D, NRT, PERM, F44>(g.a[1], g.end[0], g.end[1], b, G_);

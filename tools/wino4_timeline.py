@@ -25,6 +25,7 @@ if k >= 7 and os.environ.get("SVOC_WINO_F4") != "0": nm = (C // 32) * 16 * 7 * G
 tiles = D[:, 0]; tot = D[:, 1] / tiles; bar = D[:, 2] / tiles; mf = D[:, 3] / tiles; epi = D[:, 4] / tiles
 print(f"C={C} k={k} d={d}: {len(D)} workgroups x {tiles.mean():.1f} tiles; per tile (consumer wave 0), cycles: total {tot.mean():.0f} | barrier waits {bar.mean():.0f} | "
       f"MFMA streams {mf.mean():.0f} ({mf.mean() / nm:.1f} per MFMA, {nm} MFMAs) | epilogue {epi.mean():.0f} | rest {np.mean(tot - bar - mf - epi):.0f}")
+if int(os.environ.get("SVOC_DBG_ABL", "0")) & 128: print(f"   drain of the vector-memory queue behind the epilogue (s_waitcnt vmcnt(0)): {np.mean(D[:, 12] / tiles):.0f} cycles per tile")
 print(f"   producer wave 0 per tile: total {np.mean(D[:, 8] / tiles):.0f} cycles, of which waiting at stage barriers {np.mean(D[:, 9] / tiles):.0f}")
 wall = (D[:, 11] - D[:, 10]) / 100.0     # us (100 MHz constant clock)
 print(f"   wall time per workgroup: median {np.median(wall):.1f} us, span first start .. last end {(D[:, 11].max() - D[:, 10].min()) / 100.0:.1f} us; effective shader clock {np.median(D[:, 1] / wall):.0f} MHz (last launch of a burst; steady state: tools/power_ablate.py)")
