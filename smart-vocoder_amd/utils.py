@@ -179,7 +179,13 @@ def save_wav(path, sampling_rate, audio):
     or a numpy array; written as 32-bit float PCM exactly as scipy writes the notebook's float32 array."""
     from scipy.io.wavfile import write
     if isinstance(audio, torch.Tensor):
+        on_gpu = audio.is_cuda
         audio = audio.detach().float().cpu().numpy()
+        if on_gpu:
+            # the copy synchronised the stream: if a persistent WN launch of the call that produced this audio gave up a wait, say so HERE, for
+            # the audio that is affected (it is NaN where that happened), not at the next call (include/svoc.h svoc_check_async_error)
+            from . import _native
+            _native.check_async_error()
     audio = np.asarray(audio, dtype=np.float32)
     while audio.ndim > 1 and audio.shape[0] == 1:
         audio = audio[0]

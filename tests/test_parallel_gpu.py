@@ -203,7 +203,7 @@ def test_bench_single_gpu_line_schema():
     if rf["traffic_source"].startswith("LIVE"):
         assert rf["executed_flops_pmc"] is not None and abs(rf["executed_flops_pmc_over_library"] - 1.0) < 0.015, rf
     oc = j["other_configs"]
-    for k in ("c1_1x200", "c3_32x512", "c5_8x4096"):
+    for k in ("c1_1x200", "c3_32x512", "c5_8x4096", "b4_4x512"):
         assert oc[k]["ms_per_step"] > 0 and oc[k]["finite"], oc
     assert abs(rf["flop_per_step"] - 2568280.0 * j["config"]["samples_per_step"]) / rf["flop_per_step"] < 0.01
     assert 0.5 < rf["executed_mfma_flop_fraction"] <= 1.0
