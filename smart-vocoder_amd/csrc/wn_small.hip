@@ -13,6 +13,11 @@
 // with in_i in Winograd F(2,5) form (wn_fused.hip's image and matrices; 1152 MFMAs per workgroup, the K dimension split over the
 // twelve waves: 96 each, partial sums of the OUTPUT-transformed tiles reduced through LDS).  The last layer's 1 x 1 runs as the usual
 // convolution behind the last kernel.  H = 192, k = 5, dilation 1.
+// Round 6 (mid-size batches): template parameter PP = row pairs per workgroup.  With PP = 1 a batch of 43 .. 85 tiles (3 x 512 ..
+// 5 x 512) is 258 .. 510 workgroups - two rounds on 256 CUs, 44.6 us per layer at 4 x 512 where 2 x 512 takes 24.7.  PP = 2: three workgroups per
+// tile, each staging and recomputing the residual half ONCE and then running the input transform, the in_layer stream, the reduction and the gate for
+// its two pairs one after the other (the reduction area aliases the planes, so the transform runs again for the second pair: 0.8 us) - one round.
+// Per row the arithmetic and its order are PP = 1's: bit-identical results.
 #include "svoc_internal.h"
 #include "wino_common.h"
 
@@ -42,6 +47,7 @@ struct WnSmallArgs {
   int T; int skip_first;                               // skip_first: res_skip i-1 is the stack's first one (out = ..., not +=)
 };
 
+template <int PP>
 __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) {
   constexpr int H = WNS_H;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -54,7 +60,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, k4 = lane >> 4;
-  const int pi = blockIdx.y;
+  const int pi0 = blockIdx.y * PP;                          // this workgroup's row pairs: pi0 .. pi0 + PP - 1
   const int b = blockIdx.z;
   const int t0 = blockIdx.x * 32;
   const int T = p.T;
@@ -72,8 +78,8 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
     const int wbx = __builtin_amdgcn_readfirstlane(wave * 12 * 1024);
 #pragma unroll
     for (int ks4 = 0; ks4 < 12; ++ks4) awx[ks4] = rsload(wbx + ks4 * 1024);
-    if (wave < 4) {
-      const int wbs = __builtin_amdgcn_readfirstlane((12 + 2 * pi + (wave & 1)) * 12 * 1024);
+    if (wave < 4 * PP) {                                    // skip part: waves 4 j .. 4 j + 3 take pair pi0 + j
+      const int wbs = __builtin_amdgcn_readfirstlane((12 + 2 * (pi0 + (wave >> 2)) + (wave & 1)) * 12 * 1024);
 #pragma unroll
       for (int ks4 = 0; ks4 < 12; ++ks4) aws[ks4] = rsload(wbs + ks4 * 1024);
     }
@@ -133,9 +139,10 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
 
   if (has_prev) {
     const float* rsbias = p.wrs + 24 * 12 * 256;           // natural order: [0, H) residual part, [H, 2H) skip part
-    // ---- skip part of res_skip_{i-1}: rows H + 32 pi .. + 31 on the 32 centre columns: waves 0..3 = (row tile, column tile)
-    if (wave < 4) {
-      const int rt2 = wave & 1, nt2 = wave >> 1;
+    // ---- skip part of res_skip_{i-1}: rows H + 32 pi .. + 31 on the 32 centre columns: waves 0..3 (+ 4 j: pair pi0 + j) = (row tile, column tile)
+    if (wave < 4 * PP) {
+      const int pi = pi0 + (wave >> 2);
+      const int rt2 = wave & 1, nt2 = (wave >> 1) & 1;
       wns_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* bp = AT + k4 * WNS_AROW + 8 + 16 * nt2 + col;
 #pragma unroll
@@ -175,7 +182,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
           for (int nt = 0; nt < 3; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[4 * j * WNS_AROW + 16 * nt], acc[nt], 0, 0, 0);
         }
       }
-      const bool store = (wave >> 1) == pi;                // the workgroup of pair pi writes rows 32 pi .. of x_i
+      const bool store = (wave >> 1) >= pi0 && (wave >> 1) < pi0 + PP;      // the workgroup of pair pi writes rows 32 pi .. of x_i
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
         const int ac = 16 * nt + col;                       // column of the acts tile; x tile column = ac - 4
@@ -197,6 +204,9 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
     __syncthreads();
   }
 
+#pragma unroll 1
+  for (int pi = pi0; pi < pi0 + PP; ++pi) {
+  if (pi > pi0) __syncthreads();                             // the reduction of the pair before is done with the area the planes live in
   // ---- input transform of x_i (wn_fused.hip): window q of channel c reads tile columns 2q + 2 .. 2q + 7
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -313,6 +323,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
       if (t < T) p.ao[(long long)b * p.ao_bs + (long long)chn * p.ao_ld + t] = gate_tanh_sigmoid(vA, vB);
     }
   }
+  }
 }
 
 // res_skip of a non-last layer (2H x H x 1) as A operands of v_mfma_f32_16x16x4_f32: [row tile 24][k-step group 12][lane][4]; lane =
@@ -369,6 +380,10 @@ int pack_wn_rs16_named(DevBuf& img, int H, int Cout, const TensorTable& tab, con
   return SVOC_OK;
 }
 
+static bool wn_small_two_pairs() {
+  static const bool on = !(getenv("SVOC_WN_SMALL_PP2") && atoi(getenv("SVOC_WN_SMALL_PP2")) == 0);      // SVOC_WN_SMALL_PP2=0: always six workgroups per tile (A/B)
+  return on;
+}
 // One layer of the short-input chain.  ap / wrs null on the stack's first layer.  Returns 1 when the kernel does not apply.
 int launch_wn_small_layer(const PackedConv& in_l, const float* wpf, const float* wrs, double rs_flops_per_col, const float* x, long long x_bs,
                           int x_ld, const float* ap, long long ap_bs, int ap_ld, float* xo, long long xo_bs, int xo_ld, float* out, long long out_bs,
@@ -396,9 +411,18 @@ int launch_wn_small_layer(const PackedConv& in_l, const float* wpf, const float*
     snprintf(d, sizeof(d), "smallWN H192  k5  d1  N%-7d B%-3d F(2,5)%s", T, B, ap ? " + res_skip" : "");
     prof_idx = prof_begin(st, d, fin + frs);
   }
-  auto kern = wn_small_f25_kernel;
-  SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  hipLaunchKernelGGL(kern, dim3((T + 31) / 32, 6, B), dim3(768), (size_t)WNS_LDS_FLOATS * sizeof(float), st, a);
+  // two row pairs per workgroup when that makes ONE round of workgroups out of two (43 .. 85 tiles on 256 CUs; bit-identical to one pair each)
+  const long long tiles = (long long)variant_batch(B) * ((T + 31) / 32);
+  const int ncu = device_cu_count();
+  if (wn_small_two_pairs() && tiles * 6 > ncu && tiles * 3 <= ncu) {
+    auto kern = wn_small_f25_kernel<2>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3((T + 31) / 32, 3, B), dim3(768), (size_t)WNS_LDS_FLOATS * sizeof(float), st, a);
+  } else {
+    auto kern = wn_small_f25_kernel<1>;
+    SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+    hipLaunchKernelGGL(kern, dim3((T + 31) / 32, 6, B), dim3(768), (size_t)WNS_LDS_FLOATS * sizeof(float), st, a);
+  }
   prof_end(st, prof_idx);
   SVOC_HIP(hipGetLastError());
   return SVOC_OK;

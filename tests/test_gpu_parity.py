@@ -462,6 +462,27 @@ def test_wn_mesh_short_inputs_one_persistent_launch(M, n_layers, B, Tn):
     check(f"wn mesh n{n_layers} B{B} T{Tn} second input", m((x2 * mask).cuda(), mask.cuda()), ref2.numpy())
 
 
+@pytest.mark.parametrize("n_layers,B,Tn", [(8, 2, 512), (8, 3, 512), (16, 4, 512), (8, 5, 512), (3, 4, 500)])
+def test_wn_mid_size_batches(M, n_layers, B, Tn):
+    """21 .. 95 tiles of 32 columns (2 x 512 .. 5 x 512) sit between the short-input persistent launch and the stack launch and run
+    the chain of csrc/wn_small.hip - one launch per layer, since round 6 with TWO row pairs per workgroup where that makes one round of workgroups out of
+    two (43 .. 85 tiles).  Against the oracle, ragged lengths; n_layers + 1 launches (the last layer's 1 x 1 is a convolution of its own)."""
+    sd = sw.fill_state_dict(cases.wn_shapes(192, 5, n_layers, 0), 9500 + n_layers)
+    m = load(M.modules.WN(192, 5, 1, n_layers, gin_channels=0), sd)
+    rng = np.random.default_rng(B * 1000 + Tn)
+    x = T(cases.rnd(9500 + B, "x", (B, 192, Tn), 1.0))
+    lens = [Tn] + [int(rng.integers(Tn // 2, Tn + 1)) for _ in range(B - 1)]
+    mask = T(cases.lengths_mask(lens, Tn))
+    M.native.stats_reset()
+    y = m((x * mask).cuda(), mask.cuda())
+    st = M.native.stats_get()
+    assert st["conv_launches"] == n_layers + 1 and st["convolutions"] == 2 * n_layers, st
+    with torch.no_grad():
+        ref = O.wn(sdT(sd), "", x * mask, mask, None, hidden=192, kernel_size=5, dilation_rate=1, n_layers=n_layers)
+    check(f"wn mid-size n{n_layers} B{B} T{Tn}", y, ref.numpy())
+    assert torch.equal(y, m((x * mask).cuda(), mask.cuda()))
+
+
 def test_persistent_launch_failure_is_reported_by_the_next_call(M):
     """The persistent WN launches bound their waits (SVOC_PERSIST_TIMEOUT_MS) and a workgroup that gives up raises a word in pinned host memory
     (include/svoc.h svoc_check_async_error).  Raised from the host here, exactly as the device would: the NEXT WN call fails with the reason, once;

@@ -12,6 +12,7 @@ tests/test_gpu_parity.py::test_fallback_shapes).
   SVOC_WINO_F4=0                 Winograd F(2,3) kernels instead of F(4,3) / F(4,4) (odd row-block counts, unaligned rows, L % 4 != 0)
   SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv (short inputs)
   SVOC_WN_SMALL_F25=0            short inputs: WN layers as two K-split convolutions instead of one launch per layer (wn_small.hip)
+  SVOC_WN_SMALL_PP2=0            mid-size batches: six workgroups per 32-column tile (one row pair each) instead of three (fewer than 43 or more than 85 tiles)
   SVOC_WN_STACK=0                WN stacks one launch per layer instead of one persistent launch per stack (more 32-column tiles than CUs; conditioning input)
   SVOC_WN_F25=0                  WN in_layers in direct form (K-split layer kernel) instead of Winograd F(2,5) (H != 192, k != 5)
   SVOC_KSPLIT=0 SVOC_WN_SMALL=0 SVOC_MRF_SMALL=0    short inputs on the throughput kernels (no K-split convolutions, fused WN
@@ -48,6 +49,7 @@ VARIANTS = {
     "wn_one_launch_per_layer": ({"SVOC_WN_STACK": "0"}, WNS),
     "wn_short_inputs_one_launch_per_layer": ({"SVOC_WN_MESH": "0"}, "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_wn or test_coupling or test_flow"),
     "wn_short_inputs_two_convolutions": ({"SVOC_WN_SMALL_F25": "0"}, SMALL + " or test_coupling or test_flow"),
+    "wn_mid_size_six_workgroups_per_tile": ({"SVOC_WN_SMALL_PP2": "0"}, "test_wn_mid_size or test_wn_edge"),
     "no_small_shape_kernels": ({"SVOC_KSPLIT": "0", "SVOC_WN_SMALL": "0", "SVOC_MRF_SMALL": "0"}, SMALL),
     "no_graph": ({"SVOC_GRAPH": "0"}, SMALL),
     "upsamplers_direct": ({"SVOC_CT_WINO": "0"}, UPS),
