@@ -47,3 +47,8 @@ ls -la $O
 ( cd $R && python tools/wn_mesh_timeline.py 1 200 16; python tools/wn_mesh_timeline.py 1 200 8; python tools/wn_mesh_timeline.py 2 150 8; python tools/wn_mesh_timeline.py 1 512 16 ) > $O/${TAG}_wn_mesh_phase_stamps.txt 2>/dev/null
 ( cd $R && for n in 2 4; do echo "== $n processes, 1 x 200 (csrc/wn_mesh.hip)"; timeout 200 python tools/wn_stack_shared_gpu.py $n 2000 1 200; done; echo "== 2 processes, 1 x 512 (csrc/wn_mesh.hip, two tiles per group)"; timeout 200 python tools/wn_stack_shared_gpu.py 2 2000 1 512; for n in 2 4; do echo "== $n processes, 16 x 512 (csrc/wn_stack.hip)"; timeout 300 python tools/wn_stack_shared_gpu.py $n 200; done ) > $O/${TAG}_persistent_launches_shared_gpu.txt 2>&1
 ls -la $O
+# round 6: the WN stack launch looped alone / with its weights evicted (what the prefetch pass at the head of infer buys), mid-size batches, the device-side give-up tests
+( cd $R && python tools/wn_in_step_probe.py ) > $O/${TAG}_wn_in_step_probe.txt 2>&1
+( cd $R && python tools/latency_probe.py 2x512 3x512 4x512 5x512 6x512 8x512 ) > $O/${TAG}_latency_mid_size.txt 2>&1
+( cd $R && python -m pytest tests/test_gpu_parity.py -q -m gpu -k "give_up or persistent" 2>&1 | tail -3 ) > $O/${TAG}_give_up_tests.txt
+ls -la $O
