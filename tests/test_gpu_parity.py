@@ -6,6 +6,7 @@ Tolerances (fp32 path; the reference computes with oneDNN/ATen fp32 in a differe
   * full infer waveform (north_star): RMS error <= 1e-3, and relative RMS <= 1e-4
   * spline: 1e-3 max-abs (fp32 conditioning of the inverse), bin-edge flips tolerated
 """
+import os
 import time
 
 import numpy as np
@@ -476,7 +477,9 @@ def test_wn_mid_size_batches(M, n_layers, B, Tn):
     M.native.stats_reset()
     y = m((x * mask).cuda(), mask.cuda())
     st = M.native.stats_get()
-    assert st["conv_launches"] == n_layers + 1 and st["convolutions"] == 2 * n_layers, st
+    assert st["convolutions"] == 2 * n_layers, st
+    if not any(k in os.environ for k in ("SVOC_WN_F25", "SVOC_WN_SMALL_F25", "SVOC_WN_SMALL", "SVOC_KSPLIT", "SVOC_FUSE_WN", "SVOC_WN_SMALL_TILES")):
+        assert st["conv_launches"] == n_layers + 1, st        # (the variant runs of tests/test_gpu_variants.py take other launch forms at these shapes)
     with torch.no_grad():
         ref = O.wn(sdT(sd), "", x * mask, mask, None, hidden=192, kernel_size=5, dilation_rate=1, n_layers=n_layers)
     check(f"wn mid-size n{n_layers} B{B} T{Tn}", y, ref.numpy())
