@@ -1019,6 +1019,31 @@ def test_generator_winograd_upsamplers_vs_oracle(M):
     check("generator F(4,2) upsamplers", y, ref, 5e-5, 1e-4)
 
 
+def test_generator_conv_pre_winograd_vs_oracle(M):
+    """Round 6: conv_pre (k = 7, 192 -> 512 channels at iitp_base) runs on the F(4,4) Winograd kernel when nothing masks or conditions its input and the launch
+    has half a tile per CU (csrc/engine.hip Generator::forward).  A Generator with iitp_base's conv_pre (192 -> 512) and ONE upsampler stage, at a batch that
+    passes the gate: the event profiler must name the Winograd launch, and the output must match the oracle; a length that is not a multiple of four takes the
+    direct kernel (the F(4,x) kernels want whole windows) and must match as well."""
+    c = dict(initial_channel=192, resblock="1", rks=[3], rds=[[1, 3, 5]], ur=[2], uic=512, uks=[4], gin=0)
+    sd = sw.fill_state_dict(cases.generator_shapes(c), 7731, 1.0)
+    m = load(M.models.Generator(c["initial_channel"], c["resblock"], c["rks"], c["rds"], c["ur"], c["uic"], c["uks"], gin_channels=0), sd)
+    for Tn, want in ((256, True), (254, False)):
+        x = T(cases.rnd(7731 + Tn, "x", (16, 192, Tn), 1.0))
+        M.native.profile_enable(True)
+        y = m(x.cuda())
+        torch.cuda.synchronize()
+        rep = M.native.profile_report()
+        M.native.profile_enable(False)
+        ran = any(l.startswith("wino4 ") and "Ci192" in l and "Co512" in l and "k7" in l for l in rep.splitlines())
+        if "SVOC_WINO" not in os.environ and "SVOC_WINO_F4" not in os.environ:
+            assert ran == want, rep
+        pick = [0, 7, 15]
+        with torch.no_grad():
+            ref = O.generator(sdT(sd), x[pick], prefix="", resblock="1", resblock_kernel_sizes=c["rks"], resblock_dilation_sizes=c["rds"],
+                              upsample_rates=c["ur"], upsample_kernel_sizes=c["uks"])
+        check(f"generator conv_pre T{Tn}", y[pick], ref, 5e-5, 1e-4)
+
+
 def test_infer_long_form_tiling(M, net):
     """Long input (T=1024, B=1) against the oracle over the WHOLE waveform: many time tiles and every halo.  (The full C5
     shape, 8 x 4096, is test_c5_full_size below.)"""
