@@ -1274,43 +1274,6 @@ def test_device_side_give_up_makes_the_waveform_of_that_call_non_finite(M, net):
     M.native.check_async_error()
 
 
-@pytest.mark.parametrize("B,Tn,iters", [(16, 512, 8), (1, 200, 40), (4, 512, 12)])
-def test_two_handles_on_two_streams_in_one_process(M, net, B, Tn, iters):
-    """"two model handles or streams in one process" share the GPU like two processes do - the persistent WN launches of the two streams compete for
-    the CUs.  Two SynthesizerTrn instances with the same weights, each on a stream of its own, `infer` enqueued on both before anything is synchronised.  The
-    contract: every call either returns the bits of the same call made alone, or the failure is REPORTED (non-finite result + `check_async_error`) - never a
-    finite wrong waveform.  (On an otherwise idle GPU every call is clean: tools/two_streams_one_process.py, 300 calls.)"""
-    other = M.models.SynthesizerTrn(513, 32, n_speakers=109, **cases.IITP_MODEL)
-    other.load_state_dict({k: T(v) for k, v in cases.full_model_weights(skip_enc_q=True).items()}, strict=False)
-    nets = [net, other.cuda().eval()]
-    ins = [(T(sw.synthetic_mel(5 + i, B, Tn)).cuda(), T(sw.synthetic_eps(5 + i, B, Tn)).cuda()) for i in range(2)]
-    ln = torch.full((B,), Tn, dtype=torch.int64).cuda()
-    M.native.check_async_error()
-    refs = [nets[i].infer(ins[i][0], ln, noise_scale=0.667, eps=ins[i][1])[0].clone() for i in range(2)]
-    torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    reported = 0
-    try:
-        for _ in range(iters):
-            outs = [None, None]
-            for i in range(2):
-                with torch.cuda.stream(streams[i]):
-                    outs[i] = nets[i].infer(ins[i][0], ln, noise_scale=0.667, eps=ins[i][1])[0]
-            torch.cuda.synchronize()
-            try:
-                M.native.check_async_error()
-            except RuntimeError:
-                reported += 1
-                assert not all(bool(torch.isfinite(o).all()) for o in outs)      # the call that gave up a wait says so in its own result
-                M.native.debug_persist_control(reenable=True)
-                continue
-            for i in range(2):
-                assert torch.equal(outs[i], refs[i])
-    finally:
-        M.native.debug_persist_control(reenable=True)
-    assert reported <= iters // 2, reported
-
-
 def test_mel_encoder_standalone(M):
     for name, c in cases.MELENC_CASES.items():
         sd = sw.fill_state_dict(cases.melenc_shapes(c["Cout"], c["H"], c["k"], c["n"], c["gin"]), c["seed"])

@@ -347,3 +347,20 @@ def test_rccl_two_devices(tmp_path):
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["config"]["collective"] == "gather" and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
     assert j["value"] > 0 and len(j["per_rank"]["infer_ms"]) == 2 and j["infer_sharded"]["equals_timed_step_output"] is True, j
+
+
+def test_two_handles_on_two_streams_in_one_process():
+    """"two model handles or streams in one process" share the GPU like two processes do - the persistent WN launches of the two streams compete for
+    the CUs.  tools/two_streams_one_process.py: two SynthesizerTrn instances with the same weights, each on a stream of its own, `infer` enqueued on both before
+    anything is synchronised, at 16 x 512, 1 x 200 and 4 x 512.  The contract: every call either returns the bits of the same call made alone, or its failure is
+    REPORTED through `svoc_check_async_error` - never a silent mismatch.  (Runs here, behind the variant pool of tests/test_gpu_variants.py, so that nothing else
+    shares the GPU; on an idle GPU every call is clean.)"""
+    tool = os.path.join(cases.ROOT, "tools", "two_streams_one_process.py")
+    shapes = ((16, 512, 10), (1, 200, 60), (4, 512, 16))
+    r = subprocess.run([sys.executable, tool] + [str(v) for sh in shapes for v in sh], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    for B, Tn, iters in shapes:
+        line = [l for l in r.stdout.splitlines() if l.startswith(f"B={B} T={Tn}:")][-1]
+        assert "silent mismatches 0," in line, line
+        assert int(line.split("reported failures ")[1].split(",")[0]) <= iters // 2, line
