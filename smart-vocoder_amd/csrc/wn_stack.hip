@@ -63,6 +63,10 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
   float* const AT = PLN;
   float* const RED = PLN + 6 * WNF_PLANE;                   // exchange area [12 waves][16][64]
   volatile int* const BAD = reinterpret_cast<volatile int*>(lds + WNF_LDS_FLOATS);      // set by a wait that gave up: the workgroup's results are NaN from then on
+  // the layer's two bias vectors (in_layer: 2 H in paired tile order; res_skip: 2 H, last layer H): requested from global memory at the top of the layer,
+  // written here behind the input transform, read by the gate and by phase B's accumulator set-up - as global loads in place they were two exposed L2 round
+  // trips between the two MFMA phases (round 6: tools/wn_stack_timeline.py, "gate" 1.78 us of a 42 us layer)
+  float* const BIASL = lds + WNF_LDS_FLOATS + 4;
   if (threadIdx.x == 0) *BAD = 0;
 
   const int tid = threadIdx.x;
@@ -122,6 +126,10 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
     const int tid = tid_, lane = tid & 63;
     const int l31 = lane & 31, hi = lane >> 5, col = lane & 15, k4 = lane >> 4;
     const int te = t0 + l31, row0 = pi * 32 + 4 * hi;
+    // diagnostics (tools/wn_stack_timeline.py): wall-clock stamps (10 ns) of thread 0 in the middle layer, [workgroup][16]
+    const bool stamped = p.dbg != nullptr && li == (NL >> 1) && tid == 0;
+    auto stamp = [&](int i) { if (stamped) p.dbg[(long long)gt * 16 + i] = (long long)__builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
     float* const red_mine = RED + (wave * 16) * 64 + lane;
     float* const red_peer = RED + ((kh ? pi : pi + NPAIRS) * 16) * 64 + lane;
     // phase A's weight stream: descriptor, ring of four 16-byte sets, three requests ahead (requested before anything else of the layer)
@@ -144,6 +152,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       d = *reinterpret_cast<const float4*>(&t);
     };
     wload(a[0], w0); wload(a[1], w0 + 1024); wload(a[2], w0 + 2048);
+    const float bias_v = tid < 2 * H ? ly.bias1[tid] : ((!last || tid < 3 * H) ? ly.bias2[tid - 2 * H] : 0.f);      // 768 threads = 2 H + 2 H values
     // ---- the neighbours' edges of x_li (what they computed in layer li - 1): tile columns 2, 3 (t0 - 2, t0 - 1) and 36, 37 (t0 + 32, t0 + 33)
     if (li > 0) {
       if (((tid == 0 && has_left) || (tid == 64 && has_right)) && *BAD == 0) {      // (a workgroup that gave up once does not wait again)
@@ -162,6 +171,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
           }
         }
       }
+      stamp(1);
       __syncthreads();
       if (*BAD != 0) mk = __builtin_nanf("");
       // 2 sides x H rows x 2 columns = 768 values: one per thread.  Left neighbour's RIGHT edge -> my columns 2, 3; right neighbour's LEFT edge -> 36, 37
@@ -176,6 +186,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       }
       __syncthreads();
     }
+    stamp(2);
     // ---- input transform: window q of channel c reads x[t0 + 2q - 2 .. + 3] = tile columns 2q + 2 .. 2q + 7 (8-byte aligned)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -193,7 +204,9 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       o[4 * WNF_PLANE] = c_ - e_;
       o[5 * WNF_PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
     }
+    BIASL[tid] = bias_v;
     __syncthreads();
+    stamp(3);
     // ---- phase A: 24 k-steps x 6 products x 4 row tiles of v_mfma_f32_16x16x4_f32 (wn_layer_f25_kernel's stream)
     wn_f32x4 M[4][6];
 #pragma unroll
@@ -238,6 +251,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       rdb(std::integral_constant<int, 0>{}); rdb(std::integral_constant<int, 1>{});
       wino_static_for<0, NST>(step);
     }
+    stamp(4);
     // ---- output transform of the partial sums; this wave finishes 16-row tile kh of both halves and hands the other to its peer
     float own[2][4][2];
 #pragma unroll
@@ -255,8 +269,9 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       }
     }
     __syncthreads();     // partials published; every wave is done with the planes (the acts tile takes their place)
+    stamp(5);
     {
-      const float* bias1 = ly.bias1;
+      const float* bias1 = BIASL;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = 16 * kh + 4 * k4 + i;
@@ -274,14 +289,16 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
     // ---- phase B: res_skip 1x1 on the acts tile: tile pi = x part, tile npairs + pi = skip part (last layer: the only tile)
     f32x16 acc[2][1];
     {
-      const float* bias2 = ly.bias2;
+      const float* bias2 = BIASL + 2 * H;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           acc[h][0][i] = (!kh && (h == 0 || !last)) ? bias2[(h * NPAIRS + pi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi] : 0.f;
     }
+    stamp(6);
     __syncthreads();     // acts tile complete, exchange area free again
+    stamp(7);
     {
       const unsigned baddr = (unsigned)(size_t)AT + (unsigned)((kh * 96 + hi) * WNF_AROW + l31) * 4u;
       const int wb0 = __builtin_amdgcn_readfirstlane((pi * p.ksg2 + kh * 12) * 1024);
@@ -289,6 +306,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       if (last) wn_gemm_ct<WNF_AROW, 1, 1, false>(acc, ly.wp2, wb0, wb0, baddr, (unsigned)lane * 16u);
       else wn_gemm_ct<WNF_AROW, 1, 1, true>(acc, ly.wp2, wb0, wb1, baddr, (unsigned)lane * 16u);
     }
+    stamp(8);
     // exchange: kh=0 finishes tile 0 (residual part; on the last layer the only tile), kh=1 finishes tile 1 (skip part)
     if (!last) {
 #pragma unroll
@@ -298,6 +316,7 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
       for (int q = 0; q < 16; ++q) red_mine[q * 64] = acc[0][0][q];
     }
     __syncthreads();
+    stamp(9);
     float fin[16];
     if (!last || !kh) {
 #pragma unroll
@@ -331,9 +350,11 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
           for (int r = 0; r < 16; ++r) ob[(long long)((r & 3) + 8 * (r >> 2)) * p.out_ld] = fin[r];
         }
       }
+      stamp(10);
       // publish: the edge stores acknowledged (above: the waves that made them waited), then the layer count of this tile
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __syncthreads();                                       // every wave's edge stores are ordered before the counter; the tile is whole for the next transform
+      __syncthreads();
+      stamp(11);                                       // every wave's edge stores are ordered before the counter; the tile is whole for the next transform
       if (tid == 0 && gt != p.fault_tile) __hip_atomic_store(p.done + gt, li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (!kh && col_ok) {    // last layer: out = (out + rs) * mask
       float* const ob = p.out + (long long)b * p.out_bs + (long long)row0_ * p.out_ld + te_;
@@ -369,7 +390,7 @@ bool wn_stack_enabled() {
 // scratch: halo buffer | per-tile layer counters | error word | (64-byte aligned) the layers' pointer table
 static size_t wn_stack_table_offset() { return (((size_t)WNS_MAXL * device_cu_count() * 2 * WNF_H * 2 + device_cu_count() + 20) * sizeof(float) + 63) / 64 * 64; }
 size_t wn_stack_scratch_bytes() { return wn_stack_table_offset() + WNS_MAXL * sizeof(WnStackLayer); }
-constexpr size_t WNS_LDS_BYTES = (size_t)WNF_LDS_FLOATS * sizeof(float) + 16;      // + the give-up flag
+constexpr size_t WNS_LDS_BYTES = (size_t)(WNF_LDS_FLOATS + 4 + 4 * WNF_H) * sizeof(float);      // + the give-up flag + the layer's bias vectors
 // Workgroups of the launch that can be resident at one time: what the runtime's occupancy calculator says for this kernel's registers, threads and
 // LDS (one per CU with these figures), never more than the CU count the scratch area is sized for.  hipLaunchCooperativeKernel would make the same
 // check at launch time - and is not taken because the launch has to be capturable: DESIGN.md section 4.4d.
@@ -401,7 +422,7 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
   a.done = a.exited + 17;
   a.err = async_error_word();                                // pinned host memory (misc_kernels.hip): looked at by the next call
   if (!a.err) return 1;
-  a.dbg = nullptr;
+  a.dbg = debug_stamp_buffer();
   a.timeout = persist_timeout_ticks();
   a.fault_tile = persist_fault_tile();
   // The counters are NOT cleared by a memset ahead of the launch: a first version did that, and inside a captured plan replayed while another
