@@ -31,7 +31,7 @@ typedef float wns_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int wns_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WNS_H = 192, WNS_XROW = 40, WNS_NQ = 16, WNS_PLANE = WNS_H * WNS_NQ, WNS_AROW = 48;
 constexpr int WNS_XT = WNS_H * WNS_XROW, WNS_PLN = 6 * WNS_PLANE, WNS_AT = WNS_H * WNS_AROW;
-constexpr int WNS_LDS_FLOATS = WNS_XT + WNS_PLN + WNS_AT + 64;       // + mask tile [48]
+constexpr int WNS_LDS_FLOATS = WNS_XT + WNS_PLN + WNS_AT + 64 + 4 * WNS_H;       // + mask tile [48] + the in_layer's bias [2 H] + the previous res_skip's [2 H]
 static_assert(12 * 32 * 64 <= WNS_PLN + WNS_AT, "the reduction area aliases the planes and the acts tile");
 
 struct WnSmallArgs {
@@ -55,6 +55,10 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
   float* const PLN = lds + WNS_XT;                          // V_p [6][H][16]
   float* const AT = PLN + WNS_PLN;                          // acts_{i-1} tile [H][48]: columns t0 - 8 .. t0 + 39
   float* const MK = AT + WNS_AT;                            // mask of those 48 columns
+  // the two bias vectors the kernel adds (round 6): requested at the top, parked here by the staging pass - read from global memory where they are used they were
+  // exposed L2 round trips behind the 1 x 1's MFMAs and in the gate
+  float* const BI = MK + 64;                                // in_layer i: [2 H] paired tile order
+  float* const BR = BI + 2 * WNS_H;                         // res_skip i-1: [2 H] natural order (residual | skip)
   float* const RED = PLN;                                   // [12 waves][32][64] partial outputs (after the stream)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,6 +77,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
     const wns_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs16, lane * 16, soff, 0);
     return *reinterpret_cast<const float4*>(&t);
   };
+  const float bias_v = tid < 2 * H ? p.bias1[tid] : (has_prev ? p.wrs[24 * 12 * 256 + tid - 2 * H] : 0.f);      // 768 threads = 2 H + 2 H values
   float4 awx[12], aws[12];
   if (has_prev) {
     const int wbx = __builtin_amdgcn_readfirstlane(wave * 12 * 1024);
@@ -135,10 +140,11 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
       }
     }
   }
+  BI[tid] = bias_v;                                          // (BR directly behind BI)
   __syncthreads();
 
   if (has_prev) {
-    const float* rsbias = p.wrs + 24 * 12 * 256;           // natural order: [0, H) residual part, [H, 2H) skip part
+    const float* rsbias = BR;                               // natural order: [0, H) residual part, [H, 2H) skip part
     // ---- skip part of res_skip_{i-1}: rows H + 32 pi .. + 31 on the 32 centre columns: waves 0..3 (+ 4 j: pair pi0 + j) = (row tile, column tile)
     if (wave < 4 * PP) {
       const int pi = pi0 + (wave >> 2);
@@ -313,8 +319,8 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
       const int chn = 32 * pi + rr;
       const int m = 2 * col + (j & 1);
       const int t = t0 + m;
-      vA += p.bias1[(2 * pi) * 32 + rr];
-      vB += p.bias1[(2 * pi + 1) * 32 + rr];
+      vA += BI[(2 * pi) * 32 + rr];
+      vB += BI[(2 * pi + 1) * 32 + rr];
       if (gb) {
         const int tc = min(t, T - 1);
         vA += gb[(long long)chn * p.gadd_ld + (long long)tc * p.gadd_ts];
