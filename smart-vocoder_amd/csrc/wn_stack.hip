@@ -253,19 +253,26 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
     }
     stamp(4);
     // ---- output transform of the partial sums; this wave finishes 16-row tile kh of both halves and hands the other to its peer
+    // (the 16-row tile this wave keeps and the one it hands to its peer are picked with selects: as a wave-uniform branch per row tile the compiler kept
+    // both outcomes of every tile alive - eight spilled register pairs per layer)
     float own[2][4][2];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int h = rt >> 1;
-      const bool mine = (rt & 1) == kh;
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float s12 = M[rt][1][i] + M[rt][2][i], d12 = M[rt][1][i] - M[rt][2][i];
-        const float s34 = M[rt][3][i] + M[rt][4][i], d34 = M[rt][3][i] - M[rt][4][i];
-        const float y0 = M[rt][0][i] + (s12 + s34);
-        const float y1 = __builtin_fmaf(2.f, d34, d12) + M[rt][5][i];
-        if (mine) { own[h][i][0] = y0; own[h][i][1] = y1; }
-        else { red_mine[(h * 8 + 2 * i) * 64] = y0; red_mine[(h * 8 + 2 * i + 1) * 64] = y1; }
+        float y[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const int rt = 2 * h + o;
+          const float s12 = M[rt][1][i] + M[rt][2][i], d12 = M[rt][1][i] - M[rt][2][i];
+          const float s34 = M[rt][3][i] + M[rt][4][i], d34 = M[rt][3][i] - M[rt][4][i];
+          y[o][0] = M[rt][0][i] + (s12 + s34);
+          y[o][1] = __builtin_fmaf(2.f, d34, d12) + M[rt][5][i];
+        }
+        own[h][i][0] = kh ? y[1][0] : y[0][0];
+        own[h][i][1] = kh ? y[1][1] : y[0][1];
+        red_mine[(h * 8 + 2 * i) * 64] = kh ? y[0][0] : y[1][0];
+        red_mine[(h * 8 + 2 * i + 1) * 64] = kh ? y[0][1] : y[1][1];
       }
     }
     __syncthreads();     // partials published; every wave is done with the planes (the acts tile takes their place)
