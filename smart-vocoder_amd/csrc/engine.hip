@@ -177,6 +177,23 @@ struct WNStack {
         if (r == 0) return SVOC_OK;
       }
     }
+    // ... and batches beyond its capacity as one such launch per group of whole utterances (32 x 512: two of sixteen; 8 x 4096: four of two) - round 6
+    if (const int ng = (!g && stack_ws.p) ? wn_stack_groups(H, K, DR, NL, B, T) : 0) {
+      const PackedConv* il[16]; const PackedConv* rl[16]; const float* wf[16];
+      bool all = true;
+      for (int i = 0; i < NL; ++i) { il[i] = in_l[i].get(); rl[i] = rs_l[i].get(); wf[i] = in_f25[i]->f(); all = all && wf[i] != nullptr; }
+      if (all) {
+        const int bg = B / ng;
+        for (int gi = 0; gi < ng; ++gi) {
+          const long long b0 = (long long)gi * bg;
+          const int r = launch_wn_stack_f25(il, rl, wf, NL, H, src + b0 * src_bs, src_bs, src_ld, out + b0 * out_bs, out_bs, out_ld, mask + b0 * mask_bs, mask_bs,
+                                            stack_ws.f(), bg, T, st, gi == 0);
+          if (r < 0) return r;
+          if (r != 0) SVOC_FAIL(SVOC_ERR_UNSUPPORTED, "WN: the stack launch refused a group it had accepted");
+        }
+        return SVOC_OK;
+      }
+    }
     for (int i = 0; i < NL; ++i) {
       const bool last = i == NL - 1;
       float* dst = (i & 1) ? xb : xa;

@@ -244,8 +244,9 @@ bool wn_f25_enabled();
 // wn_stack.hip: a whole WN stack in one persistent launch (neighbour-to-neighbour edge exchange between the layers)
 size_t wn_stack_scratch_bytes();
 bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T);
+int wn_stack_groups(int H, int K, int dil_rate, int NL, int B, int T);      // > 1: that many launches over equal groups of utterances (batches beyond the launch's capacity)
 int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, int H, const float* x, long long x_bs,
-                        int x_ld, float* out, long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st);
+                        int x_ld, float* out, long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st, bool first_group = true);
 int wn_stack_prepare(float* scratch, const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, hipStream_t st);
 bool wn_layer_prefers_unfused(int B, int T);              // short inputs: fewer 32-column tiles than half the CUs (wn_fused.hip's size gate)
 // wn_mesh.hip: a whole WN stack for SHORT inputs in one persistent launch (twelve workgroups per 32-column tile, two hand-overs per layer)

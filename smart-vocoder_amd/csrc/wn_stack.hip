@@ -408,9 +408,21 @@ bool wn_stack_applies(int H, int K, int dil_rate, int NL, int B, int T) {
   const long long tiles = (long long)B * ((T + 31) / 32);
   return !wn_layer_prefers_unfused(B, T) && tiles <= wn_stack_capacity() && B <= 65535;
 }
+// Batches of MORE tiles than the launch can hold resident (32 x 512, 8 x 4096): utterances are independent, so the batch is cut into n equal groups of whole
+// utterances and the stack launched once per group, one after the other on the stream (the hand-shake state is left clean by every launch) - taken when every
+// group fills at least 7/8 of the launch's capacity, i.e. when n launches of ~41 us per layer beat the per-layer kernel's tiles / CUs rounds of ~46 us.  0: no.
+int wn_stack_groups(int H, int K, int dil_rate, int NL, int B, int T) {
+  if (!wn_stack_enabled() || persist_disabled() || H != WNF_H || K != 5 || dil_rate != 1 || NL < 2 || NL > WNS_MAXL || B <= 1 || T <= 0) return 0;
+  const long long ntx = (T + 31) / 32, tiles = (long long)B * ntx, cap = wn_stack_capacity();
+  if (cap <= 0 || tiles <= cap || ntx > cap) return 0;
+  const long long n = (tiles + cap - 1) / cap;
+  if (B % n != 0) return 0;
+  const long long per = (B / n) * ntx;
+  return (per <= cap && per * 8 >= cap * 7 && wn_stack_applies(H, K, dil_rate, NL, (int)(B / n), T)) ? (int)n : 0;
+}
 // in_l / rs_l: the NL layers' packed convolutions; wpf[i]: their F(2,5) images; scratch: wn_stack_scratch_bytes() of device memory.  1 = not eligible.
 int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* rs_l, const float* const* wpf, int NL, int H, const float* x, long long x_bs,
-                        int x_ld, float* out, long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st) {
+                        int x_ld, float* out, long long out_bs, int out_ld, const float* mask, long long mask_bs, float* scratch, int B, int T, hipStream_t st, bool first_group) {
   if (!wn_stack_applies(H, in_l[0]->ktaps, 1, NL, B, T) || !scratch) return 1;
   WnStackArgs a{};
   for (int i = 0; i < NL; ++i) {
@@ -441,7 +453,7 @@ int launch_wn_stack_f25(const PackedConv* const* in_l, const PackedConv* const* 
     flops += (in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;
     exec += (0.6 * in_l[i]->flops_per_col + rs_l[i]->flops_per_col) * (double)B * (double)T;
   }
-  stats_add_conv(flops, 2 * NL, exec);
+  stats_add_conv(flops, first_group ? 2 * NL : 0, exec);      // (a batch launched in groups of utterances counts its convolutions once)
   int prof_idx = -1;
   if (prof_enabled()) {
     char d[160];
