@@ -324,11 +324,11 @@ __global__ void __launch_bounds__(768) wn_stack_f25_kernel(const WnStackArgs p) 
     }
     __syncthreads();
     stamp(9);
+    // (assigned on every path - on the last layer K half 1 reads stale words it never uses: left conditionally unassigned the compiler carried the sixteen
+    // registers across the layer loop's back edge and spilled them)
     float fin[16];
-    if (!last || !kh) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) fin[q] = (kh ? acc[1][0][q] : acc[0][0][q]) + red_peer[q * 64];
-    }
+    for (int q = 0; q < 16; ++q) fin[q] = (kh ? acc[1][0][q] : acc[0][0][q]) + red_peer[q * 64];
     // ---- epilogue (modules.py:168-175).  The addresses are rebuilt from opaque copies of the lane's coordinates in every layer: left to itself the
     // compiler hoists the sixteen 64-bit row addresses of each branch out of the layer loop and keeps them live through the streams (~190 spilled registers)
     const int te_ = te, row0_ = row0, l31_ = l31;
