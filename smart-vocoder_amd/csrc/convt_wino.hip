@@ -410,11 +410,19 @@ __global__ void __launch_bounds__(NRT == 8 ? 768 : 512) convt_wino_kernel(const 
         for (int c = 0; c < 2; ++c) {                      // the quad's two channels: rows 2 c (phase 0), 2 c + 1 (phase 1)
           float* const yrow = reinterpret_cast<float*>(yb + (size_t)(16 * mt + 4 * Q + 2 * hi + c) * ylb);
           const int n0 = 2 * qc - 1;                       // eight consecutive samples n0 .. n0 + 7: (i, phase) = (0,0) (0,1) (1,0) ...
+          // (round 6) the lane's samples start one short of a 32-byte boundary: its first one is stored by the lane to its LEFT, which thereby writes two
+          // aligned 16-byte groups [n0 + 1, n0 + 9) instead of 4 + 16 + 8 + 4 bytes; the first lane of the 32 and a lane whose left neighbour is off the row
+          // store their own first sample, the last lane of the 32 keeps the short form
+          const float nxt = __shfl_down(yv[0][2 * c], 1, 64);
           if (n0 >= 0 && n0 + 7 < LoutE) {
-            yrow[n0] = yv[0][2 * c];
+            if (l31 == 0 || n0 < 8) yrow[n0] = yv[0][2 * c];
             *reinterpret_cast<float4*>(yrow + n0 + 1) = make_float4(yv[0][2 * c + 1], yv[1][2 * c], yv[1][2 * c + 1], yv[2][2 * c]);
-            *reinterpret_cast<float2*>(yrow + n0 + 5) = make_float2(yv[2][2 * c + 1], yv[3][2 * c]);
-            yrow[n0 + 7] = yv[3][2 * c + 1];
+            if (l31 < 31 && n0 + 8 < LoutE) {
+              *reinterpret_cast<float4*>(yrow + n0 + 5) = make_float4(yv[2][2 * c + 1], yv[3][2 * c], yv[3][2 * c + 1], nxt);
+            } else {
+              *reinterpret_cast<float2*>(yrow + n0 + 5) = make_float2(yv[2][2 * c + 1], yv[3][2 * c]);
+              yrow[n0 + 7] = yv[3][2 * c + 1];
+            }
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
