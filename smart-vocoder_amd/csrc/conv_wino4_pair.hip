@@ -300,15 +300,18 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
       char* const ybase = reinterpret_cast<char*>(pm.y + (long long)bz * pm.y_bs + (long long)(32 * rt + 4 * hi) * pm.y_ld + ne);
       const char* const rbase = reinterpret_cast<const char*>(pm.x + (long long)bz * pm.x_bs + (long long)(32 * rt + 4 * hi) * pm.x_ld + ne);
       const size_t ylb = (size_t)pm.y_ld * 4, rlb = (size_t)pm.x_ld * 4;
+      // the sixteen residual rows are requested in ONE batch ahead of the first output transform (round 6): a quarter at a time - four loads, transform, add,
+      // store, the next four loads - the epilogue paid four L2 round trips in a row (the compiler keeps the source order across the stores)
+      float4 rvall[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rvall[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (r >> 2) + (r & 3)) * rlb);
       auto quarter = [&](auto q_c) {
         constexpr int Q = decltype(q_c)::value;
-        float4 rv[4], vo[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * Q + r) * rlb);
+        float4 vo[4];
         ytrans(q_c, vo);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          w4_add4(vo[r], rv[r]);
+          w4_add4(vo[r], rvall[4 * Q + r]);
           *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q + r) * ylb) = vo[r];
         }
       };
@@ -534,30 +537,36 @@ __device__ __forceinline__ void pairacc_consume(const PairMember& pm, const Pair
     const bool eacc = (pm.eflags & F_ACC) != 0, ediv = (pm.eflags & F_DIV) != 0;
     const float dv = pm.div, rc = 1.0f / dv;
     auto dv1 = [&](float x) { const float q = x * rc; return __builtin_fmaf(__builtin_fmaf(-q, dv, x), rc, q); };      // x / div (conv_wino4_kernels.h)
-    auto quarter = [&](auto q_c) {
-      constexpr int Q = decltype(q_c)::value;
-      float4 rv[4], vo[4];
+    // the residual rows (and, from the second member on, what this lane stored one member earlier) are requested for TWO quarters at a time, ahead of the
+    // first of their output transforms (round 6: a quarter at a time the epilogue paid four round trips in a row; all four at once would not fit the registers)
+    auto half = [&](auto h_c) {
+      constexpr int HQ = decltype(h_c)::value;               // quarters 2 HQ, 2 HQ + 1
+      float4 rv[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * Q + r) * rlb);
+      for (int r = 0; r < 8; ++r) rv[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (2 * HQ + (r >> 2)) + (r & 3)) * rlb);
       if (eacc) {                                            // what this lane stored one member earlier
-        float4 yv[4];
+        float4 yv[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yv[r] = *reinterpret_cast<const float4*>(ybase + (size_t)(8 * Q + r) * ylb);
+        for (int r = 0; r < 8; ++r) yv[r] = *reinterpret_cast<const float4*>(ybase + (size_t)(8 * (2 * HQ + (r >> 2)) + (r & 3)) * ylb);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w4_add4(rv[r], yv[r]);
+        for (int r = 0; r < 8; ++r) w4_add4(rv[r], yv[r]);
       }
-      ytrans(q_c, vo);
+      auto quarter = [&](auto q_c) {
+        constexpr int Q = decltype(q_c)::value;
+        float4 vo[4];
+        ytrans(q_c, vo);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        w4_add4(vo[r], rv[r]);
-        if (ediv) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
-        *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q + r) * ylb) = vo[r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          w4_add4(vo[r], rv[4 * (Q - 2 * HQ) + r]);
+          if (ediv) vo[r] = make_float4(dv1(vo[r].x), dv1(vo[r].y), dv1(vo[r].z), dv1(vo[r].w));
+          *reinterpret_cast<float4*>(ybase + (size_t)(8 * Q + r) * ylb) = vo[r];
+        }
+      };
+      quarter(std::integral_constant<int, 2 * HQ>{});
+      quarter(std::integral_constant<int, 2 * HQ + 1>{});
     };
-    quarter(std::integral_constant<int, 0>{});
-    quarter(std::integral_constant<int, 1>{});
-    quarter(std::integral_constant<int, 2>{});
-    quarter(std::integral_constant<int, 3>{});
+    half(std::integral_constant<int, 0>{});
+    half(std::integral_constant<int, 1>{});
   }
 }
 
