@@ -550,14 +550,14 @@ __device__ __forceinline__ void wino4_problem(const WinoArgs& p, const int v0, c
               for (int r = 0; r < 4; ++r) stq(ybase + (size_t)(8 * Q) * ylb + yo4[r], vo[r]);
             }
           };
-          quarter(std::integral_constant<int, 0>{}, rvA);
-          float4 rvB[8];                                   // requested once the first quarter's accumulator registers are free
+          float4 rvB[8];                                   // (experiment: requested AHEAD of the first quarter)
           if (DBG && (abl & 32u)) {                        // ablation 32: the epilogue without its residual loads
 #pragma unroll
             for (int r = 0; r < 8; ++r) rvB[r] = make_float4(0.f, 0.f, 0.f, 0.f);
           } else
 #pragma unroll
           for (int r = 0; r < 8; ++r) rvB[r] = ldq(rbase + (size_t)(8 * (2 + (r >> 2))) * rlb + ro4[r & 3]);
+          quarter(std::integral_constant<int, 0>{}, rvA);
           quarter(std::integral_constant<int, 1>{}, rvA + 4);
           quarter(std::integral_constant<int, 2>{}, rvB);
           quarter(std::integral_constant<int, 3>{}, rvB + 4);
