@@ -381,7 +381,7 @@ def test_wn_edge_shapes(M):
             check(f"wn H{H} k{k} dr{dr} T{Tn} B{B}", y, ref.numpy())
 
 
-@pytest.mark.parametrize("n_layers,B,Tn", [(16, 8, 520), (8, 5, 1000), (3, 16, 512), (2, 255, 32), (8, 6, 512), (4, 32, 512), (3, 4, 4096)])
+@pytest.mark.parametrize("n_layers,B,Tn", [(16, 8, 520), (8, 5, 1000), (3, 16, 512), (2, 255, 32), (8, 6, 512), (4, 32, 512), (3, 4, 4096), (2, 32, 500)])
 def test_wn_stack_one_persistent_launch(M, n_layers, B, Tn, tmp_path):
     """A whole WN stack in ONE persistent launch (csrc/wn_stack.hip; reference modules.py:148-176): taken while every 32-column tile has a CU of its
     own (96 .. 256 tiles: from 3/8 of the CUs on), the tiles exchanging two-column edges between the layers.  Ragged lengths (an utterance that ends inside a tile, one
