@@ -1018,11 +1018,20 @@ struct Synth {
     const int IC = cfg.inter_channels, Tp = pad4(T);
     const long long iper = (long long)IC * Tp, ubs = (long long)IC * T;
     const Bufs w = bufs(B, T);
-    if (m_p) SVOC_TRY(k_copy2d(st, w.mp, iper, Tp, m_p, ubs, T, B, IC, T, nullptr, 0));
-    if (logs_p) SVOC_TRY(k_copy2d(st, w.lp, iper, Tp, logs_p, ubs, T, B, IC, T, nullptr, 0));
-    if (z_p) SVOC_TRY(k_copy2d(st, w.zp, iper, Tp, z_p, ubs, T, B, IC, T, nullptr, 0));
-    if (z) SVOC_TRY(k_copy2d(st, w.P, iper, Tp, z, ubs, T, B, IC, T, nullptr, 0));
-    if (x_mask) SVOC_TRY(k_copy2d(st, w.mask, Tp, Tp, x_mask, T, T, B, 1, T, nullptr, 0));
+    {   // the five small user-visible outputs in ONE launch (round 6; one launch each until then)
+      CopyMany cm{};
+      cm.cols = T; cm.B = B;
+      auto add = [&](const float* src, long long s_bs, float* dst, long long d_bs, int rows) {
+        if (!dst) return;
+        const int k = cm.n++;
+        cm.src[k] = src; cm.dst[k] = dst; cm.s_bs[k] = s_bs; cm.d_bs[k] = d_bs; cm.s_ld[k] = Tp; cm.d_ld[k] = T; cm.rows[k] = rows;
+      };
+      add(w.mp, iper, m_p, ubs, IC); add(w.lp, iper, logs_p, ubs, IC); add(w.zp, iper, z_p, ubs, IC); add(w.P, iper, z, ubs, IC); add(w.mask, Tp, x_mask, T, 1);
+      const int rc = k_copy2d_many(st, cm);
+      if (rc == SVOC_ERR_UNSUPPORTED) {                     // (a batch too large for the grid's z dimension: one launch per output)
+        for (int k = 0; k < cm.n; ++k) SVOC_TRY(k_copy2d(st, cm.src[k], cm.s_bs[k], cm.s_ld[k], cm.dst[k], cm.d_bs[k], cm.d_ld[k], B, cm.rows[k], T, nullptr, 0));
+      } else if (rc != SVOC_OK) return rc;
+    }
     return dec.post(st, ls, o, B);
   }
 

@@ -411,6 +411,26 @@ int k_copy2d(hipStream_t st, const float* src, long long s_bs, int s_ld, float* 
   return SVOC_OK;
 }
 
+// up to five strided 2-D copies in ONE launch (round 6: the user-visible outputs of infer - m_p, logs_p, z_p, z, x_mask - were five launches behind every call;
+// at 1 x 200 four launches are 0.5 % of the call); blockIdx.z = (copy, batch element)
+__global__ void copy2d_many_kernel(const CopyMany m) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  const int k = blockIdx.z / m.B, b = blockIdx.z - k * m.B;
+  if (c >= m.cols || r >= m.rows[k]) return;
+  m.dst[k][(long long)b * m.d_bs[k] + (long long)r * m.d_ld[k] + c] = m.src[k][(long long)b * m.s_bs[k] + (long long)r * m.s_ld[k] + c];
+}
+int k_copy2d_many(hipStream_t st, const CopyMany& m) {
+  if (m.n <= 0 || m.B <= 0 || m.cols <= 0) return SVOC_OK;
+  int rows = 0;
+  for (int k = 0; k < m.n; ++k) rows = std::max(rows, m.rows[k]);
+  if (rows <= 0 || (long long)m.n * m.B > 65535) return SVOC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(copy2d_many_kernel, dim3((m.cols + 255) / 256, rows, m.n * m.B), dim3(256), 0, st, m);
+  SVOC_HIP(hipGetLastError());
+  stats_add_other();
+  return SVOC_OK;
+}
+
 // channel flip (modules.Flip, modules.py:272) as a strided copy: dst[b][c] = src[b][C-1-c]
 __global__ void flip_copy_kernel(const float* __restrict__ src, long long s_bs, int s_ld, float* __restrict__ dst,
                                  long long d_bs, int d_ld, int C, int T) {

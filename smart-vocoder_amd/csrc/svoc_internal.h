@@ -281,6 +281,8 @@ int k_sequence_mask(hipStream_t st, const int64_t* lengths, float* mask, int B, 
 int k_gate(hipStream_t st, const float* a, const float* b, float* y, int B, int H, int T);
 int k_conv_post_tanh(hipStream_t st, const float* x, long long x_bs, int x_ld, const float* w, int C, int K, float slope,
                      float* y, int B, int L);
+struct CopyMany { const float* src[5]; float* dst[5]; long long s_bs[5], d_bs[5]; int s_ld[5], d_ld[5], rows[5]; int n, cols, B; };
+int k_copy2d_many(hipStream_t st, const CopyMany& m);      // up to five strided copies with one column count in one launch (misc_kernels.hip)
 int k_copy2d(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
              int rows, int cols, const float* mask, long long mask_bs);
 int k_flip_copy(hipStream_t st, const float* src, long long s_bs, int s_ld, float* dst, long long d_bs, int d_ld, int B,
