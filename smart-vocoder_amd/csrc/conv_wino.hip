@@ -540,8 +540,11 @@ bool wino44_enabled();
 int wino4_slots(int K, bool f44);
 int wino4_ntn(int L, int D, int NRT);
 int pack_wino4_image(float* wp4, int Cin, int Cout, int K, bool f44, const float* w_or_v, const float* scale, hipStream_t st);
+int pack_wino4_raw(float* dst, int Cin, int Cout, int K, const float* w_or_v, const float* scale, hipStream_t st);
+int wino4_tail_plan(int L, int D, int NRT, int* w_first, int* nwin);
 int wino4_launch(const WinoArgs& w, int K, int D, int NC, bool f44, long long total, hipStream_t st);
-int wino4_launch_group(const WinoGroup& g, int D, int NC, int in_perm, int out_perm, bool f44, long long total, hipStream_t st);
+int wino4_launch_group(const WinoGroup& g, int D, int NC, int in_perm, int out_perm, bool f44, long long total, hipStream_t st, const float* const* wraw,
+                       const int* Cout, int tail_w0, int tail_nw, int B);
 int wino4_launch_acc3(const WinoArgs* a, int NRT, int in_perm, bool f44, long long total, hipStream_t st);      // conv_wino4_acc.hip
 
 bool wino_supported(int Cin, int Cout, int K, int dil) {
@@ -578,6 +581,10 @@ int pack_wino(PackedWino& pw, int Cin, int Cout, int K, const float* w_or_v, con
     SVOC_TRY(pw.wp4.ensure((size_t)(total4 + 1024) * sizeof(float)));
     SVOC_HIP(hipMemsetAsync(pw.wp4.f() + total4, 0, 1024 * sizeof(float), st));
     SVOC_TRY(pack_wino4_image(pw.wp4.f(), Cin, Cout, K, pw.f44, w_or_v, g ? scale.f() : nullptr, st));
+    if (Cin % 32 == 0 && Cout % 32 == 0) {                  // (the tail kernel's 16-byte weight loads and four rows per pass)
+      SVOC_TRY(pw.wraw.ensure((size_t)Cout * Cin * K * sizeof(float)));
+      SVOC_TRY(pack_wino4_raw(pw.wraw.f(), Cin, Cout, K, w_or_v, g ? scale.f() : nullptr, st));
+    }
     if (wino44_enabled() && K == 3) {
       const long long total44 = (long long)pw.mtiles * pw.nchunks * wino4_slots(K, true) * 4 * 256;
       SVOC_TRY(pw.wp44.ensure((size_t)(total44 + 1024) * sizeof(float)));
@@ -809,6 +816,25 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
   for (int i = 1; i < n; ++i) if (as[i].wperm_in != in_perm || as[i].wperm_out != out_perm) return 1;
   if (query) return f4 ? 0 : 1;
   if ((in_perm || out_perm) && !f4) SVOC_FAIL(SVOC_ERR_INVALID_ARG, "window-major rows exist in the grouped F(4,3) launches only");
+  // the rows' partial last tiles go to the tail kernel where that saves a round of the persistent workgroups (conv_wino4.hip; the rounds are counted for
+  // the variant batch, so that a shard of a job takes the same path as the job)
+  int tail_w0 = 0, tail_nw = 0;
+  if (f4 && dil > 1) {
+    int w0 = 0, nw = 0;
+    const int full = wino4_tail_plan(as[0].Ncols, dil, wino4_nc(*pws[0]), &w0, &nw);
+    bool ok = full > 0;
+    for (int i = 0; i < n; ++i) ok = ok && pws[i]->wraw.p && as[i].Ncols == as[0].Ncols && !(g4.a[i].flags & (F_RES | F_ACC | F_DIV)) && pws[i]->Cin * pws[i]->K * 32 <= 160 * 1024;
+    if (ok) {
+      const long long G = device_cu_count(), bv = variant_batch(B);
+      long long per_b = 0, per_b_drop = 0;
+      for (int i = 0; i < n; ++i) { per_b += (long long)g4.a[i].ntn * g4.a[i].gy; per_b_drop += (long long)full * g4.a[i].gy; }
+      if ((per_b_drop * bv + G - 1) / G < (per_b * bv + G - 1) / G) {
+        total4 = 0;
+        for (int i = 0; i < n; ++i) { g4.a[i].ntn = full; total4 += (long long)full * g4.a[i].gy * B; g4.end[i] = (int)total4; }
+        tail_w0 = w0; tail_nw = nw;
+      }
+    }
+  }
   for (int i = n; i < 3; ++i) { g.end[i] = 0x7fffffff; g.k[i] = 3; }
   stats_add_conv(flops, n, f4 ? exec4 : exec_flops);
   int prof_idx = -1;
@@ -819,7 +845,11 @@ int launch_conv_wino_group(const PackedWino* const* pws, const ConvArgs* as, int
     prof_idx = prof_begin(st, d, flops);
   }
   int rc = SVOC_OK;
-  if (f4) rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), in_perm, out_perm, f44, total4, st);
+  if (f4) {
+    const float* wr[3]; int co[3];
+    for (int i = 0; i < 3; ++i) { wr[i] = pws[i]->wraw.f(); co[i] = pws[i]->Cout; }
+    rc = wino4_launch_group(g4, dil, wino4_nc(*pws[0]), in_perm, out_perm, f44, total4, st, wr, co, tail_w0, tail_nw, B);
+  }
   else if (WM == 4) rc = dil == 1 ? wino_launch_group<1, 4>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 4>(g, total, lds, st) : wino_launch_group<5, 4>(g, total, lds, st));
   else rc = dil == 1 ? wino_launch_group<1, 2>(g, total, lds, st) : (dil == 3 ? wino_launch_group<3, 2>(g, total, lds, st) : wino_launch_group<5, 2>(g, total, lds, st));
   prof_end(st, prof_idx);

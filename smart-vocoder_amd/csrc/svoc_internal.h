@@ -191,6 +191,7 @@ struct PackedWino {
   DevBuf wp4;                     // F(4,3) image (conv_wino4.hip), present when that form is enabled and the shape is eligible
   bool f44 = false;               // wp4 is in F(4,4) form (conv_wino4.h: k = 7 / 11 of the 128-row layout)
   DevBuf wp44;                    // k = 3 of the 128-row layout: second image in F(4,4) form (the merged accumulate launch, whose members share accumulators)
+  DevBuf wraw;                    // plain weights [Cout][Cin * K], weight norm applied: the dilated launches' row tails (conv_wino4.hip: conv_wino4_tail_kernel)
   int Cin = 0, Cout = 0, K = 0, nchunks = 0, mtiles = 0, slots = 0;
   double flops_per_col = 0;       // algorithmic 2*MAC of the convolution per output column
 };

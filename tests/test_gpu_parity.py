@@ -1022,6 +1022,33 @@ def test_generator_winograd_upsamplers_vs_oracle(M):
     check("generator F(4,2) upsamplers", y, ref, 5e-5, 1e-4)
 
 
+def test_generator_dilated_row_tails_vs_oracle(M):
+    """Round 6: a row of L outputs has D * ceil(L / 4D) windows of a dilated Winograd convolution; at L = 4096 / 16384 (T a power of two) the partial last
+    q block's D windows are alone in one more column tile per row (33 instead of 32).  Where dropping that tile saves a round of the persistent workgroups
+    the grouped launch stops at the last full tile and conv_wino4_tail_kernel computes the dropped windows' outputs in direct form (csrc/conv_wino4.hip).
+    A decoder with C = 128 / 64 stages at 8 x 1024 frames: both dilated launches of both stages take that path (four more small launches than with
+    SVOC_W4_TAIL=0 - counted), window-major hand-over included, and the waveform must match the oracle; 8 x 1000 frames (no such tile) must not take it."""
+    c = dict(initial_channel=32, resblock="1", rks=[3, 7, 11], rds=[[1, 3, 5]] * 3, ur=[4, 4], uic=256, uks=[8, 8], gin=0)
+    sd = sw.fill_state_dict(cases.generator_shapes(c), 7741, 1.0)
+    m = load(M.models.Generator(c["initial_channel"], c["resblock"], c["rks"], c["rds"], c["ur"], c["uic"], c["uks"], gin_channels=0), sd)
+    counts = {}
+    for Tn in (1024, 1000):
+        x = T(cases.rnd(7741 + Tn, "x", (8, 32, Tn), 1.0))
+        M.native.stats_reset()
+        y = m(x.cuda())
+        torch.cuda.synchronize()
+        counts[Tn] = M.native.stats_get()["other_launches"]
+        pick = [0, 7]
+        with torch.no_grad():
+            ref = O.generator(sdT(sd), x[pick], prefix="", resblock="1", resblock_kernel_sizes=c["rks"], resblock_dilation_sizes=c["rds"],
+                              upsample_rates=c["ur"], upsample_kernel_sizes=c["uks"])
+        check(f"generator row tails T{Tn}", y[pick], ref, 5e-5, 1e-4)
+        # the last columns of every row are the tail kernel's: compare them on their own
+        check(f"generator row tails T{Tn}, last 64 samples", y[pick][..., -64:], ref[..., -64:], 5e-5, 1e-4)
+    if not any(k.startswith("SVOC_") and k not in ("SVOC_LIB", "SVOC_VARIANT_JOBS") for k in os.environ):      # (a variant run may take other kernels)
+        assert counts[1024] - counts[1000] == 4, counts
+
+
 def test_generator_conv_pre_winograd_vs_oracle(M):
     """Round 6: conv_pre (k = 7, 192 -> 512 channels at iitp_base) runs on the F(4,4) Winograd kernel when nothing masks or conditions its input and the launch
     has half a tile per CU (csrc/engine.hip Generator::forward).  A Generator with iitp_base's conv_pre (192 -> 512) and ONE upsampler stage, at a batch that

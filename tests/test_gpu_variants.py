@@ -11,6 +11,8 @@ tests/test_gpu_parity.py::test_fallback_shapes).
   SVOC_WINO=0                    direct-form kernels instead of Winograd (kernel sizes other than 3 / 7 / 11, dilations other than 1 / 3 / 5)
   SVOC_WINO_F4=0                 Winograd F(2,3) kernels instead of F(4,3) / F(4,4) (odd row-block counts, unaligned rows, L % 4 != 0)
   SVOC_W4_C32=0                  C = 32 MRF stage on the fused direct-form ResBlock kernel instead of F(4,3) conv by conv (short inputs)
+  SVOC_W4_TAIL=0                 dilated Winograd rows keep their partial last tile instead of handing its windows to the direct-form tail launch (every length
+                                 whose last q block does not sit alone in a tile, or where dropping it saves no round of the persistent workgroups)
   SVOC_WN_SMALL_F25=0            short inputs: WN layers as two K-split convolutions instead of one launch per layer (wn_small.hip)
   SVOC_WN_SMALL_PP2=0            mid-size batches: six workgroups per 32-column tile (one row pair each) instead of three (fewer than 43 or more than 85 tiles)
   SVOC_WN_STACK=0                WN stacks one launch per layer instead of one persistent launch per stack (more 32-column tiles than CUs; conditioning input)
@@ -45,6 +47,7 @@ VARIANTS = {
     "no_winograd": ({"SVOC_WINO": "0"}, DEC),
     "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
+    "dilated_rows_keep_their_last_tile": ({"SVOC_W4_TAIL": "0"}, "test_generator_dilated_row_tails or test_c2_full_size or test_wn_mid_size"),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),
     "wn_one_launch_per_layer": ({"SVOC_WN_STACK": "0"}, WNS),
     "wn_short_inputs_one_launch_per_layer": ({"SVOC_WN_MESH": "0"}, "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_wn or test_coupling or test_flow"),
