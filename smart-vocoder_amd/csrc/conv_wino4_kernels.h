@@ -17,7 +17,7 @@
 // its predecessor, stored by the same transform item) that is X_{(r+2)%4}[q + t + (r+2)/4]: r = 0 goes into M0 (part of y0
 // only), r = 3 into M5 (part of y3 only), r = 1 / 2 into two accumulators of their own.  MFMAs per output and channel pair:
 // k=3: 1.5 (F(2,3): 2, direct 3), k=7: 4 (5, 7), k=11: 6.5 (8, 11).  Dilation D through the polyphase view (as conv_wino.hip):
-// the four outputs of a window are n, n + D, n + 2D, n + 3D; a tile holds (32 / D) * D windows.
+// the four outputs of a window are n, n + D, n + 2D, n + 3D; a tile holds 32 consecutive windows w = D b + ph (conv_wino4.h: W4Geo::NWT).
 // fp32 throughout; the transforms scale by up to 8, measured waveform error below (tests assert <= 1e-4 relative RMS).
 //
 // Kernel form: wave-specialised persistent workgroups, ONE per CU (eight accumulator tiles = 128 registers per consumer):
