@@ -52,3 +52,6 @@ ls -la $O
 ( cd $R && python tools/latency_probe.py 2x512 3x512 4x512 5x512 6x512 8x512 ) > $O/${TAG}_latency_mid_size.txt 2>&1
 ( cd $R && python -m pytest tests/test_gpu_parity.py -q -m gpu -k "give_up or persistent" 2>&1 | tail -3 ) > $O/${TAG}_give_up_tests.txt
 ls -la $O
+# round 6: one replayed 4 x 512 step kernel by kernel (the mid-size regime: short-input WN chain, the dilated rows' tail launches)
+( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt4 --output-format csv -- python $R/tools/small_shape_run.py 4 512 20 > /dev/null 2>&1; python $R/tools/timeline.py /tmp/kt4 400 > $O/${TAG}_kernel_timeline_4x512.txt 2>&1 )
+ls -la $O
