@@ -45,6 +45,7 @@ struct WnSmallArgs {
   const float* wpf; const float* bias1;                // in_layer i: F(2,5) image (wn_fused.hip), bias in paired tile order
   const float* wrs;                                    // res_skip i-1: 16x16x4 image + natural-order bias (pack_wn_rs16)
   int T; int skip_first;                               // skip_first: res_skip i-1 is the stack's first one (out = ..., not +=)
+  long long* dbg;                                      // optional [workgroup][16] wall-clock stamps of thread 0 (tools/wn_small_timeline.py)
 };
 
 template <int PP>
@@ -69,6 +70,10 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
   const int t0 = blockIdx.x * 32;
   const int T = p.T;
   const bool has_prev = p.ap != nullptr;
+  const bool stamped = p.dbg != nullptr && tid == 0;
+  const long long wg_ = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) { if (stamped) p.dbg[wg_ * 16 + i] = (long long)__builtin_amdgcn_s_memrealtime(); };
+  stamp(0);
 
   // ---- the A operands of the previous layer's res_skip for this wave (12 + 12 sixteen-byte loads) are requested first: their L2
   // round trips run under the staging of the tiles (requested inside the GEMM loops they cost 12 exposed latencies: +7 us per layer)
@@ -142,6 +147,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
   }
   BI[tid] = bias_v;                                          // (BR directly behind BI)
   __syncthreads();
+  stamp(1);
 
   if (has_prev) {
     const float* rsbias = BR;                               // natural order: [0, H) residual part, [H, 2H) skip part
@@ -209,9 +215,11 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
     }
     __syncthreads();
   }
+  stamp(2);
 
 #pragma unroll 1
   for (int pi = pi0; pi < pi0 + PP; ++pi) {
+  const int sb = 3 + 4 * (pi - pi0);
   if (pi > pi0) __syncthreads();                             // the reduction of the pair before is done with the area the planes live in
   // ---- input transform of x_i (wn_fused.hip): window q of channel c reads tile columns 2q + 2 .. 2q + 7
 #pragma unroll
@@ -231,6 +239,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
     o[5 * WNS_PLANE] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
   }
   __syncthreads();
+  stamp(sb);
 
   // ---- in_layer of pair pi, K split over the twelve waves: wave w = k-steps 4 w .. 4 w + 3 of the 48 (channels 16 w .. 16 w + 15),
   // all four 16-row tiles and six products: 96 MFMAs from wn_fused.hip's image [pair][half][k-step 24][product][lane][tile]
@@ -288,6 +297,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
     rdb(std::integral_constant<int, 0>{}); rdb(std::integral_constant<int, 1>{});
     wino_static_for<0, NST>(step);
   }
+  stamp(sb + 1);
   __syncthreads();                                           // every wave is done with the planes: the reduction area takes their place
   // ---- output transform of the partial sums -> RED[wave][j][lane], j = 8 rt + 2 i + o (rt: tanh lo, tanh hi, sigmoid lo, sigmoid hi)
   {
@@ -303,6 +313,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
       }
   }
   __syncthreads();
+  stamp(sb + 2);
   // ---- reduction over the twelve K parts + bias + gate: waves 0..7 take two (tanh, sigmoid) pairs per lane each
   if (wave < 8) {
     const float* gb = p.gadd ? p.gadd + (long long)b * p.gadd_bs : nullptr;
@@ -329,6 +340,7 @@ __global__ void __launch_bounds__(768) wn_small_f25_kernel(const WnSmallArgs p) 
       if (t < T) p.ao[(long long)b * p.ao_bs + (long long)chn * p.ao_ld + t] = gate_tanh_sigmoid(vA, vB);
     }
   }
+  stamp(sb + 3);
   }
 }
 
@@ -407,6 +419,7 @@ int launch_wn_small_layer(const PackedConv& in_l, const float* wpf, const float*
   a.gadd = gadd; a.gadd_bs = gadd_bs; a.gadd_ld = gadd_ld; a.gadd_ts = gadd_ts;
   a.wpf = wpf; a.bias1 = in_l.bias.f(); a.wrs = wrs;
   a.T = T; a.skip_first = skip_first;
+  a.dbg = debug_stamp_buffer();
   // algorithmic work: the in_layer and, from the second layer on, the previous layer's 1 x 1; executed: 3/5 of the in_layer, the residual
   // half of the 1 x 1 six times on 48 of 32 columns, its skip half once
   const double fin = in_l.flops_per_col * (double)B * (double)T, frs = ap ? rs_flops_per_col * (double)B * (double)T : 0.0;
