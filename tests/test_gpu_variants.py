@@ -48,6 +48,9 @@ VARIANTS = {
     "winograd_f23": ({"SVOC_WINO_F4": "0"}, DEC),
     "c32_fused_direct": ({"SVOC_W4_C32": "0"}, DEC),
     "dilated_rows_keep_their_last_tile": ({"SVOC_W4_TAIL": "0"}, "test_generator_dilated_row_tails or test_c2_full_size or test_wn_mid_size"),
+    # the merged accumulate launch refuses (fewer than 1000 tiles) where the grouped ones still run: the last dilated launch of a stage then writes its rows in
+    # natural order, and so does its tail launch (the window-major position is the other branch of conv_wino4_tail_kernel's store)
+    "row_tails_in_natural_order": ({"SVOC_MRF_MIN_TILES": "1000"}, "test_generator_dilated_row_tails"),
     "wn_direct_form": ({"SVOC_WN_F25": "0"}, WNS),
     "wn_one_launch_per_layer": ({"SVOC_WN_STACK": "0"}, WNS),
     "wn_short_inputs_one_launch_per_layer": ({"SVOC_WN_MESH": "0"}, "test_infer_vs_reference_golden or test_small_shape_graph_replay or test_wn or test_coupling or test_flow"),
