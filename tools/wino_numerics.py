@@ -53,7 +53,9 @@ def check(m, r, pts, N=200000, seed=0):
     return e64, rms(y32 - ref) / rms(ref), rms(dir32 - ref) / rms(ref)
 for name, m, r, pts in (("F(2,3)", 2, 3, [0, 1, -1]), ("F(4,3)", 4, 3, [0, 1, -1, 2, -2]), ("F(2,5)", 2, 5, [0, 1, -1, 2, -2]),
                         ("F(2,5) halves", 2, 5, [0, 1, -1, F(1, 2), F(-1, 2)]), ("F(4,5)", 4, 5, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)]),
-                        ("F(6,3)", 6, 3, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)])):
+                        ("F(6,3)", 6, 3, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)]),
+                        # round 6: the k = 7 convolutions as ONE group (10 products per four outputs instead of two F(4,4) groups' 14) - the best of five point sets tried
+                        ("F(4,4)", 4, 4, [0, 1, -1, 2, -2, F(1, 2)]), ("F(4,7)", 4, 7, [0, 1, -1, F(1, 2), F(-1, 2), 2, -2, F(3, 4), F(-3, 4)])):
     e64, w, dr = check(m, r, pts)
     print(f"{name:14s} exactness (f64 max err) {e64:.1e}   fp32 rel-RMS: winograd {w:.2e}   direct {dr:.2e}   ratio {w / dr:.1f}")
 
@@ -87,6 +89,7 @@ def conv_level(m, r, pts, C=192, Co=64, T=512, seed=1):
 
 print("\none convolution, C = 192 input channels, 64 output rows, 512 columns (fp32 transforms / products / accumulation):")
 for name, m, r, pts in (("F(4,3)", 4, 3, [0, 1, -1, 2, -2]), ("F(2,5)", 2, 5, [0, 1, -1, 2, -2]),
-                        ("F(4,5)", 4, 5, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)]), ("F(6,3)", 6, 3, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)])):
+                        ("F(4,5)", 4, 5, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)]), ("F(6,3)", 6, 3, [0, 1, -1, 2, -2, F(1, 2), F(-1, 2)]),
+                        ("F(4,4)", 4, 4, [0, 1, -1, 2, -2, F(1, 2)]), ("F(4,7)", 4, 7, [0, 1, -1, F(1, 2), F(-1, 2), 2, -2, F(3, 4), F(-3, 4)])):
     w_, d_ = conv_level(m, r, pts)
     print(f"{name:14s} fp32 rel-RMS: winograd {w_:.2e}   direct {d_:.2e}   ratio {w_ / d_:.1f}")
