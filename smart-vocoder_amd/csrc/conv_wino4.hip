@@ -76,9 +76,8 @@ int pack_wino4_image(float* wp4, int Cin, int Cout, int K, bool f44, const float
 // partial and - at T a power of two - its D windows are the ONLY occupants of one more column tile per row: 33 tiles instead of 32 at 16 x 512's
 // first stage, 13 rounds of the 256 persistent workgroups instead of 12 for a dozen valid outputs per row.  Where dropping that tile saves a round
 // (wino4_tail_plan) the launch stops at the last full tile and this kernel computes the dropped windows' outputs in direct form from the plain weights
-// (PackedWino::wraw): one workgroup per output column (batch element, column, member): the column's Cin x K inputs (leaky-relu applied, zero outside the
-// row) are parked in LDS once, then every wave takes output channels in turn - the lanes split the Cin x K products of the dot product, coalesced over
-// the weight row, and a butterfly adds the 64 partial sums.  Window-major rows (out_perm) receive the value where the main launch would have put it.
+// (PackedWino::wraw), one workgroup per work item (w4_tail_item below).  Window-major rows (out_perm) receive the value where the main launch would have put
+// it.  Measured: profiles/r06_dilated_row_tails.txt (4 x 512 8.02 -> 7.86 ms; nothing at 16 x 512, which runs at the power cap).
 struct W4TailMember { const float* x; const float* w; const float* bias; float* y; long long x_bs, y_bs; int x_ld, y_ld, Cin, Cout, K; };
 // nv valid output columns per row: natural column n[v], position in the output row ypos[v]; pairs = (batch element, v), batch-major
 struct W4Tail { W4TailMember m[3]; int L, D, nv, npairs; float slope; int n[32]; int ypos[32]; };
