@@ -9,9 +9,10 @@ namespace svoc {
 // ------------------------------------------------------------------------------------------------ consumer side
 // One member of one tile: its stages' MFMA streams into the shared accumulators (conv_wino4.hip's stream: fragment reads two steps
 // ahead at immediate LDS offsets, weights through buffer loads with SGPR slot offsets, one or three slots ahead).
-template <class Geo, int NACC, int NPS>
+// DBG (stamped instantiations, tools/pair_timeline.py): cyc[0] += cycles waited at the stage barriers, cyc[1] += cycles of the MFMA streams
+template <class Geo, int NACC, int NPS, bool DBG = false>
 __device__ __forceinline__ void acc3_consume(const WinoArgs& p, f32x16 (&M)[NACC], const unsigned plbase, const int PLFMAX_, const int wt, int& s_,
-                                            const unsigned wlane, const unsigned lanefrag) {
+                                            const unsigned wlane, const unsigned lanefrag, long long* const cyc = nullptr) {
   constexpr int PQ = Geo::PQ, WSLOTS = Geo::WSLOTS, PLANE = Geo::PLANE, NSTEP = Geo::NSTEP, CPS = Geo::CPS, HALVES = Geo::HALVES, KGS = Geo::KGS;
   constexpr int NSET = Geo::NSET, PD = Geo::PD;
   const int nst = p.nchunks * HALVES / CPS;
@@ -65,7 +66,10 @@ __device__ __forceinline__ void acc3_consume(const WinoArgs& p, f32x16 (&M)[NACC
   };
   auto stage = [&](int st_, auto par, auto hf) {
     constexpr int HF = decltype(hf)::value;
+    long long c0 = 0, c1 = 0;
+    if constexpr (DBG) c0 = (long long)__builtin_readcyclecounter();
     __syncthreads();                                       // B_s: plane set s & 1 is complete, the other one may be overwritten
+    if constexpr (DBG) c1 = (long long)__builtin_readcyclecounter();
     const unsigned baddr = plbase + (unsigned)(s_ * PLFMAX_) * 4u + lanefrag;
     s_ = s_ + 1 == NPS ? 0 : s_ + 1;
     constexpr auto c0_ = std::integral_constant<int, 0>{};
@@ -84,6 +88,7 @@ __device__ __forceinline__ void acc3_consume(const WinoArgs& p, f32x16 (&M)[NACC
       const int wnext = st_ + 1 < nst ? wa + 2 * WSLOTS * 4096 : -1;
       mfma_chunk(baddr, wa + WSLOTS * 4096, wnext, par, std::integral_constant<int, CPS - 1>{}, c0_);
     }
+    if constexpr (DBG) { cyc[0] += c1 - c0; cyc[1] += (long long)__builtin_readcyclecounter() - c1; }
   };
   if constexpr (HALVES > 1) {
     constexpr int U = (HALVES * WSLOTS) % NSET == 0 ? HALVES : 2 * HALVES;

@@ -31,7 +31,7 @@ struct PairMember {
   const float* wp2; const float* bias2;                     // c2
   unsigned eflags; float div;                               // accumulate form: F_ACC (y += ...) and F_DIV (... / div) of this member's epilogue
 };
-struct PairGroup { PairMember m[3]; int end[3]; int L; int B; int xcd; unsigned flags; float slope; };   // members k = 11, 7, 3; end[i] = first tile id behind member i
+struct PairGroup { PairMember m[3]; int end[3]; int L; int B; int xcd; unsigned flags; float slope; long long* dbg; };      // dbg: stamped build only (tools/pair_timeline.py)   // members k = 11, 7, 3; end[i] = first tile id behind member i
 // NRT = 1: C = 32 (1 x 4 consumers, 128 windows per tile); NRT = 2: C = 64 (2 x 2 consumers, 64 windows per tile, two 32-channel chunks)
 
 // NW2CAP > 0: keep at most that many c2 windows per tile (the accumulate form gives the three members ONE tile space: the k = 11 member's count)
@@ -59,7 +59,7 @@ struct PairGeo {
   static constexpr int LDS_FLOATS = MID_FLOATS + 2 * PLFMAX;
 };
 
-template <int K, int D1, int NRT, bool F44>
+template <int K, int D1, int NRT, bool F44, bool DBG = false>
 __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGroup& g, const int first, const int vend, const int blk, const int G_) {
   using PG = PairGeo<K, D1, NRT, F44>;
   using G1 = typename PG::G1;
@@ -99,6 +99,16 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
     lead_ = f0 - xs_;
   };
   int s_ = 0;                                               // plane set of the next stage (both sides count stages alike)
+  // stamped build: [dilation 1 / 3 / 5][member k = 11 / 7 / 3][workgroup][16] behind row 8192 of the stamp buffer
+  long long* const drow = DBG ? g.dbg + (8192LL + ((D1 == 1 ? 0 : (D1 == 3 ? 1 : 2)) * 3 + (K == 11 ? 0 : (K == 7 ? 1 : 2))) * 1024 + blockIdx.x) * 16 : nullptr;
+  long long pc_all0 = 0, pc_bar = 0;
+  if constexpr (DBG) pc_all0 = (long long)__builtin_readcyclecounter();
+  auto pbarrier = [&]() {
+    long long b0 = 0;
+    if constexpr (DBG) b0 = (long long)__builtin_readcyclecounter();
+    __syncthreads();
+    if constexpr (DBG) pc_bar += (long long)__builtin_readcyclecounter() - b0;
+  };
 
   if (wave >= 4) {
     // ================================================================= producers
@@ -201,10 +211,10 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
             w4_transform_window<G1>(pb + t1dst[u], D1 == 1 ? r - G1::LEAD : r);
           }
         }
-        __syncthreads();                                     // B_s: plane set complete
+        pbarrier();                                          // B_s: plane set complete
         s_ ^= 1;
       }
-      __syncthreads();                                       // X: the consumers have written the rows of c2's first stage into the intermediate tile
+      pbarrier();                                            // X: the consumers have written the rows of c2's first stage into the intermediate tile
       // ---------------- phase B: c2's four stages from the intermediate tile; the next tile's first raw rows are requested meanwhile
       if (more) issue(bzn, xs1n, 0);
       for (int ch = 0; ch < 4; ++ch) {
@@ -216,11 +226,12 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
             w4_transform_window<G2>(pb + t2dst[u], mrow + t2src[u]);
           }
         }
-        __syncthreads();
+        pbarrier();
         s_ ^= 1;
       }
       bz = bzn; n2 = n2n; m0 = m0n; off2 = off2n; xs1 = xs1n; lead1 = lead1n;
     }
+    if constexpr (DBG) if (tid == 256) { drow[8] = (long long)__builtin_readcyclecounter() - pc_all0; drow[9] = pc_bar; }
     return;
   }
 
@@ -248,12 +259,16 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
 #pragma unroll
     for (int r = 0; r < 4; r += 2) w4_output_transform2<G1, NACC>(M, 4 * Q + r, vo[r], vo[r + 1]);
   };
+  long long cyA[2] = {0, 0}, cyB[2] = {0, 0}, cy_epiA = 0, cy_epiB = 0, wall0 = 0;
+  if constexpr (DBG) wall0 = (long long)wall_clock64();
   for (int ti = 0; ti < my_tiles; ++ti) {
     int bz, n2, m0, off2;
     locate(v0 + ti * G_, bz, n2, m0, off2);
     // ---------------- phase A: c1 into the accumulators
     init_bias(pm.bias1);
-    acc3_consume<G1, NACC, 2>(p1, M, plbase, PLFMAX, wt1, s_, wlane, (unsigned)(hi * G1::PQ + uu) * 4u);
+    acc3_consume<G1, NACC, 2, DBG>(p1, M, plbase, PLFMAX, wt1, s_, wlane, (unsigned)(hi * G1::PQ + uu) * 4u, cyA);
+    long long ce0 = 0;
+    if constexpr (DBG) ce0 = (long long)__builtin_readcyclecounter();
     // ---- epilogue A: lrelu(c1) -> the intermediate tile, zero outside [0, L).  Window uu = q block uu / D1, phase uu % D1: its four
     // outputs are D1 columns apart
     {
@@ -292,19 +307,29 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
       quarter(std::integral_constant<int, 2>{});
       quarter(std::integral_constant<int, 3>{});
     }
+    if constexpr (DBG) cy_epiA += (long long)__builtin_readcyclecounter() - ce0;
     // ---------------- phase B: c2, then + x and store
-    init_bias(pm.bias2);
-    acc3_consume<G2, NACC, 2>(p2, M, plbase, PLFMAX, wt2, s_, wlane, (unsigned)(hi * G2::PQ + uu) * 4u);
+    // The residual rows of the tile are requested HERE, ahead of c2's MFMA streams (round 6, tools/pair_timeline.py: requested at the head of the epilogue their
+    // L2 round trip was exposed - the epilogue took 5.1 - 7.0 k cycles of a 28 - 63 k cycle tile at C = 32): all sixteen where the registers allow (one row tile per
+    // workgroup: 164 + 64), the first eight with two row tiles (201 + 32), the rest at the head of the epilogue as before.
+    constexpr int NEARLY = NRT == 1 ? 16 : 8;
     const int ne = n2 + 4 * uu;
-    if (uu < NW2 && ne < L) {
-      char* const ybase = reinterpret_cast<char*>(pm.y + (long long)bz * pm.y_bs + (long long)(32 * rt + 4 * hi) * pm.y_ld + ne);
-      const char* const rbase = reinterpret_cast<const char*>(pm.x + (long long)bz * pm.x_bs + (long long)(32 * rt + 4 * hi) * pm.x_ld + ne);
-      const size_t ylb = (size_t)pm.y_ld * 4, rlb = (size_t)pm.x_ld * 4;
-      // the sixteen residual rows are requested in ONE batch ahead of the first output transform (round 6): a quarter at a time - four loads, transform, add,
-      // store, the next four loads - the epilogue paid four L2 round trips in a row (the compiler keeps the source order across the stores)
-      float4 rvall[16];
+    const bool lane_ok = uu < NW2 && ne < L;
+    const char* const rbase = reinterpret_cast<const char*>(pm.x + (long long)bz * pm.x_bs + (long long)(32 * rt + 4 * hi) * pm.x_ld + (lane_ok ? ne : 0));
+    const size_t rlb = (size_t)pm.x_ld * 4;
+    float4 rvall[16];
+    init_bias(pm.bias2);                                     // (first: its wait for the sixteen bias words would otherwise wait for the rows requested below as well)
+    if (lane_ok) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rvall[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (r >> 2) + (r & 3)) * rlb);
+      for (int r = 0; r < NEARLY; ++r) rvall[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (r >> 2) + (r & 3)) * rlb);
+    }
+    acc3_consume<G2, NACC, 2, DBG>(p2, M, plbase, PLFMAX, wt2, s_, wlane, (unsigned)(hi * G2::PQ + uu) * 4u, cyB);
+    if constexpr (DBG) ce0 = (long long)__builtin_readcyclecounter();
+    if (lane_ok) {
+      char* const ybase = reinterpret_cast<char*>(pm.y + (long long)bz * pm.y_bs + (long long)(32 * rt + 4 * hi) * pm.y_ld + ne);
+      const size_t ylb = (size_t)pm.y_ld * 4;
+#pragma unroll
+      for (int r = NEARLY; r < 16; ++r) rvall[r] = *reinterpret_cast<const float4*>(rbase + (size_t)(8 * (r >> 2) + (r & 3)) * rlb);
       auto quarter = [&](auto q_c) {
         constexpr int Q = decltype(q_c)::value;
         float4 vo[4];
@@ -320,17 +345,23 @@ __device__ __forceinline__ void pair_member(const PairMember& pm, const PairGrou
       quarter(std::integral_constant<int, 2>{});
       quarter(std::integral_constant<int, 3>{});
     }
+    if constexpr (DBG) cy_epiB += (long long)__builtin_readcyclecounter() - ce0;
+  }
+  if constexpr (DBG) if (tid == 0) {      // [0] tiles, [1] total cycles, c1: [2] barrier waits [3] MFMA streams [4] epilogue -> LDS, c2: [5] [6] [7] epilogue; [8] [9] producer wave 0: total, barrier waits
+    drow[0] = my_tiles; drow[1] = (long long)__builtin_readcyclecounter() - pc_all0;
+    drow[2] = cyA[0]; drow[3] = cyA[1]; drow[4] = cy_epiA; drow[5] = cyB[0]; drow[6] = cyB[1]; drow[7] = cy_epiB;
+    drow[10] = wall0; drow[11] = (long long)wall_clock64();
   }
 }
 
-template <int D1, int NRT, bool F44>
+template <int D1, int NRT, bool F44, bool DBG = false>
 __global__ void __launch_bounds__(512, 2) conv_wino4_pair_kernel(const PairGroup g) {
   const int b = blockIdx.x, G_ = gridDim.x;
-  pair_member<11, D1, NRT, F44>(g.m[0], g, 0, g.end[0], b, G_);
+  pair_member<11, D1, NRT, F44, DBG>(g.m[0], g, 0, g.end[0], b, G_);
   __syncthreads();
-  pair_member<7, D1, NRT, F44>(g.m[1], g, g.end[0], g.end[1], b, G_);
+  pair_member<7, D1, NRT, F44, DBG>(g.m[1], g, g.end[0], g.end[1], b, G_);
   __syncthreads();
-  pair_member<3, D1, NRT, F44>(g.m[2], g, g.end[1], g.end[2], b, G_);
+  pair_member<3, D1, NRT, F44, DBG>(g.m[2], g, g.end[1], g.end[2], b, G_);
 }
 
 // ------------------------------------------------------------------------------------------------ the accumulate form (round 5)
@@ -658,9 +689,17 @@ static int pair_launch_d(PairGroup& g, hipStream_t st) {
     if (total > 0x7fffffffLL) return 1;
     g.end[i] = (int)total;
   }
+  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
+  if (g.dbg && (D1 == 1 || (D1 == 3 && NRT == 1))) {        // stamped build (tools/pair_timeline.py): the launches the model takes
+    if constexpr (D1 == 1 || (D1 == 3 && NRT == 1)) {
+      auto kern = conv_wino4_pair_kernel<D1, NRT, F44, true>;
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, st, g);
+      return SVOC_OK;
+    }
+  }
   auto kern = conv_wino4_pair_kernel<D1, NRT, F44>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  const unsigned grid = (unsigned)std::min<long long>(total, (long long)device_cu_count());
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, st, g);
   return SVOC_OK;
 }
@@ -709,6 +748,7 @@ int launch_wino4_pair(const PackedWino* const* pw1, const PackedWino* const* pw2
   if (wino4_pair_tiles(C, L, B, D1) > 0x7fffffffLL) return 1;           // an upper bound of pair_launch_d's total (the k = 11 member has the narrowest tiles)
   g.L = L; g.B = B; g.xcd = xcd_mapping_enabled(); g.slope = slope;
   g.flags = 0u;
+  g.dbg = debug_stamp_buffer();
   stats_add_conv(flops, 6, exec);
   int prof_idx = -1;
   if (prof_enabled()) {
