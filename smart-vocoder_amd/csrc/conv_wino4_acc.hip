@@ -199,7 +199,9 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
 // the F(4,4) form there is room for the two sets of twelve registers (254 registers, 0-2 spilled; with F(4,3)'s eight the same code
 // spilled 14-19 and gained nothing): accumulate launches 772 / 1666 / 1030 / 776 -> 777 / 1650 / 1004 / 734 us at C = 256 / 128 / 64 / 32,
 // 16x512 step 26.49 -> 26.34 ms (profiles/r04_accumulate_pipelined_residuals_{on,off}.txt).  On with F44, off without.
-template <int NRT, int PERM, bool F44 = false, bool PIPE = false>
+// DBG: stamped instantiation (tools/acc3_timeline.py): consumer wave 0's cycles per member (barrier waits, MFMA streams) and in the epilogue, [workgroup][16] behind
+// row 20000 of the stamp buffer
+template <int NRT, int PERM, bool F44 = false, bool PIPE = false, bool DBG = false>
 __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 g) {
   using AG = Acc3Geo<NRT, PERM, F44>;
   using G3 = typename AG::G3;
@@ -261,6 +263,8 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
   unsigned yo4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) yo4[i] = (unsigned)((4 * hi + i) * p3.y_ld + 4 * uu) * 4u;
+  long long cy3[2] = {0, 0}, cy7[2] = {0, 0}, cy11[2] = {0, 0}, cy_epi = 0, cy_all0 = 0, wall0 = 0;
+  if constexpr (DBG) { cy_all0 = (long long)__builtin_readcyclecounter(); wall0 = (long long)wall_clock64(); }
   for (int ti = 0; ti < my_tiles; ++ti) {
     int w0, bz, by;
     locate(v0 + ti * stride, w0, bz, by);
@@ -280,8 +284,8 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
           M[q][i] = q == 1 ? (b3[r] + b7[r]) + b11[r] : 0.f;
         }
     }
-    acc3_consume<G3, NACC, AG::NPS>(p3, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p3.nchunks * G3::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G3::PQ + uu) * 4u);
-    acc3_consume<G7, NACC, AG::NPS>(p7, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p7.nchunks * G7::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G7::PQ + uu) * 4u);
+    acc3_consume<G3, NACC, AG::NPS, DBG>(p3, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p3.nchunks * G3::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G3::PQ + uu) * 4u, cy3);
+    acc3_consume<G7, NACC, AG::NPS, DBG>(p7, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p7.nchunks * G7::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G7::PQ + uu) * 4u, cy7);
     const bool lane_ok = row_ok && ne < L;
     const long long roff3 = (long long)bz * p3.res_bs + (long long)(mt * 32 + 4 * hi) * p3.res_ld + ne;
     const long long roff7 = (long long)bz * p7.res_bs + (long long)(mt * 32 + 4 * hi) * p7.res_ld + ne;
@@ -296,7 +300,9 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
     };
     float4 ra[12], rb[12];
     if constexpr (PIPE) if (lane_ok) rq(ra, 0);
-    acc3_consume<G11, NACC, AG::NPS>(p11, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p11.nchunks * G11::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G11::PQ + uu) * 4u);
+    acc3_consume<G11, NACC, AG::NPS, DBG>(p11, M, plbase, AG::PLFMAX, __builtin_amdgcn_readfirstlane(mtc * p11.nchunks * G11::WSLOTS * 4096), s_, wlane, (unsigned)(hi * G11::PQ + uu) * 4u, cy11);
+    long long ce0 = 0;
+    if constexpr (DBG) ce0 = (long long)__builtin_readcyclecounter();
     // ---- output transform + epilogue: y = (A^T M + res_3 + res_7 + res_11) / div, sixteen-byte stores
     if (lane_ok) {
       char* const ybase = reinterpret_cast<char*>(p3.y + (long long)bz * p3.y_bs + (long long)(mt * 32) * p3.y_ld + n0);
@@ -327,6 +333,12 @@ __global__ void __launch_bounds__(512, 2) conv_wino4_acc3_kernel(const WinoAcc3 
       quarter(std::integral_constant<int, 2>{}, ra, rb);
       quarter(std::integral_constant<int, 3>{}, rb, ra);
     }
+    if constexpr (DBG) cy_epi += (long long)__builtin_readcyclecounter() - ce0;
+  }
+  if constexpr (DBG) if (tid == 0) {
+    long long* d = p3.dbg + (20000LL + blockIdx.x) * 16;
+    d[0] = my_tiles; d[1] = (long long)__builtin_readcyclecounter() - cy_all0; d[2] = cy3[0]; d[3] = cy3[1]; d[4] = cy7[0]; d[5] = cy7[1]; d[6] = cy11[0]; d[7] = cy11[1];
+    d[8] = cy_epi; d[10] = wall0; d[11] = (long long)wall_clock64();
   }
 }
 
@@ -335,9 +347,17 @@ template <int NRT, int PERM, bool F44 = false>
 static int acc3_launch_n(const WinoAcc3& g, hipStream_t st) {
   using AG = Acc3Geo<NRT, PERM, F44>;
   static_assert(AG::LDS_BYTES <= 160 * 1024, "tile does not fit");
+  const unsigned grid = (unsigned)std::min<long long>(g.total, (long long)device_cu_count());
+  if constexpr (PERM == 5 && NRT >= 2) {                      // stamped build: the launches the model takes at C >= 64
+    if (g.a[0].dbg) {
+      auto kern = conv_wino4_acc3_kernel<NRT, PERM, F44, F44, true>;
+      SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)AG::LDS_BYTES, st, g);
+      return SVOC_OK;
+    }
+  }
   auto kern = conv_wino4_acc3_kernel<NRT, PERM, F44, F44>;
   SVOC_TRY(ensure_max_dyn_lds((const void*)kern));
-  const unsigned grid = (unsigned)std::min<long long>(g.total, (long long)device_cu_count());
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)AG::LDS_BYTES, st, g);
   return SVOC_OK;
 }
