@@ -139,6 +139,32 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
     tdst[u] = row * PQ + e;
     asm volatile("" : "+v"(tsrc[u]), "+v"(tdst[u]));       // kept in registers over the member's stages, not re-computed at each (conv_wino4_kernels.h)
   }
+  // byte offsets of this lane's sixteen-byte groups inside a stage's rows: the same for every stage of the member (round 6, tools/acc3_timeline.py: acc3_issue
+  // re-derived them - two divisions and a clamp per group - at EVERY stage, ~100 producer instructions per stage at one instruction per ~100 cycles)
+  unsigned voff[P::NV];
+  {
+    if constexpr (PERM > 0) {
+      const int pnblk_row = (L + 4 * PERM - 1) / (4 * PERM);
+      const int bf = (xs + 4 * PERM) / (4 * PERM) - 1;
+#pragma unroll
+      for (int u = 0; u < SPWP; ++u) {
+        const int it = min(l_ + 64 * u, NGWP - 1);
+        const int row = RPW * pw_ + it / Geo::PNG, g = it % Geo::PNG;
+        int bb = bf + g / PERM;
+        if (!interior) bb = min(max(bb, 0), pnblk_row - 1);
+        voff[u] = (unsigned)(row * p.x_ld + 4 * (PERM * bb + g % PERM)) * 4u;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < SPW; ++u) {
+        const int it = min(l_ + 64 * u, NGW - 1);
+        const int row = RPW * pw_ + it / R4, tg = xs + 4 * (it % R4);
+        voff[u] = (unsigned)(row * p.x_ld + ((interior || (tg >= 0 && tg + 3 < L)) ? tg : 0)) * 4u;
+      }
+    }
+  }
+  const float* const xb_ = p.x + (long long)bz * p.x_bs;
+  const int sstep = P::KS * p.x_ld * 4;
   for (int ch = 0; ch < nst; ++ch) {
     // ---- publish own rows
     if constexpr (PERM > 0) {
@@ -177,8 +203,11 @@ __device__ __forceinline__ void acc3_produce(const WinoArgs& p, float4 (&v)[Acc3
       }
     }
     // ---- request the next stage's raw rows
-    if (ch + 1 < nst) acc3_issue<Geo>(v, p, bz, xs, ch + 1, lane, pw_);
-    else next();
+    if (ch + 1 < nst) {
+      const int so = (ch + 1) * sstep;
+#pragma unroll
+      for (int u = 0; u < (PERM > 0 ? SPWP : SPW); ++u) v[u] = w4_load16(xb_, voff[u], so);
+    } else next();
     // ---- transform own rows into plane set s mod NPS (s_ holds that index; it wraps here)
     float* const pb = pl + (s_ & 0xff) * PLFMAX_;
 #pragma unroll

@@ -433,6 +433,17 @@ __device__ __forceinline__ void pairacc_produce(const PairMember& pm, const Pair
     const int it = min(l_ + 64 * u, NGW - 1);
     rdst[u] = raw + (RPW * pw_ + it / R4) * RAW1 + 4 * (it % R4);
   }
+  // byte offsets of this lane's sixteen-byte groups inside a stage's rows: the same for the member's four stages (pairacc_issue re-derives them per call; as in
+  // conv_wino4_acc.hip that was ~50 producer instructions per stage)
+  unsigned voff[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {
+    const int it = min(l_ + 64 * u, NGW - 1);
+    const int row = RPW * pw_ + it / R4, tg = xs1 + 4 * (it % R4);
+    voff[u] = (unsigned)(row * pm.x_ld + ((interior || (tg >= 0 && tg + 3 < L)) ? tg : 0)) * 4u;
+  }
+  const float* const xb_ = pm.x + (long long)bz * pm.x_bs;
+  const int sstep = KS * pm.x_ld * 4;
   int t1off[TPW1], t1dst[TPW1];
 #pragma unroll
   for (int u = 0; u < TPW1; ++u) {
@@ -457,7 +468,11 @@ __device__ __forceinline__ void pairacc_produce(const PairMember& pm, const Pair
         *reinterpret_cast<float4*>(rdst[u]) = q;
       }
     }
-    if (ch + 1 < 4) pairacc_issue<T>(v, pm, L, bz, xs1, ch + 1, lane, pw_);
+    if (ch + 1 < 4) {
+      const int so = (ch + 1) * sstep;
+#pragma unroll
+      for (int u = 0; u < SPW; ++u) v[u] = w4_load16(xb_, voff[u], so);
+    }
     float* const pb = pl + s_ * PLFMAX;
 #pragma unroll
     for (int u = 0; u < TPW1; ++u) {
@@ -569,7 +584,8 @@ __device__ __forceinline__ void pairacc_consume(const PairMember& pm, const Pair
     const float dv = pm.div, rc = 1.0f / dv;
     auto dv1 = [&](float x) { const float q = x * rc; return __builtin_fmaf(__builtin_fmaf(-q, dv, x), rc, q); };      // x / div (conv_wino4_kernels.h)
     // the residual rows (and, from the second member on, what this lane stored one member earlier) are requested for TWO quarters at a time, ahead of the
-    // first of their output transforms (round 6: a quarter at a time the epilogue paid four round trips in a row; all four at once would not fit the registers)
+    // first of their output transforms (round 6: a quarter at a time the epilogue paid four round trips in a row; all four at once would not fit the registers;
+    // the first two requested ahead of c2's MFMA streams, as the pair kernel does: 234 -> 253 registers, launch 1149 -> 1146 us - not kept)
     auto half = [&](auto h_c) {
       constexpr int HQ = decltype(h_c)::value;               // quarters 2 HQ, 2 HQ + 1
       float4 rv[8];
