@@ -425,8 +425,7 @@ __device__ __forceinline__ void pairacc_produce(const PairMember& pm, const Pair
   int m0, off2, xs1, lead1;
   pairacc_origin<T>(n2, m0, off2, xs1, lead1);
   const bool interior = xs1 >= 0 && xs1 + RAW1 <= L;
-  int l_ = lane;
-  asm volatile("" : "+v"(l_));
+  const int l_ = lane;                                      // (no barrier against hoisting the member's per-lane constants over the tile loop: conv_wino4_acc.hip)
   float* rdst[SPW];
 #pragma unroll
   for (int u = 0; u < SPW; ++u) {
